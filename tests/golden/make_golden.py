@@ -1,0 +1,127 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference (/root/reference)
+on CPU through oracle/ref_harness.py.  Run from the repo root, in the build
+container only:   python tests/golden/make_golden.py
+
+Each fixture stores only OUTPUTS of the reference (plus a checksum of the seeded
+inputs); the tests regenerate the inputs from the recipe in scenes.py.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import ref_harness as rh  # noqa: E402
+from tests.golden import scenes  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def input_digest(sd, batch):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    for k in sorted(batch):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(batch[k]).tobytes())
+    return h.hexdigest()
+
+
+def run_scene(name):
+    ns = rh.load()
+    r, sd, body, batch, cam, t_rand = scenes.build(name)
+    cfg = ns.cfg
+    cfg.N_samples = r["n_samples"]
+    cfg.white_bkgd = bool(r["white_bkgd"])
+    cfg.perturb = 1.0 if r["perturb"] else 0.0
+    cfg.raw_noise_std = 0.0
+    net = rh.make_reference_network(sd, train_mode=(r["mode"] == "train"))
+    ren = rh.make_reference_renderer(net)
+    tb = rh.torch_batch(batch)
+    real_rand = torch.rand
+    if t_rand is not None:
+        # if_clight_renderer.py:22 draws torch.rand(z_vals.shape); feed it a known tensor instead
+        tr = torch.from_numpy(t_rand)
+        torch.rand = lambda *a, **k: tr
+    try:
+        with torch.no_grad():
+            out = ren.render(tb)
+            # BN running statistics after exactly ONE forward (momentum 0.01, latent_xyzc.py:215)
+            bn_after_one = {k: v.clone().numpy() for k, v in net.state_dict().items()
+                            if k.endswith("running_mean") or k.endswith("running_var")}
+            # explicit-point decode (latent_xyzc.py:91-126) for a subset of rays
+            sp_input = ren.prepare_sp_input(tb)
+            vols = net.encode_sparse_voxels(sp_input)
+            sel = slice(0, None, scenes.RAW_RAY_STRIDE)
+            wpts, z_vals = ren.get_sampling_points(tb["ray_o"][:, sel], tb["ray_d"][:, sel], tb["near"][:, sel],
+                                                   tb["far"][:, sel]) if t_rand is None else (None, None)
+            raw = None
+            dens = None
+            if wpts is not None:
+                viewdir = tb["ray_d"][:, sel] / torch.norm(tb["ray_d"][:, sel], dim=2, keepdim=True)
+                raw = ren.get_density_color(
+                    wpts, viewdir, lambda x, v: net.calculate_density_color(x, v, vols, sp_input))
+                dens = net.calculate_density(wpts.view(1, -1, 3), vols, sp_input)
+    finally:
+        torch.rand = real_rand
+    g = {k: v.numpy() for k, v in out.items()}
+    g["input_digest"] = np.array(input_digest(sd, batch))
+    if raw is not None:
+        g["raw_subset"] = raw.numpy()
+        g["density_subset"] = dens.numpy()
+    if r["probes"]:
+        for li, v in enumerate(vols):
+            v = v[0].permute(1, 2, 3, 0).reshape(-1, v.shape[1]).numpy()  # [DHW, C]
+            active = np.abs(v).sum(1) > 0
+            idx = scenes.probe_indices(active)
+            g["vol%d_probe_idx" % li] = idx
+            g["vol%d_probe_val" % li] = v[idx]
+            g["vol%d_sum" % li] = np.array(v.astype(np.float64).sum())
+            g["vol%d_abs_sum" % li] = np.array(np.abs(v.astype(np.float64)).sum())
+            g["vol%d_nonzero_voxels" % li] = np.array(int(active.sum()))
+            g["vol%d_shape" % li] = np.array(vols[li].shape)
+    if r["mode"] == "train":
+        for k, v in bn_after_one.items():
+            g["bn/" + k] = v
+    path = os.path.join(OUT, "scene_%s.npz" % name)
+    np.savez_compressed(path, **g)
+    print(name, "rays", out["rgb_map"].shape[1], "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
+def run_raygen():
+    """get_rays / get_near_far (if_nerf_data_utils.py:8-21,54-69) and image_rays
+    (render_utils.py:120-137) on a non-square camera."""
+    ns = rh.load()
+    from neuralbody_amd import synthetic as syn
+
+    g = {}
+    for tag, body_kw, H, W, ff in (("a", dict(seed=3, box=(0.9, 1.7, 0.35), rh=(0.2, 0.4, 0.0), th=(0.3, 0.1, 0.2)), 40, 56, 1.1),
+                                   ("b", dict(seed=4, box=(0.3, 0.5, 0.2)), 33, 17, 3.0)):
+        body = syn.make_body(**body_kw)
+        K, R, T = syn.make_camera(body, H, W, focal_factor=ff, distance=2.2, yaw=-0.6, pitch=0.25)
+        ro, rd = ns.get_rays(H, W, K, R, T)
+        ro32 = ro.reshape(-1, 3).astype(np.float32)
+        rd32 = rd.reshape(-1, 3).astype(np.float32)
+        near, far, mask = ns.get_near_far(body["can_bounds"], ro32, rd32.copy())
+        ns.cfg.H, ns.cfg.W, ns.cfg.ratio = H, W, 1.0
+        RT = np.concatenate([R, T], 1)
+        iro, ird, inear, ifar, _c, _s, imask = ns.image_rays(RT, K, body["can_bounds"])
+        assert np.array_equal(imask, mask)
+        g.update({tag + "_ray_o": ro32[0], tag + "_ray_d": rd32.reshape(H, W, 3), tag + "_near": near.astype(np.float32),
+                  tag + "_far": far.astype(np.float32), tag + "_mask": mask, tag + "_img_near": inear, tag + "_img_far": ifar,
+                  tag + "_img_ray_d": ird})
+    path = os.path.join(OUT, "raygen.npz")
+    np.savez_compressed(path, **g)
+    print("raygen ->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen"]
+    for n in names:
+        run_raygen() if n == "raygen" else run_scene(n)

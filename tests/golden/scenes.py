@@ -1,0 +1,53 @@
+"""Scene recipes shared by the golden generator (make_golden.py, runs the reference)
+and by the tests (which regenerate the identical inputs from the seeds)."""
+import numpy as np
+
+from neuralbody_amd import synthetic as syn
+
+_SMALL_BODY = dict(seed=0, box=(0.3, 0.5, 0.2), rh=(0.1, 0.2, -0.1), th=(0.05, -0.1, 0.2))
+_SMALL_CAM = dict(H=32, W=32, focal_factor=2.5, distance=1.5)
+
+SCENES = {
+    # name: recipe.  mode 'train' == run.py's evaluate/visualise mode (net.train(), perturb=0)
+    "small": dict(weights_seed=0, num_train_frame=7, body=_SMALL_BODY, cam=_SMALL_CAM, n_samples=64,
+                  latent_index=3, mode="train", perturb=False, white_bkgd=False, probes=True),
+    "small_s128": dict(weights_seed=0, num_train_frame=7, body=_SMALL_BODY,
+                       cam=dict(H=16, W=16, focal_factor=2.5, distance=1.5), n_samples=128,
+                       latent_index=0, mode="train", perturb=False, white_bkgd=False, probes=False),
+    "small_perturb": dict(weights_seed=0, num_train_frame=7, body=_SMALL_BODY, cam=_SMALL_CAM, n_samples=64,
+                          latent_index=6, mode="train", perturb=True, white_bkgd=False, probes=False),
+    "small_eval": dict(weights_seed=0, num_train_frame=7, body=_SMALL_BODY, cam=_SMALL_CAM, n_samples=64,
+                       latent_index=1, mode="eval", perturb=False, white_bkgd=True, probes=True),
+    "full": dict(weights_seed=1, num_train_frame=5,
+                 body=dict(seed=1, box=(0.9, 1.7, 0.35), rh=(0.3, -0.2, 0.1), th=(0.1, 0.2, -0.3), layout="capsules"),
+                 cam=dict(H=24, W=20, focal_factor=1.3, distance=2.5), n_samples=64,
+                 latent_index=2, mode="train", perturb=False, white_bkgd=False, probes=True),
+}
+N_PROBES = 160
+RAW_RAY_STRIDE = 8
+
+
+def build(name):
+    """-> (recipe, state_dict_np, body, batch_np, cam(K,R,T,H,W), t_rand or None)"""
+    r = SCENES[name]
+    sd = syn.make_weights(r["weights_seed"], num_train_frame=r["num_train_frame"])
+    body = syn.make_body(**r["body"])
+    c = r["cam"]
+    K, R, T = syn.make_camera(body, c["H"], c["W"], focal_factor=c["focal_factor"], distance=c["distance"])
+    ray_o, ray_d, near, far, mask = syn.host_image_rays(c["H"], c["W"], K, R, T, body["can_bounds"])
+    batch = syn.make_batch(body, ray_o, ray_d, near, far, mask, latent_index=r["latent_index"])
+    t_rand = None
+    if r["perturb"]:
+        t_rand = np.random.RandomState(77).uniform(0, 1, (1, ray_o.shape[0], r["n_samples"])).astype(np.float32)
+        t_rand = np.minimum(t_rand, np.float32(1.0 - 2 ** -24))
+    return r, sd, body, batch, (K, R, T, c["H"], c["W"]), t_rand
+
+
+def probe_indices(mask_flat, n=N_PROBES, seed=123):
+    """Deterministic probe voxels: 3/4 from the active set, 1/4 anywhere."""
+    rs = np.random.RandomState(seed)
+    act = np.flatnonzero(mask_flat)
+    n_act = min(len(act), (3 * n) // 4)
+    a = act[rs.choice(len(act), n_act, replace=False)] if n_act else np.zeros(0, np.int64)
+    b = rs.randint(0, mask_flat.size, n - n_act)
+    return np.concatenate([a, b]).astype(np.int64)

@@ -1,0 +1,85 @@
+"""The CPU oracle (oracle/neuralbody_oracle.py) against the fixtures that
+tests/golden/make_golden.py produced by running the UNMODIFIED reference.
+Tolerances: the oracle and the reference are both fp32 CPU torch, so they agree
+to fp32 round-off (<= 5e-6 on O(1) quantities)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import neuralbody_oracle as orc
+from tests.golden import scenes
+
+TOL = 5e-6
+
+
+def _digest(sd, batch):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(sd[k]).tobytes())
+    for k in sorted(batch):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(batch[k]).tobytes())
+    return h.hexdigest()
+
+
+def _close(a, b, tol=TOL, name=""):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    nan_a, nan_b = np.isnan(a), np.isnan(b)
+    assert np.array_equal(nan_a, nan_b), name + ": NaN pattern differs"
+    err = np.abs(a[~nan_a] - b[~nan_a])
+    scale = np.maximum(1.0, np.abs(b[~nan_a]))
+    assert (err / scale).max(initial=0.0) <= tol, (name, float((err / scale).max()))
+
+
+@pytest.mark.parametrize("name", list(scenes.SCENES))
+def test_oracle_render_matches_reference_golden(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, "scene_%s.npz" % name))
+    r, sd, body, batch, cam, t_rand = scenes.build(name)
+    assert _digest(sd, batch) == str(g["input_digest"]), "seeded inputs drifted from the fixture"
+    sdt = orc.tensor_state_dict(sd)
+    stats = {}
+    with torch.no_grad():
+        out_sh = batch["out_sh"].max(0).tolist()
+        vols = orc.encode_sparse_voxels(sdt, torch.from_numpy(batch["coord"]), out_sh,
+                                        training=(r["mode"] == "train"), update_stats=stats)
+        out = orc.render(sdt, batch, n_samples=r["n_samples"], training=(r["mode"] == "train"),
+                         t_rand=None if t_rand is None else torch.from_numpy(t_rand),
+                         white_bkgd=r["white_bkgd"], feature_volume=vols)
+    for k in ("rgb_map", "disp_map", "acc_map", "weights", "depth_map"):
+        _close(out[k].numpy(), g[k], name=k)
+    if "raw_subset" in g:
+        ns = r["n_samples"]
+        raw = out["raw"].view(1, -1, ns, 4)[:, ::scenes.RAW_RAY_STRIDE].reshape(1, -1, 4)
+        _close(raw.numpy(), g["raw_subset"], tol=2e-4, name="raw")  # fp32 GEMM order differs with batch shape
+    if r["probes"]:
+        for li, v in enumerate(vols):
+            flat = v[0].permute(1, 2, 3, 0).reshape(-1, v.shape[1]).numpy()
+            assert list(v.shape) == list(g["vol%d_shape" % li])
+            _close(flat[g["vol%d_probe_idx" % li]], g["vol%d_probe_val" % li], tol=1e-4, name="vol%d" % li)  # 17 fp32 conv+BN layers
+            assert int((np.abs(flat).sum(1) > 0).sum()) == int(g["vol%d_nonzero_voxels" % li])
+            assert abs(flat.astype(np.float64).sum() - float(g["vol%d_sum" % li])) <= 1e-5 * float(g["vol%d_abs_sum" % li])
+    for k, v in stats.items():
+        _close(v.numpy(), g["bn/" + k], tol=1e-5, name=k)
+
+
+def test_oracle_raygen_matches_reference_golden(golden_dir):
+    from neuralbody_amd import synthetic as syn
+
+    g = np.load(os.path.join(golden_dir, "raygen.npz"))
+    for tag, body_kw, H, W, ff in (("a", dict(seed=3, box=(0.9, 1.7, 0.35), rh=(0.2, 0.4, 0.0), th=(0.3, 0.1, 0.2)), 40, 56, 1.1),
+                                   ("b", dict(seed=4, box=(0.3, 0.5, 0.2)), 33, 17, 3.0)):
+        body = syn.make_body(**body_kw)
+        K, R, T = syn.make_camera(body, H, W, focal_factor=ff, distance=2.2, yaw=-0.6, pitch=0.25)
+        ro, rd, near, far, mask = orc.image_rays(H, W, K, R, T, body["can_bounds"])
+        assert np.array_equal(mask, g[tag + "_mask"])
+        assert 0 < mask.sum() < mask.size or tag == "b"
+        np.testing.assert_array_equal(rd, g[tag + "_img_ray_d"])
+        np.testing.assert_array_equal(near, g[tag + "_img_near"])
+        np.testing.assert_array_equal(far, g[tag + "_img_far"])
+        np.testing.assert_array_equal(ro[0], g[tag + "_ray_o"])
