@@ -1,0 +1,188 @@
+"""bench.py — Neural Body hot-path throughput on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`): synthetic 6890-vertex SMPL scene, 512x512 image whose every pixel
+hits the SMPL bounding box, 64 samples/ray, random latents/MLP weights (neuralbody_amd/synthetic.py,
+seed 0).  One STEP = `Renderer.render(batch)` for one view per GPU: structured-latent-code encoder
+(17 sparse conv+BN+ReLU layers) + fused march (sampling, trilinear gather, MLP, compositing) of
+262 144 rays, inputs (rays, vertices, weights) resident in HBM.  With N GPUs the job is N views
+(weak scaling): rank r marches view r, then the rendered RGB tiles are all-gathered over RCCL.
+
+The JSON line also carries
+  roofline     — the dominant kernel (nb_march_kernel): algorithmic MLP flops (859 904 per ray-sample,
+                 SURVEY.md §8(d)) / its average launch duration measured with HIP events inside the timed
+                 region, against the dense fp32-MFMA peak (157.3 TFLOP/s; the kernel computes in exact fp32
+                 with v_mfma_f32_32x32x2_f32).
+  cpu_baseline — the CPU restatement of the reference (oracle/, torch CPU, all host cores) marching a
+                 bounded sample of the same rays through the same feature volumes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOP_PER_SAMPLE = 859904.0      # MLP MACs x 2 as the reference layers are written
+EXEC_FLOP_PER_SAMPLE = 663296.0  # executed: feature_fc.latent_fc merged, latent folded into a bias
+PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def build_scene(dev, H=512, W=512, n_samples=64):
+    from neuralbody_amd import ops
+    from neuralbody_amd import synthetic as syn
+    from neuralbody_amd.network import Network
+    from neuralbody_amd.renderer import RenderConfig, Renderer
+
+    sd = syn.make_weights(0, num_train_frame=230)
+    body = syn.make_body(seed=0)
+    K, R, T = syn.full_coverage_camera(body, H, W)
+    net = Network(num_train_frame=230)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net = net.to(dev)
+    net.train()  # run.py:57,89 renders in train() mode: BatchNorm uses batch statistics
+    ro, rd, near, far, mask, n = ops.raygen(H, W, K, R, T, body["can_bounds"], dev)
+    n = int(n)
+    assert n == H * W, "the throughput camera must see the bbox in every pixel (%d of %d)" % (n, H * W)
+    batch = syn.make_batch(body, np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32), np.zeros(1, np.float32),
+                           np.zeros(1, np.float32), np.ones(1, bool))
+    bd = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in batch.items()
+          if k not in ("ray_o", "ray_d", "near", "far", "mask_at_box")}
+    bd.update(ray_o=ro[None, :n], ray_d=rd[None, :n], near=near[None, :n], far=far[None, :n])
+    rend = Renderer(net, RenderConfig(N_samples=n_samples, perturb=0.0))
+    return sd, body, net, rend, bd, n
+
+
+def cpu_baseline(sd, bd, vols, n_samples, budget_s=12.0, max_rays=8192):
+    """The oracle (CPU restatement of the reference, chunked by 2048 rays like if_clight_renderer.py:107)
+    marching a bounded sample of the bench rays through the same feature volumes."""
+    from oracle import neuralbody_oracle as orc
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    sdt = orc.tensor_state_dict(sd)
+    vols_cpu = [v.detach().cpu().contiguous() for v in vols]  # NCDHW like the reference's .dense()
+    n = bd["ray_o"].shape[1]
+    sel = torch.linspace(0, n - 1, max_rays).long()
+    b = {k: v.detach().cpu() for k, v in bd.items()}
+    done, t_total = 0, 0.0
+    with torch.no_grad():
+        for i in range(0, max_rays, 2048):
+            idx = sel[i:i + 2048]
+            bb = dict(b)
+            bb.update(ray_o=b["ray_o"][:, idx], ray_d=b["ray_d"][:, idx], near=b["near"][:, idx], far=b["far"][:, idx])
+            t0 = time.perf_counter()
+            orc.render({k: v for k, v in sdt.items()}, bb, n_samples=n_samples, training=True, feature_volume=vols_cpu)
+            dt = time.perf_counter() - t0
+            done += len(idx)
+            t_total += dt
+            if t_total > budget_s:
+                break
+    return {"value": done * n_samples / t_total, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+            "kind": "port", "rays_per_s": done / t_total,
+            "sample": "%d of the bench rays x %d samples, march only (K2-K8) on precomputed feature volumes, "
+                      "%.1f s of oracle/neuralbody_oracle.py (torch CPU %s)" % (done, n_samples, t_total, torch.__version__)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--samples", type=int, default=64)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
+                         % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)  # RCCL over xGMI
+
+    from neuralbody_amd import ops
+    from neuralbody_amd.parallel import all_gather_tiles
+
+    H = W = args.size
+    sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples)
+    S = args.samples
+
+    def step():
+        out = rend.render(bd)
+        if world > 1:
+            return all_gather_tiles(out["rgb_map"][0], dist.group.WORLD)
+        return out["rgb_map"][0]
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ops.MARCH_EVENTS = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        events, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
+    march_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_rays = n_rays * world * args.steps
+    samples_per_s = total_rays * S / elapsed
+    achieved_tflops = FLOP_PER_SAMPLE * n_rays * S / (march_ms * 1e-3) / 1e12
+    result = {
+        "metric": "ray_samples_per_sec", "value": samples_per_s, "unit": "ray-samples/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rays_per_sec": total_rays / elapsed,
+        "config": {"workload": "synthetic 6890-vertex SMPL scene, %dx%d full-coverage view, %d samples/ray, "
+                               "Renderer.render = encoder + fused march, one view per GPU per step" % (H, W, S),
+                   "rays_per_view": n_rays, "out_sh": [int(s) for s in body["out_sh"]],
+                   "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
+        "roofline": {"bound": "mfma", "kernel": "nb_march_kernel", "achieved": achieved_tflops,
+                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+                     "traffic": None, "avg_launch_ms": march_ms,
+                     "executed_tflops": EXEC_FLOP_PER_SAMPLE * n_rays * S / (march_ms * 1e-3) / 1e12,
+                     "note": "achieved = 859904 algorithmic flop/sample x %d samples/launch / avg launch time; the kernel "
+                             "executes 663296 flop/sample (feature_fc.latent_fc merged, latent folded into a bias), so "
+                             "executed_tflops/peak is the MFMA-pipe occupancy" % (n_rays * S)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        with torch.no_grad():
+            vols = net.encode_sparse_voxels(rend.prepare_sp_input(bd))
+        result["cpu_baseline"] = cpu_baseline(sd, bd, vols, S)
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+/*
+ * nb_hip.h — C ABI of libnb_hip.so, the MI355X (gfx950) implementation of the
+ * Neural Body rendering hot path.
+ *
+ * Conventions:
+ *   - every entry point returns 0 on success, a negative NB_E* code on failure;
+ *     nb_last_error() returns a thread-local description of the last failure.
+ *     Nothing throws across the ABI, nothing calls exit().
+ *   - all pointers marked "dev" are DEVICE pointers owned by the caller (PyTorch-ROCm
+ *     tensors: tensor.data_ptr()).  The library never allocates or frees user-visible
+ *     memory and keeps no hidden state between calls.
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     work is enqueued asynchronously, no entry point synchronises the device.
+ *   - floats are fp32, indices int32 unless stated.
+ *
+ * Each entry point names the reference interface it replaces (paths are into
+ * zju3dv/neuralbody, i.e. /root/reference).
+ */
+#ifndef NB_HIP_H
+#define NB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NB_OK 0
+#define NB_EINVAL (-1)  /* bad argument (null pointer, unsupported size) */
+#define NB_ELAUNCH (-2) /* HIP launch / runtime error */
+#define NB_ENODEV (-3)  /* no gfx950 device */
+
+#define NB_ABI_VERSION 1
+
+/* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
+#define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */
+#define NB_HID 256
+#define NB_VIEW_HID 128
+#define NB_N_LEVELS 4
+
+const char *nb_last_error(void);
+int nb_abi_version(void);
+/* returns the number of visible HIP devices (>=0) or a negative error */
+int nb_device_count(void);
+
+/* ---------------------------------------------------------------------------------
+ * Scene description shared by the decode / march entry points.
+ * Mirrors `sp_input` built at lib/networks/renderer/if_clight_renderer.py:29-52 plus
+ * the four feature volumes returned by Network.encode_sparse_voxels
+ * (lib/networks/latent_xyzc.py:30-39).  Volumes are CHANNELS-LAST: vol[l] is a dense
+ * [D_l, H_l, W_l, C_l] fp32 array (C_l = 32, 64, 128, 128), zeros at inactive voxels.
+ * ------------------------------------------------------------------------------- */
+typedef struct nb_scene {
+    const float *vol[NB_N_LEVELS]; /* dev */
+    int32_t vol_dhw[NB_N_LEVELS][3];
+    float R[9];          /* row-major 3x3; canonical = (p_world - Th) @ R  (latent_xyzc.py:41-47) */
+    float Th[3];
+    float bounds_min[3]; /* SMPL-space AABB minimum, xyz order (sp_input['bounds'][0]) */
+    float voxel_size[3]; /* cfg.voxel_size, dhw order (latent_xyzc.py:54) */
+    int32_t out_sh[3];   /* full-resolution grid D,H,W (sp_input['out_sh']) */
+} nb_scene;
+
+/* ---------------------------------------------------------------------------------
+ * Packed decoder weights.  nb_mlp_pack_size() floats; produced by nb_mlp_pack() from
+ * the reference's parameter tensors (Conv1d(k=1) weights [out,in,1] viewed as [out,in]).
+ * The packing re-orders every layer into MFMA A-operand fragment order and merges
+ * feature_fc with the first 256 columns of latent_fc (no activation sits between them,
+ * latent_xyzc.py:106-111).  nb_mlp_latent_bias() folds the per-frame latent code
+ * (latent_xyzc.py:108-111) into that merged layer's bias; call it whenever
+ * latent_index or the parameters change.
+ * ------------------------------------------------------------------------------- */
+int64_t nb_mlp_pack_size(void);        /* floats in the packed blob */
+int64_t nb_mlp_latent_bias_size(void); /* floats in the per-frame bias (256) */
+
+typedef struct nb_mlp_params { /* all dev, row-major [out,in] / [out] */
+    const float *fc0_w, *fc0_b;         /* [256,352] */
+    const float *fc1_w, *fc1_b;         /* [256,256] */
+    const float *fc2_w, *fc2_b;         /* [256,256] */
+    const float *alpha_w, *alpha_b;     /* [1,256]   */
+    const float *feature_w, *feature_b; /* [256,256] */
+    const float *latent_w, *latent_b;   /* [256,384] */
+    const float *view_w, *view_b;       /* [128,346] */
+    const float *rgb_w, *rgb_b;         /* [3,128]   */
+} nb_mlp_params;
+
+/* replaces: module parameter access in Network.calculate_density_color
+ * (lib/networks/latent_xyzc.py:99-121).  `packed` dev, nb_mlp_pack_size() floats. */
+int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream);
+/* latent_row: dev pointer to latent.weight[latent_index] (128 floats);
+ * out: dev, nb_mlp_latent_bias_size() floats. */
+int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * nb_decode_points — replaces Network.calculate_density_color
+ * (lib/networks/latent_xyzc.py:91-126) and, with density_only != 0,
+ * Network.calculate_density (:74-89).
+ *   wpts    dev [n,3] world-space points; viewdir dev [n,3] (ignored when density_only)
+ *   raw_out dev [n,4] (rgb logits, sigma)   or [n,1] sigma when density_only
+ *   dbg     dev or NULL: when non-NULL receives, per point, [352 features | 256 h3 |
+ *           256 merged-latent layer output | 128 view hidden] = 992 floats (tests only)
+ * ------------------------------------------------------------------------------- */
+int nb_decode_points(const nb_scene *scene, const float *packed, const float *latent_bias,
+                     const float *wpts, const float *viewdir, int64_t n, int density_only,
+                     float *raw_out, float *dbg, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * nb_march — the fused per-ray path: replaces Renderer.get_pixel_value
+ * (lib/networks/renderer/if_clight_renderer.py:62-92), i.e. get_sampling_points (:11-27),
+ * get_density_color (:54-60), Network.calculate_density_color and raw2outputs
+ * (lib/networks/renderer/nerf_net_utils.py:6-51, raw_noise_std = 0), for ALL rays of a
+ * batch element in one launch (the reference's 2048-ray chunk loop :107-118 disappears).
+ *   ray_o, ray_d dev [n_rays,3]; near, far dev [n_rays]
+ *   t_vals  dev [n_samples]  = torch.linspace(0,1,n_samples)   (if_clight_renderer.py:13)
+ *   t_rand  dev [n_rays,n_samples] in [0,1) or NULL            (stratified jitter, :16-23)
+ *   outputs dev: rgb_map [n_rays,3], disp_map/acc_map/depth_map [n_rays],
+ *           weights [n_rays,n_samples]; raw (optional, may be NULL) [n_rays,n_samples,4]
+ * ------------------------------------------------------------------------------- */
+int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias,
+             const float *ray_o, const float *ray_d, const float *near, const float *far,
+             int64_t n_rays, int32_t n_samples, const float *t_vals, const float *t_rand,
+             int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
+             float *depth_map, float *raw, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * nb_composite — raw2outputs alone (lib/networks/renderer/nerf_net_utils.py:6-51) for
+ * callers that decode points themselves (the _mmsk/_msk renderers).
+ *   raw dev [n_rays,n_samples,4]; z_vals dev [n_rays,n_samples]; ray_d dev [n_rays,3]
+ * ------------------------------------------------------------------------------- */
+int nb_composite(const float *raw, const float *z_vals, const float *ray_d, int64_t n_rays,
+                 int32_t n_samples, int white_bkgd, float *rgb_map, float *disp_map,
+                 float *acc_map, float *weights, float *depth_map, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Structured-latent-code encoder — replaces Network.encode_sparse_voxels
+ * (lib/networks/latent_xyzc.py:30-39) + SparseConvNet.forward (:184-205) and the spconv
+ * v1.2.1 calls inside (SubMConv3d / SparseConv3d / BatchNorm1d / ReLU / .dense()).
+ * A sparse tensor is (rows [n,C] fp32, coords [n] linear voxel index, index grid
+ * [D,H,W] int32 holding the row id or -1).
+ * ------------------------------------------------------------------------------- */
+
+/* Voxelise the SMPL vertices: dedup (last vertex index wins, spconv_standin rule),
+ * build the index grid and compact row list.
+ *   coord dev [n_verts,3] (d,h,w) int32; grid dev [D*H*W] int32 (overwritten);
+ *   rows_vert dev [n_verts] int32 out: vertex id feeding each row; rows_lin dev [n_verts]
+ *   int32 out: linear voxel index of each row; n_rows dev [1] int32 out.
+ *   scratch dev: at least nb_scan_scratch_size(n_verts) bytes. */
+int64_t nb_scan_scratch_size(int64_t n);
+int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3], int32_t *grid,
+                    int32_t *rows_vert, int32_t *rows_lin, int32_t *n_rows, void *scratch,
+                    void *stream);
+
+/* Output active set of SparseConv3d(k=3, s=2, p=1) (latent_xyzc.py:265-274): every output
+ * site with >=1 active input in its 3^3 receptive field, rows numbered in linear-voxel
+ * order.  in_lin dev [n_in_max] with *n_in valid (device count); out grid dev [Do*Ho*Wo]. */
+int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t n_in_max,
+                            const int32_t in_dhw[3], const int32_t out_dhw[3], int32_t *out_grid,
+                            int32_t *out_lin, int32_t *n_out, int32_t n_out_max, void *scratch,
+                            void *stream);
+
+/* One sparse 3x3x3 convolution (stride 1 submanifold or stride 2) without bias:
+ *   out[r, :] = sum_o W[o] . in[nbr(r, o), :]   over ACTIVE neighbours
+ * and per-channel sum / sum of squares of the result rows (fp64) for BatchNorm.
+ *   weight dev [3,3,3,Cin,Cout] (spconv 1.x layout); in_rows dev [n_in,Cin];
+ *   in_grid dev index grid of the INPUT tensor; out_lin dev [n_out_max] linear voxel index
+ *   of each OUTPUT row in the OUTPUT grid; n_out dev [1]; stats dev [2*Cout] fp64 (zeroed
+ *   by the call). */
+int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3],
+                const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max,
+                const int32_t out_dhw[3], int32_t stride, const float *weight, int32_t cin,
+                int32_t cout, float *out_rows, double *stats, void *stream);
+
+/* BatchNorm1d(eps=1e-3) over active rows + ReLU, in place (latent_xyzc.py:208-274).
+ * training != 0: normalise with the batch statistics in `stats` (biased variance) and
+ * write [mean | biased var | n_rows] (2*C+1 floats) to batch_stats (dev, may be NULL);
+ * training == 0: use running_mean / running_var.
+ * dense (dev or NULL): channels-last [D,H,W,C] volume receiving the rows (.dense(),
+ * latent_xyzc.py:189-201); it must have been zero-filled by the caller. */
+int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c,
+                   const double *stats, const float *gamma, const float *beta,
+                   const float *running_mean, const float *running_var, int training, float eps,
+                   float *batch_stats, const int32_t *rows_lin, float *dense, void *stream);
+
+/* Embedding lookup of the per-vertex codes (latent_xyzc.py:33-34): rows[r,:] = c[rows_vert[r],:] */
+int nb_enc_gather_codes(const float *codes, const int32_t *rows_vert, const int32_t *n_rows,
+                        int32_t n_rows_max, int32_t c, float *rows, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * nb_raygen — replaces lib/utils/render_utils.py:120-137 (image_rays), i.e. get_rays
+ * (lib/utils/if_nerf/if_nerf_data_utils.py:8-21) + get_near_far (:54-69) + compaction by
+ * mask_at_box, on device.  K, R (row-major 3x3) and T (3) are HOST doubles.
+ *   bounds: host float[6] world-space AABB (min xyz, max xyz)
+ *   outputs dev: ray_o, ray_d [H*W,3]; near, far [H*W] (first *n_rays rows valid, pixel
+ *   order preserved); mask_at_box [H*W] uint8; n_rays dev [1] int32.
+ *   scratch dev: nb_scan_scratch_size(H*W) bytes. */
+int nb_raygen(int32_t H, int32_t W, const double K[9], const double R[9], const double T[3],
+              const float bounds[6], float *ray_o, float *ray_d, float *near, float *far,
+              uint8_t *mask_at_box, int32_t *n_rays, void *scratch, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NB_HIP_H */

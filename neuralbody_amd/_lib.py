@@ -1,0 +1,105 @@
+"""ctypes binding of libnb_hip.so (include/nb_hip.h).  PyTorch-ROCm tensors in, raw device
+pointers out.  There is NO fallback: if the library is missing or a call fails this raises."""
+import ctypes as C
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libnb_hip.so")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
+
+NB_N_LEVELS = 4
+
+
+class NbScene(C.Structure):
+    _fields_ = [
+        ("vol", C.c_void_p * NB_N_LEVELS),
+        ("vol_dhw", (C.c_int32 * 3) * NB_N_LEVELS),
+        ("R", C.c_float * 9),
+        ("Th", C.c_float * 3),
+        ("bounds_min", C.c_float * 3),
+        ("voxel_size", C.c_float * 3),
+        ("out_sh", C.c_int32 * 3),
+    ]
+
+
+MLP_PARAM_FIELDS = ["fc0_w", "fc0_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "alpha_w", "alpha_b", "feature_w",
+                    "feature_b", "latent_w", "latent_b", "view_w", "view_b", "rgb_w", "rgb_b"]
+
+
+class NbMlpParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in MLP_PARAM_FIELDS]
+
+
+_P = C.c_void_p
+_I32 = C.c_int32
+_I64 = C.c_int64
+_I32x3 = C.c_int32 * 3
+
+# name -> (restype, argtypes); must list every function include/nb_hip.h declares
+SIGNATURES = {
+    "nb_last_error": (C.c_char_p, []),
+    "nb_abi_version": (C.c_int, []),
+    "nb_device_count": (C.c_int, []),
+    "nb_mlp_pack_size": (_I64, []),
+    "nb_mlp_latent_bias_size": (_I64, []),
+    "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
+    "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),
+    "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, _P]),
+    "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_int, _P, _P, _P, _P,
+                           _P, _P, _P]),
+    "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "nb_scan_scratch_size": (_I64, [_I64]),
+    "nb_enc_voxelize": (C.c_int, [_P, _I32, _I32x3, _P, _P, _P, _P, _P, _P]),
+    "nb_enc_downsample_index": (C.c_int, [_P, _P, _I32, _I32x3, _I32x3, _P, _P, _P, _I32, _P, _P]),
+    "nb_enc_conv": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _P]),
+    "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P]),
+    "nb_enc_gather_codes": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
+    "nb_raygen": (C.c_int, [_I32, _I32, C.c_double * 9, C.c_double * 9, C.c_double * 3, C.c_float * 6, _P, _P, _P,
+                            _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class NbError(RuntimeError):
+    pass
+
+
+def header_functions():
+    """Names of all functions declared in include/nb_hip.h (used by the export test)."""
+    with open(HEADER) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    """Load libnb_hip.so (once).  Raises NbError when it has not been built — the product path
+    never substitutes another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NbError("libnb_hip.so is missing (%s). Build it with `python -m neuralbody_amd.build`; "
+                      "there is no non-HIP fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if L.nb_abi_version() != 1:
+        raise NbError("libnb_hip.so ABI version %d, expected 1" % L.nb_abi_version())
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().nb_last_error()
+        raise NbError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())

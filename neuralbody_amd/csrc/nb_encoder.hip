@@ -1,0 +1,351 @@
+// nb_encoder.hip — structured-latent-code encoder for gfx950: a from-scratch replacement of the
+// spconv v1.2.1 calls made by SparseConvNet (zju3dv/neuralbody lib/networks/latent_xyzc.py:166-274).
+//
+// Data structure: a sparse tensor is a compact row matrix [n_rows, C] (fp32) + a dense int32
+// INDEX GRID [D,H,W] holding the row id of every voxel (-1 = inactive) + the linear voxel index
+// of every row.  With <=7 M voxels at full resolution the grid is 28 MB — trivial next to 288 GB
+// of HBM — and turns spconv's hash-table rulebook into one coalescible int32 load per neighbour.
+//
+// Convolution: each WAVE owns 32 output rows x all Cout channels.  For every kernel offset with at
+// least one active neighbour in the tile (wave-uniform skip otherwise) it gathers the 32
+// neighbour rows (each half-wave fetches one half of the channels with 16-byte loads) and runs
+// v_mfma_f32_32x32x2_f32 with the gathered activations as A and the weight slab W[o] (read in its
+// native spconv [kD,kH,kW,Cin,Cout] layout, 128-byte coalesced) as B.  Exact fp32 — BatchNorm with
+// batch statistics follows every conv, so the encoder is not a place to drop precision.
+// Per-channel sum / sum-of-squares of the conv output are accumulated in fp64 (one atomic per
+// channel per wave) for the BatchNorm that follows.
+//
+// Semantics (spconv source is not available offline -> "parity unpinned" against
+// spconv itself, pinned against oracle/spconv_standin.py):
+//   SubMConv3d(k=3):           out[p] = sum_k W[k] . in[p + k - 1], active set unchanged
+//   SparseConv3d(k=3,s=2,p=1): out[o] = sum_k W[k] . in[2 o - 1 + k], active where any input is
+//   BatchNorm1d(eps=1e-3) over ACTIVE rows, then ReLU;  .dense() -> zeros at inactive sites
+//   duplicate vertex coordinates: the LAST vertex wins; BN counts unique voxels
+#include "nb_scan.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+struct Dims {
+    int d, h, w;
+};
+
+__host__ __device__ constexpr int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ------------------------------------------------------------------ voxelisation
+__global__ void vox_scatter_kernel(const int *__restrict__ coord, int n, Dims g, int *__restrict__ grid) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int d = coord[v * 3], h = coord[v * 3 + 1], w = coord[v * 3 + 2];
+    if ((unsigned)d >= (unsigned)g.d || (unsigned)h >= (unsigned)g.h || (unsigned)w >= (unsigned)g.w) return;
+    atomicMax(&grid[((long long)d * g.h + h) * g.w + w], v);  // last vertex wins
+}
+
+__global__ void vox_flag_kernel(const int *__restrict__ coord, int n, Dims g, const int *__restrict__ grid,
+                                int *__restrict__ flags) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int d = coord[v * 3], h = coord[v * 3 + 1], w = coord[v * 3 + 2];
+    int f = 0;
+    if ((unsigned)d < (unsigned)g.d && (unsigned)h < (unsigned)g.h && (unsigned)w < (unsigned)g.w)
+        f = grid[((long long)d * g.h + h) * g.w + w] == v;
+    flags[v] = f;
+}
+
+__global__ void vox_assign_kernel(const int *__restrict__ coord, int n, Dims g, const int *__restrict__ flags,
+                                  const int *__restrict__ pos, int *__restrict__ grid, int *__restrict__ rows_vert,
+                                  int *__restrict__ rows_lin) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !flags[v]) return;
+    const int d = coord[v * 3], h = coord[v * 3 + 1], w = coord[v * 3 + 2];
+    const int lin = (d * g.h + h) * g.w + w;
+    const int r = pos[v];
+    rows_vert[r] = v;
+    rows_lin[r] = lin;
+    grid[lin] = r;
+}
+
+// ------------------------------------------------------------------ strided-conv output index set
+__global__ void down_mark_kernel(const int *__restrict__ in_lin, const int *__restrict__ n_in, Dims gi, Dims go,
+                                 int *__restrict__ out_grid) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_in) return;
+    const int lin = in_lin[r];
+    const int x = lin % gi.w, y = (lin / gi.w) % gi.h, z = lin / (gi.w * gi.h);
+    // input i feeds outputs o with 2o-1 <= i <= 2o+1:  o = i/2, and (i+1)/2 when i is odd
+    const int oz[2] = {z >> 1, (z + 1) >> 1}, oy[2] = {y >> 1, (y + 1) >> 1}, ox[2] = {x >> 1, (x + 1) >> 1};
+    for (int a = 0; a < 1 + (z & 1); ++a)
+        for (int b = 0; b < 1 + (y & 1); ++b)
+            for (int c = 0; c < 1 + (x & 1); ++c)
+                if (oz[a] < go.d && oy[b] < go.h && ox[c] < go.w)
+                    out_grid[((long long)oz[a] * go.h + oy[b]) * go.w + ox[c]] = 0;  // mark (any value >= 0)
+}
+
+__global__ void grid_flag_kernel(const int *__restrict__ grid, long long n, int *__restrict__ flags) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = grid[i] >= 0;
+}
+
+__global__ void grid_assign_kernel(int *__restrict__ grid, long long n, const int *__restrict__ pos, int cap,
+                                   int *__restrict__ out_lin) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || grid[i] < 0) return;
+    const int r = pos[i];
+    grid[i] = r < cap ? r : -1;
+    if (r < cap) out_lin[r] = (int)i;
+}
+
+__global__ void clamp_count_kernel(int *n, int cap) {
+    if (*n > cap) *n = cap;
+}
+
+// ------------------------------------------------------------------ sparse 3x3x3 convolution
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_rows, const int *__restrict__ in_grid,
+                                                   Dims gi, const int *__restrict__ out_lin,
+                                                   const int *__restrict__ n_out, Dims go, int stride,
+                                                   const float *__restrict__ weight, float *__restrict__ out_rows,
+                                                   double *__restrict__ stats) {
+    constexpr int NT = (COUT + 31) / 32, HALF = CIN / 2;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = *n_out;
+    const int row0 = wave * 32;
+    if (row0 >= n) return;  // wave-uniform
+    const int row = row0 + i;
+    const bool valid = row < n;
+    const int lin = valid ? out_lin[row] : 0;
+    const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int o = 0; o < 27; ++o) {
+        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
+        int nbr = -1;
+        if (valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
+            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+        if (!__any(nbr >= 0)) continue;  // nothing active under this offset for the whole tile
+        float A[HALF];
+        if (nbr >= 0) {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(in_rows + (size_t)nbr * CIN + hi * HALF);
+#pragma unroll
+            for (int q = 0; q < HALF / 4; ++q) {
+                const f32x4 v = p[q];
+                A[4 * q] = v.x;
+                A[4 * q + 1] = v.y;
+                A[4 * q + 2] = v.z;
+                A[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < HALF; ++c) A[c] = 0.f;
+        }
+        const float *wo = weight + ((size_t)o * CIN + hi * HALF) * COUT + i;  // B[k=hi][j=i]
+#pragma unroll
+        for (int c = 0; c < HALF; ++c) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = t * 32 + i;
+                const float b = (COUT % 32 == 0 || co < COUT) ? wo[(size_t)c * COUT + t * 32] : 0.f;
+                acc[t] = NB_MFMA(A[c], b, acc[t]);
+            }
+        }
+    }
+    // D fragment: lane (j = i, hi) holds channel t*32 + j of rows row0 + tile_row(r, hi)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = t * 32 + i;
+        const bool cok = (COUT % 32 == 0) || co < COUT;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = row0 + tile_row(r, hi);
+            const float v = acc[t][r];
+            if (orow < n && cok) {
+                out_rows[(size_t)orow * COUT + co] = v;
+                s += (double)v;
+                ss += (double)v * (double)v;
+            }
+        }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (hi == 0 && cok) {
+            atomicAdd(&stats[co], s);
+            atomicAdd(&stats[COUT + co], ss);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ BatchNorm1d + ReLU (+ .dense())
+__global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__ n_rows, int C,
+                               const double *__restrict__ stats, const float *__restrict__ gamma,
+                               const float *__restrict__ beta, const float *__restrict__ rmean,
+                               const float *__restrict__ rvar, int training, float eps,
+                               float *__restrict__ batch_stats, const int *__restrict__ rows_lin,
+                               float *__restrict__ dense) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *n_rows;
+    if (batch_stats && idx <= C) {
+        if (idx == C) {
+            batch_stats[2 * C] = (float)n;
+        } else if (training && n > 0) {
+            const double m = stats[idx] / n;
+            batch_stats[idx] = (float)m;
+            batch_stats[C + idx] = (float)fmax(stats[C + idx] / n - m * m, 0.0);
+        } else {
+            batch_stats[idx] = 0.f;
+            batch_stats[C + idx] = 0.f;
+        }
+    }
+    if (idx >= (long long)n * C) return;
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    double mean, var;
+    if (training) {
+        mean = stats[c] / n;
+        var = fmax(stats[C + c] / n - mean * mean, 0.0);
+    } else {
+        mean = rmean[c];
+        var = rvar[c];
+    }
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float a = (float)(invstd * (double)gamma[c]);
+    const float b = (float)((double)beta[c] - mean * invstd * (double)gamma[c]);
+    const float y = fmaxf(fmaf(rows[idx], a, b), 0.f);
+    rows[idx] = y;
+    if (dense) dense[(size_t)rows_lin[r] * C + c] = y;
+}
+
+__global__ void gather_codes_kernel(const float *__restrict__ codes, const int *__restrict__ rows_vert,
+                                    const int *__restrict__ n_rows, int C, float *__restrict__ rows) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)(*n_rows) * C) return;
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    rows[idx] = codes[(size_t)rows_vert[r] * C + c];
+}
+
+template <int CIN, int COUT>
+void launch_conv(int n_out_max, hipStream_t st, const float *in_rows, const int *in_grid, Dims gi, const int *out_lin,
+                 const int *n_out, Dims go, int stride, const float *weight, float *out_rows, double *stats) {
+    hipLaunchKernelGGL((conv_kernel<CIN, COUT>), dim3(nb_ceil_div(n_out_max, 128)), dim3(256), 0, st, in_rows, in_grid,
+                       gi, out_lin, n_out, go, stride, weight, out_rows, stats);
+}
+
+}  // namespace
+
+extern "C" {
+
+int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3], int32_t *grid, int32_t *rows_vert,
+                    int32_t *rows_lin, int32_t *n_rows, void *scratch, void *stream) {
+    NB_REQUIRE(coord && dhw && grid && rows_vert && rows_lin && n_rows && scratch, "nb_enc_voxelize: NULL pointer");
+    NB_REQUIRE(n_verts >= 0 && dhw[0] > 0 && dhw[1] > 0 && dhw[2] > 0, "nb_enc_voxelize: bad sizes");
+    NB_REQUIRE((long long)dhw[0] * dhw[1] * dhw[2] < (1LL << 31), "nb_enc_voxelize: grid too large for int32 indices");
+    hipStream_t st = (hipStream_t)stream;
+    const Dims g = {dhw[0], dhw[1], dhw[2]};
+    const long long nvox = (long long)g.d * g.h * g.w;
+    NB_HIP(hipMemsetAsync(grid, 0xFF, nvox * sizeof(int), st));
+    if (n_verts == 0) {
+        NB_HIP(hipMemsetAsync(n_rows, 0, sizeof(int), st));
+        return NB_OK;
+    }
+    int *flags, *pos, *bs;
+    nb_scan_carve(scratch, n_verts, &flags, &pos, &bs);
+    const dim3 grd(nb_ceil_div(n_verts, 256)), blk(256);
+    hipLaunchKernelGGL(vox_scatter_kernel, grd, blk, 0, st, coord, n_verts, g, grid);
+    hipLaunchKernelGGL(vox_flag_kernel, grd, blk, 0, st, coord, n_verts, g, grid, flags);
+    if (int rc = nb_exclusive_scan(flags, pos, n_rows, n_verts, bs, st)) return rc;
+    hipLaunchKernelGGL(vox_assign_kernel, grd, blk, 0, st, coord, n_verts, g, flags, pos, grid, rows_vert, rows_lin);
+    NB_CHECK_LAUNCH("nb_enc_voxelize");
+    return NB_OK;
+}
+
+int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3],
+                            const int32_t out_dhw[3], int32_t *out_grid, int32_t *out_lin, int32_t *n_out,
+                            int32_t n_out_max, void *scratch, void *stream) {
+    NB_REQUIRE(in_lin && n_in && in_dhw && out_dhw && out_grid && out_lin && n_out && scratch,
+               "nb_enc_downsample_index: NULL pointer");
+    NB_REQUIRE(n_in_max >= 0 && n_out_max >= 0, "nb_enc_downsample_index: negative capacity");
+    const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]}, go = {out_dhw[0], out_dhw[1], out_dhw[2]};
+    for (int k = 0; k < 3; ++k)
+        NB_REQUIRE(out_dhw[k] == (in_dhw[k] + 2 - 3) / 2 + 1 && in_dhw[k] > 0,
+                   "nb_enc_downsample_index: out_dhw[%d] = %d is not floor((%d - 1) / 2) + 1", k, out_dhw[k], in_dhw[k]);
+    hipStream_t st = (hipStream_t)stream;
+    const long long nvox = (long long)go.d * go.h * go.w;
+    NB_HIP(hipMemsetAsync(out_grid, 0xFF, nvox * sizeof(int), st));
+    int *flags, *pos, *bs;
+    nb_scan_carve(scratch, nvox, &flags, &pos, &bs);
+    if (n_in_max > 0)
+        hipLaunchKernelGGL(down_mark_kernel, dim3(nb_ceil_div(n_in_max, 256)), dim3(256), 0, st, in_lin, n_in, gi, go,
+                           out_grid);
+    hipLaunchKernelGGL(grid_flag_kernel, dim3(nb_ceil_div(nvox, 256)), dim3(256), 0, st, out_grid, nvox, flags);
+    if (int rc = nb_exclusive_scan(flags, pos, n_out, nvox, bs, st)) return rc;
+    hipLaunchKernelGGL(grid_assign_kernel, dim3(nb_ceil_div(nvox, 256)), dim3(256), 0, st, out_grid, nvox, pos,
+                       n_out_max, out_lin);
+    hipLaunchKernelGGL(clamp_count_kernel, dim3(1), dim3(1), 0, st, n_out, n_out_max);
+    NB_CHECK_LAUNCH("nb_enc_downsample_index");
+    return NB_OK;
+}
+
+int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3], const int32_t *out_lin,
+                const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride, const float *weight,
+                int32_t cin, int32_t cout, float *out_rows, double *stats, void *stream) {
+    NB_REQUIRE(in_rows && in_grid && in_dhw && out_lin && n_out && out_dhw && weight && out_rows && stats,
+               "nb_enc_conv: NULL pointer");
+    NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv: stride %d", stride);
+    hipStream_t st = (hipStream_t)stream;
+    const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]}, go = {out_dhw[0], out_dhw[1], out_dhw[2]};
+    NB_HIP(hipMemsetAsync(stats, 0, 2 * (size_t)cout * sizeof(double), st));
+    if (n_out_max <= 0) return NB_OK;
+#define NB_CONV_CASE(CI, CO)                                                                                     \
+    if (cin == CI && cout == CO) {                                                                               \
+        launch_conv<CI, CO>(n_out_max, st, in_rows, in_grid, gi, out_lin, n_out, go, stride, weight, out_rows, stats); \
+        NB_CHECK_LAUNCH("nb_enc_conv");                                                                          \
+        return NB_OK;                                                                                            \
+    }
+    NB_CONV_CASE(16, 16)
+    NB_CONV_CASE(16, 32)
+    NB_CONV_CASE(32, 32)
+    NB_CONV_CASE(32, 64)
+    NB_CONV_CASE(64, 64)
+    NB_CONV_CASE(64, 128)
+    NB_CONV_CASE(128, 128)
+#undef NB_CONV_CASE
+    nb_set_error("nb_enc_conv: unsupported channel pair %d -> %d", cin, cout);
+    return NB_EINVAL;
+}
+
+int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c, const double *stats,
+                   const float *gamma, const float *beta, const float *running_mean, const float *running_var,
+                   int training, float eps, float *batch_stats, const int32_t *rows_lin, float *dense, void *stream) {
+    NB_REQUIRE(rows && n_rows && gamma && beta, "nb_enc_bn_relu: NULL pointer");
+    NB_REQUIRE(training ? stats != nullptr : (running_mean && running_var), "nb_enc_bn_relu: statistics missing");
+    NB_REQUIRE(!dense || rows_lin, "nb_enc_bn_relu: rows_lin required with dense");
+    NB_REQUIRE(c > 0 && n_rows_max >= 0, "nb_enc_bn_relu: bad sizes");
+    const long long total = (long long)n_rows_max * c;
+    const long long threads = total > c + 1 ? total : c + 1;
+    hipLaunchKernelGGL(bn_relu_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_rows,
+                       c, stats, gamma, beta, running_mean, running_var, training, eps, batch_stats, rows_lin, dense);
+    NB_CHECK_LAUNCH("nb_enc_bn_relu");
+    return NB_OK;
+}
+
+int nb_enc_gather_codes(const float *codes, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,
+                        int32_t c, float *rows, void *stream) {
+    NB_REQUIRE(codes && rows_vert && n_rows && rows, "nb_enc_gather_codes: NULL pointer");
+    if (n_rows_max <= 0) return NB_OK;
+    hipLaunchKernelGGL(gather_codes_kernel, dim3(nb_ceil_div((long long)n_rows_max * c, 256)), dim3(256), 0,
+                       (hipStream_t)stream, codes, rows_vert, n_rows, c, rows);
+    NB_CHECK_LAUNCH("nb_enc_gather_codes");
+    return NB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// nb_raygen.hip — full-image ray generation + SMPL-bbox intersection + compaction on device.
+//
+// Restates (zju3dv/neuralbody):
+//   lib/utils/if_nerf/if_nerf_data_utils.py:8-21   get_rays      (float64 like numpy: K is float64)
+//   lib/utils/if_nerf/if_nerf_data_utils.py:54-69  get_near_far  (float32; uses the FIRST ray's origin)
+//   lib/utils/render_utils.py:120-137              image_rays    (cast to float32, compact by mask)
+// One thread per pixel; mask -> exclusive scan -> ordered compaction, so the surviving rays keep
+// the reference's row-major pixel order (visualizers re-assemble with img[mask_at_box] = rgb).
+#include "nb_scan.h"
+
+namespace {
+
+struct RayCam {
+    double Kinv[9];  // inv(K), row-major
+    double R[9];
+    double T[3];
+    double o[3];  // -R^T T
+    float bmin[3], bmax[3];
+};
+
+__device__ __forceinline__ void pixel_ray(const RayCam &c, int px, int py, float (&o)[3], float (&d)[3]) {
+    // xy1 is float32 in the reference (np.arange(..., dtype=float32)), promoted to float64 by np.dot
+    const double x = (double)(float)px, y = (double)(float)py;
+    double pc[3], pw[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)  // xy1 @ inv(K).T
+        pc[a] = __dadd_rn(__dadd_rn(__dmul_rn(x, c.Kinv[a * 3 + 0]), __dmul_rn(y, c.Kinv[a * 3 + 1])), c.Kinv[a * 3 + 2]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pc[a] = __dsub_rn(pc[a], c.T[a]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)  // (pixel_camera - T) @ R
+        pw[a] = __dadd_rn(__dadd_rn(__dmul_rn(pc[0], c.R[0 * 3 + a]), __dmul_rn(pc[1], c.R[1 * 3 + a])),
+                          __dmul_rn(pc[2], c.R[2 * 3 + a]));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        d[a] = (float)__dsub_rn(pw[a], c.o[a]);
+        o[a] = (float)c.o[a];
+    }
+}
+
+__device__ __forceinline__ bool near_far(const RayCam &c, const float (&o)[3], const float (&d)[3], float *near,
+                                         float *far) {
+    const float n = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(d[0], d[0]), __fmul_rn(d[1], d[1])), __fmul_rn(d[2], d[2])));
+    float tn = -INFINITY, tf = INFINITY;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float v = __fdiv_rn(d[a], n);
+        if (v < 1e-5f && v > -1e-10f) v = 1e-5f;   // if_nerf_data_utils.py:58
+        if (v > -1e-5f && v < 1e-10f) v = -1e-5f;  // :59 (order matters)
+        const float t0 = __fdiv_rn(__fsub_rn(c.bmin[a], o[a]), v);
+        const float t1 = __fdiv_rn(__fsub_rn(c.bmax[a], o[a]), v);
+        tn = fmaxf(tn, fminf(t0, t1));
+        tf = fminf(tf, fmaxf(t0, t1));
+    }
+    *near = __fdiv_rn(tn, n);
+    *far = __fdiv_rn(tf, n);
+    return tn < tf;
+}
+
+__global__ void ray_flag_kernel(RayCam c, int H, int W, int *__restrict__ flags, uint8_t *__restrict__ mask) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long long)H * W) return;
+    float o[3], d[3], near, far;
+    pixel_ray(c, (int)(p % W), (int)(p / W), o, d);
+    const bool hit = near_far(c, o, d, &near, &far);
+    flags[p] = hit;
+    mask[p] = hit;
+}
+
+__global__ void ray_emit_kernel(RayCam c, int H, int W, const int *__restrict__ flags, const int *__restrict__ pos,
+                                float *__restrict__ ray_o, float *__restrict__ ray_d, float *__restrict__ near_out,
+                                float *__restrict__ far_out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long long)H * W || !flags[p]) return;
+    float o[3], d[3], near, far;
+    pixel_ray(c, (int)(p % W), (int)(p / W), o, d);
+    near_far(c, o, d, &near, &far);
+    const long long r = pos[p];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        ray_o[r * 3 + a] = o[a];
+        ray_d[r * 3 + a] = d[a];
+    }
+    near_out[r] = near;
+    far_out[r] = far;
+}
+
+bool inv3(const double *m, double *out) {
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    if (det == 0.0 || det != det) return false;
+    const double r = 1.0 / det;
+    out[0] = (e * i - f * h) * r;
+    out[1] = (c * h - b * i) * r;
+    out[2] = (b * f - c * e) * r;
+    out[3] = (f * g - d * i) * r;
+    out[4] = (a * i - c * g) * r;
+    out[5] = (c * d - a * f) * r;
+    out[6] = (d * h - e * g) * r;
+    out[7] = (b * g - a * h) * r;
+    out[8] = (a * e - b * d) * r;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int nb_raygen(int32_t H, int32_t W, const double K[9], const double R[9], const double T[3],
+                         const float bounds[6], float *ray_o, float *ray_d, float *near, float *far,
+                         uint8_t *mask_at_box, int32_t *n_rays, void *scratch, void *stream) {
+    NB_REQUIRE(K && R && T && bounds && ray_o && ray_d && near && far && mask_at_box && n_rays && scratch,
+               "nb_raygen: NULL pointer");
+    NB_REQUIRE(H > 0 && W > 0, "nb_raygen: H = %d, W = %d", H, W);
+    RayCam c;
+    NB_REQUIRE(inv3(K, c.Kinv), "nb_raygen: K is singular");
+    for (int k = 0; k < 9; ++k) c.R[k] = R[k];
+    for (int a = 0; a < 3; ++a) {
+        c.T[a] = T[a];
+        c.o[a] = -(R[0 * 3 + a] * T[0] + R[1 * 3 + a] * T[1] + R[2 * 3 + a] * T[2]);  // -R^T T
+        c.bmin[a] = bounds[a];
+        c.bmax[a] = bounds[3 + a];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const long long n = (long long)H * W;
+    int *flags, *pos, *bs;
+    nb_scan_carve(scratch, n, &flags, &pos, &bs);
+    const dim3 grd(nb_ceil_div(n, 256)), blk(256);
+    hipLaunchKernelGGL(ray_flag_kernel, grd, blk, 0, st, c, H, W, flags, mask_at_box);
+    if (int rc = nb_exclusive_scan(flags, pos, n_rays, n, bs, st)) return rc;
+    hipLaunchKernelGGL(ray_emit_kernel, grd, blk, 0, st, c, H, W, flags, pos, ray_o, ray_d, near, far);
+    NB_CHECK_LAUNCH("nb_raygen");
+    return NB_OK;
+}

@@ -1,0 +1,237 @@
+"""`Network` — drop-in for zju3dv/neuralbody lib/networks/latent_xyzc.py::Network whose compute is
+the HIP library (no spconv, no torch ops on the hot path).
+
+Kept from the reference:
+  * parameter / buffer names and shapes -> `state_dict()` is interchangeable (120 keys:
+    c.weight, xyzc_net.convN.K.weight, xyzc_net.convN.K+1.{weight,bias,running_mean,running_var,
+    num_batches_tracked}, latent.weight, fc_0.{weight,bias} [out,in,1], ...)      latent_xyzc.py:10-28,166-182
+  * encode_sparse_voxels(sp_input) -> list of 4 volumes [B,C,D,H,W]               latent_xyzc.py:30-39
+  * calculate_density(wpts, feature_volume, sp_input) -> [B,N,1]                  latent_xyzc.py:74-89
+  * calculate_density_color(wpts, viewdir, feature_volume, sp_input) -> [B,N,4]   latent_xyzc.py:91-126
+  * forward(sp_input, grid_coords, viewdir, light_pts) -> [B,N,4]                 latent_xyzc.py:128-163
+  * `.training` honoured: BatchNorm uses batch statistics over the active voxels and updates the
+    running statistics (momentum 0.01) in train() — which is also how run.py renders (run.py:57,89).
+New: `render_rays(...)`, the fused march used by `Renderer.render` (one launch for all rays).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+N_VERTS = 6890
+CODE_DIM = 16
+# (name, cin, cout, n_convs, stride) — latent_xyzc.py:170-182
+ENCODER_BLOCKS = [
+    ("conv0", 16, 16, 2, 1), ("down0", 16, 32, 1, 2), ("conv1", 32, 32, 2, 1), ("down1", 32, 64, 1, 2),
+    ("conv2", 64, 64, 3, 1), ("down2", 64, 128, 1, 2), ("conv3", 128, 128, 3, 1), ("down3", 128, 128, 1, 2),
+    ("conv4", 128, 128, 3, 1),
+]
+DENSE_AFTER = ("conv1", "conv2", "conv3", "conv4")  # latent_xyzc.py:188-201
+BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
+
+
+class SparseConv3dParam(nn.Module):
+    """Holds the weight of one SubMConv3d / SparseConv3d in spconv 1.x layout [kD,kH,kW,Cin,Cout]
+    (bias=False).  The convolution itself runs in nb_enc_conv."""
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = cin, cout, stride
+        bound = 1.0 / math.sqrt(27 * cin)
+        self.weight = nn.Parameter(torch.empty(3, 3, 3, cin, cout).uniform_(-bound, bound))
+
+    def extra_repr(self):
+        return "%d, %d, kernel_size=3, stride=%d, bias=False" % (self.in_channels, self.out_channels, self.stride)
+
+
+def _block(cin, cout, n, stride):
+    layers = []
+    for j in range(n):
+        layers += [SparseConv3dParam(cin if j == 0 else cout, cout, stride),
+                   nn.BatchNorm1d(cout, eps=BN_EPS, momentum=BN_MOMENTUM), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+class SparseConvNet(nn.Module):
+    """Parameter container + layer schedule of the reference's SparseConvNet (latent_xyzc.py:166-205)."""
+
+    def __init__(self):
+        super().__init__()
+        for name, cin, cout, n, stride in ENCODER_BLOCKS:
+            setattr(self, name, _block(cin, cout, n, stride))
+
+    def forward(self, codes, coord, out_sh, training):
+        """codes [6890,16] fp32, coord [6890,3] int32 (d,h,w) -> 4 channels-last volumes [D,H,W,C]."""
+        dev = codes.device
+        dhw = [int(s) for s in out_sh]
+        grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw)
+        n_max = coord.shape[0]
+        rows = ops.enc_gather_codes(codes, rows_vert, n_rows, n_max)
+        volumes = []
+        bn_updates = []
+        for name, cin, cout, n, stride in ENCODER_BLOCKS:
+            block = getattr(self, name)
+            for j in range(n):
+                conv, bn = block[3 * j], block[3 * j + 1]
+                if stride == 2:
+                    out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw)
+                else:
+                    out_grid, out_lin, n_out, n_out_max, out_dhw = grid, rows_lin, n_rows, n_max, dhw
+                new_rows, stats = ops.enc_conv(rows, grid, dhw, out_lin, n_out, n_out_max, out_dhw, stride,
+                                               conv.weight.detach())
+                dense = None
+                if name in DENSE_AFTER and j == n - 1:
+                    dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
+                    volumes.append(dense)
+                bstats = ops.enc_bn_relu(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
+                                         bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense)
+                if training:
+                    bn_updates.append((bn, bstats))
+                rows, grid, rows_lin, n_rows, n_max, dhw = new_rows, out_grid, out_lin, n_out, n_out_max, out_dhw
+        if training:
+            # nn.BatchNorm1d bookkeeping (momentum 0.01, unbiased variance into running_var); tiny
+            # device-side vector updates, no host sync
+            with torch.no_grad():
+                for bn, bs in bn_updates:
+                    c = bn.num_features
+                    n = bs[2 * c]
+                    unbias = n / torch.clamp(n - 1.0, min=1.0)
+                    bn.running_mean.mul_(1 - bn.momentum).add_(bs[:c], alpha=bn.momentum)
+                    bn.running_var.mul_(1 - bn.momentum).add_(bs[c:2 * c] * unbias, alpha=bn.momentum)
+                    bn.num_batches_tracked += 1
+        return volumes
+
+
+_MLP_NAMES = {"fc0": "fc_0", "fc1": "fc_1", "fc2": "fc_2", "alpha": "alpha_fc", "feature": "feature_fc",
+              "latent": "latent_fc", "view": "view_fc", "rgb": "rgb_fc"}
+
+
+class Network(nn.Module):
+    def __init__(self, num_train_frame, voxel_size=(0.005, 0.005, 0.005), xyz_res=10, view_res=4):
+        super().__init__()
+        if int(xyz_res) != 10 or int(view_res) != 4:
+            raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
+        self.voxel_size = [float(v) for v in voxel_size]
+        self.c = nn.Embedding(N_VERTS, CODE_DIM)
+        self.xyzc_net = SparseConvNet()
+        self.latent = nn.Embedding(int(num_train_frame), 128)
+        self.actvn = nn.ReLU()
+        self.fc_0 = nn.Conv1d(352, 256, 1)
+        self.fc_1 = nn.Conv1d(256, 256, 1)
+        self.fc_2 = nn.Conv1d(256, 256, 1)
+        self.alpha_fc = nn.Conv1d(256, 1, 1)
+        self.feature_fc = nn.Conv1d(256, 256, 1)
+        self.latent_fc = nn.Conv1d(384, 256, 1)
+        self.view_fc = nn.Conv1d(346, 128, 1)
+        self.rgb_fc = nn.Conv1d(128, 3, 1)
+        self._packed = None
+        self._packed_key = None
+        self._host_cache = {}
+
+    # ------------------------------------------------------------------ packed decoder weights
+    def _mlp_param_dict(self):
+        d = {}
+        for short, name in _MLP_NAMES.items():
+            m = getattr(self, name)
+            d[short + "_w"] = m.weight
+            d[short + "_b"] = m.bias
+        return d
+
+    def packed_weights(self):
+        """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed."""
+        d = self._mlp_param_dict()
+        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in d.values())
+        if self._packed is None or key != self._packed_key:
+            self._packed = ops.mlp_pack(d, None)
+            self._packed_key = key
+        return self._packed
+
+    def latent_bias(self, latent_index):
+        """Per-frame bias of the merged feature_fc/latent_fc layer (latent_xyzc.py:108-111)."""
+        w = self.latent.weight.detach()
+        if not isinstance(latent_index, torch.Tensor):
+            latent_index = torch.tensor([int(latent_index)])
+        idx = latent_index.reshape(-1)[:1].long().to(w.device)
+        row = w.index_select(0, idx)[0].contiguous()
+        return ops.mlp_latent_bias(self._mlp_param_dict(), row)
+
+    # ------------------------------------------------------------------ scene description
+    def _host(self, t):
+        """Small per-frame tensors (R, Th, bounds) are needed as kernel arguments: one D2H copy per
+        distinct tensor, cached on (data_ptr, version)."""
+        key = (t.data_ptr(), t._version, tuple(t.shape))
+        v = self._host_cache.get(key)
+        if v is None:
+            if len(self._host_cache) > 64:
+                self._host_cache.clear()
+            v = t.detach().float().cpu().numpy()
+            self._host_cache[key] = v
+        return v
+
+    def make_scene(self, feature_volume, sp_input):
+        vols = []
+        for v in feature_volume:
+            vols.append(v if v.dim() == 4 else ops.volume_as_channels_last(v))
+        R = self._host(sp_input["R"]).reshape(-1, 3, 3)
+        if R.shape[0] != 1:
+            raise NotImplementedError("batch size 1 only (train.batch_size / test batch are 1 in every shipped config)")
+        Th = self._host(sp_input["Th"]).reshape(-1)[:3]
+        bmin = self._host(sp_input["bounds"]).reshape(-1, 2, 3)[0, 0]
+        out_sh = [int(s) for s in sp_input["out_sh"]]
+        return ops.make_scene(vols, R[0], Th, bmin, self.voxel_size, out_sh)
+
+    # ------------------------------------------------------------------ reference API
+    def encode_sparse_voxels(self, sp_input):
+        coord = sp_input["coord"]
+        if int(sp_input.get("batch_size", 1)) != 1:
+            raise NotImplementedError("batch size 1 only")
+        if coord.dim() == 2 and coord.shape[1] == 4:  # [N,4] = (batch idx, d, h, w), if_clight_renderer.py:33-38
+            coord = coord[:, 1:]
+        coord = coord.reshape(-1, 3).to(torch.int32).contiguous()
+        codes = self.c.weight.detach()
+        vols = self.xyzc_net(codes, coord, sp_input["out_sh"], self.training)
+        # logical layout [1,C,D,H,W] like spconv's .dense(); storage stays channels-last
+        return [v.permute(3, 0, 1, 2)[None] for v in vols]
+
+    def calculate_density(self, wpts, feature_volume, sp_input):
+        scene = self.make_scene(feature_volume, sp_input)
+        n_batch = wpts.shape[0]
+        if n_batch != 1:
+            raise NotImplementedError("batch size 1 only")
+        p = wpts.reshape(-1, 3).float().contiguous()
+        out = ops.decode_points(scene, self.packed_weights(), None, p, None, density_only=True)
+        return out.view(1, -1, 1)
+
+    def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
+        scene = self.make_scene(feature_volume, sp_input)
+        if wpts.shape[0] != 1:
+            raise NotImplementedError("batch size 1 only")
+        p = wpts.reshape(-1, 3).float().contiguous()
+        v = viewdir.reshape(-1, 3).float().contiguous()
+        lb = self.latent_bias(sp_input["latent_index"])
+        out = ops.decode_points(scene, self.packed_weights(), lb, p, v)
+        return out.view(1, -1, 4)
+
+    def forward(self, sp_input, grid_coords, viewdir, light_pts):
+        """Working equivalent of the reference's (broken, latent_xyzc.py:128-163) forward: `viewdir`
+        [B,N,27] and `light_pts` [B,N,63] are the positional encodings whose first three entries are
+        the raw direction / world point (embedder.py:14-17); the volume is sampled at those world
+        points, which is where `grid_coords` came from (get_grid_coords)."""
+        feature_volume = self.encode_sparse_voxels(sp_input)
+        return self.calculate_density_color(light_pts[..., :3], viewdir[..., :3], feature_volume, sp_input)
+
+    # ------------------------------------------------------------------ fused march
+    def render_rays(self, ray_o, ray_d, near, far, feature_volume, sp_input, n_samples, t_rand=None,
+                    white_bkgd=False, want_raw=False):
+        """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
+        scene = self.make_scene(feature_volume, sp_input)
+        lb = self.latent_bias(sp_input["latent_index"])
+        key = ("t_vals", int(n_samples), str(ray_o.device))
+        t_vals = self._host_cache.get(key)
+        if t_vals is None:
+            t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
+            self._host_cache[key] = t_vals
+        return ops.march(scene, self.packed_weights(), lb, ray_o, ray_d, near, far, t_vals, t_rand,
+                         white_bkgd=white_bkgd, want_raw=want_raw)

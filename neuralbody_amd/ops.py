@@ -1,0 +1,304 @@
+"""Tensor-level wrappers over the C ABI (include/nb_hip.h).  Every function validates device,
+dtype, contiguity and shape, then hands raw device pointers + the current HIP stream to
+libnb_hip.so.  Nothing here computes: there is no PyTorch / CPU fallback for any operator."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import NbError, NbMlpParams, NbScene, check, ptr
+
+LEVEL_CHANNELS = (32, 64, 128, 128)
+DBG_WIDTH = 992
+# bench.py sets this to a list to collect (start, end) HIP events bracketing every nb_march launch on
+# the stream it is enqueued on
+MARCH_EVENTS = None
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t, dtype, shape=None, name="tensor"):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise NbError("%s must live on a HIP device (got %s); the HIP path has no CPU fallback" % (name, t.device))
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    if shape is not None:
+        if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+            raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), shape))
+    return t
+
+
+def volume_as_channels_last(v):
+    """[1,C,D,H,W] (any strides) -> contiguous [D,H,W,C] view or copy."""
+    if v.dim() != 5 or v.shape[0] != 1:
+        raise ValueError("feature volume must be [1,C,D,H,W] (batch 1), got %s" % (tuple(v.shape),))
+    return v[0].permute(1, 2, 3, 0).contiguous()  # no copy when the storage is already channels-last
+
+
+def make_scene(volumes_cl, R, Th, bounds_min, voxel_size, out_sh):
+    """volumes_cl: four contiguous [D,H,W,C] fp32 device tensors.  R (3x3), Th (3), bounds_min (3,
+    xyz), voxel_size (3, dhw) and out_sh (3) are HOST sequences.  Returns (NbScene, keepalive)."""
+    sc = NbScene()
+    if len(volumes_cl) != 4:
+        raise ValueError("expected 4 feature volumes")
+    for l, v in enumerate(volumes_cl):
+        _req(v, torch.float32, (None, None, None, LEVEL_CHANNELS[l]), "volume[%d]" % l)
+        sc.vol[l] = v.data_ptr()
+        for k in range(3):
+            sc.vol_dhw[l][k] = int(v.shape[k])
+    Rf = [float(x) for row in R for x in row]
+    for k in range(9):
+        sc.R[k] = Rf[k]
+    for k in range(3):
+        sc.Th[k] = float(Th[k])
+        sc.bounds_min[k] = float(bounds_min[k])
+        sc.voxel_size[k] = float(voxel_size[k])
+        sc.out_sh[k] = int(out_sh[k])
+    return sc, list(volumes_cl)
+
+
+def mlp_pack_size():
+    return int(_lib.lib().nb_mlp_pack_size())
+
+
+def _mlp_params(params):
+    """params: dict name -> fp32 device tensor ([out,in] or [out,in,1] weights, [out] biases)."""
+    shapes = {"fc0": (256, 352), "fc1": (256, 256), "fc2": (256, 256), "alpha": (1, 256), "feature": (256, 256),
+              "latent": (256, 384), "view": (128, 346), "rgb": (3, 128)}
+    p = NbMlpParams()
+    keep = []
+    for name, (o, i) in shapes.items():
+        w = params[name + "_w"]
+        b = params[name + "_b"]
+        if w.dim() == 3 and w.shape[2] == 1:
+            w = w[:, :, 0]
+        w = w.detach()
+        b = b.detach()
+        if not w.is_contiguous():
+            w = w.contiguous()
+        _req(w, torch.float32, (o, i), name + "_w")
+        _req(b, torch.float32, (o,), name + "_b")
+        setattr(p, name + "_w", w.data_ptr())
+        setattr(p, name + "_b", b.data_ptr())
+        keep += [w, b]
+    return p, keep
+
+
+def mlp_pack(params, out=None):
+    """nb_mlp_pack: re-order the decoder weights into MFMA fragment order -> 1-D fp32 blob."""
+    p, keep = _mlp_params(params)
+    dev = keep[0].device
+    if out is None:
+        out = torch.empty(mlp_pack_size(), dtype=torch.float32, device=dev)
+    _req(out, torch.float32, (mlp_pack_size(),), "packed")
+    check(_lib.lib().nb_mlp_pack(C.byref(p), ptr(out), _stream()), "nb_mlp_pack")
+    return out
+
+
+def mlp_latent_bias(params, latent_row, out=None):
+    p, keep = _mlp_params(params)
+    latent_row = latent_row.detach()
+    _req(latent_row, torch.float32, (128,), "latent_row")
+    if out is None:
+        out = torch.empty(256, dtype=torch.float32, device=latent_row.device)
+    _req(out, torch.float32, (256,), "latent_bias")
+    check(_lib.lib().nb_mlp_latent_bias(C.byref(p), ptr(latent_row), ptr(out), _stream()), "nb_mlp_latent_bias")
+    return out
+
+
+def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=False, debug=False):
+    """nb_decode_points: wpts [n,3] (+ viewdir [n,3]) -> raw [n,4] (or sigma [n,1])."""
+    sc, _keep = scene
+    _req(packed, torch.float32, (mlp_pack_size(),), "packed")
+    _req(wpts, torch.float32, (None, 3), "wpts")
+    n = wpts.shape[0]
+    if not density_only:
+        _req(viewdir, torch.float32, (n, 3), "viewdir")
+        _req(latent_bias, torch.float32, (256,), "latent_bias")
+    out = torch.empty((n, 1 if density_only else 4), dtype=torch.float32, device=wpts.device)
+    dbg = torch.zeros((n, DBG_WIDTH), dtype=torch.float32, device=wpts.device) if debug else None
+    check(_lib.lib().nb_decode_points(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(wpts), ptr(viewdir), n,
+                                      1 if density_only else 0, ptr(out), ptr(dbg), _stream()), "nb_decode_points")
+    return (out, dbg) if debug else out
+
+
+def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=None, white_bkgd=False,
+          want_raw=False):
+    """nb_march: all rays of one batch element -> dict of per-ray outputs."""
+    sc, _keep = scene
+    _req(packed, torch.float32, (mlp_pack_size(),), "packed")
+    _req(latent_bias, torch.float32, (256,), "latent_bias")
+    _req(ray_o, torch.float32, (None, 3), "ray_o")
+    n = ray_o.shape[0]
+    _req(ray_d, torch.float32, (n, 3), "ray_d")
+    _req(near, torch.float32, (n,), "near")
+    _req(far, torch.float32, (n,), "far")
+    _req(t_vals, torch.float32, (None,), "t_vals")
+    S = t_vals.shape[0]
+    if t_rand is not None:
+        _req(t_rand, torch.float32, (n, S), "t_rand")
+    dev = ray_o.device
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, S), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    raw = torch.empty((n, S, 4), dtype=torch.float32, device=dev) if want_raw else None
+    ev = None
+    if MARCH_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    check(_lib.lib().nb_march(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(ray_o), ptr(ray_d), ptr(near), ptr(far),
+                              n, S, ptr(t_vals), ptr(t_rand), 1 if white_bkgd else 0, ptr(rgb), ptr(disp), ptr(acc),
+                              ptr(weights), ptr(depth), ptr(raw), _stream()), "nb_march")
+    if ev is not None:
+        ev[1].record()
+        MARCH_EVENTS.append(ev)
+    ret = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": weights, "depth_map": depth}
+    if want_raw:
+        ret["raw"] = raw
+    return ret
+
+
+def composite(raw, z_vals, ray_d, white_bkgd=False):
+    """nb_composite: raw2outputs on device. raw [n,S,4], z_vals [n,S], ray_d [n,3]."""
+    _req(raw, torch.float32, (None, None, 4), "raw")
+    n, S = raw.shape[:2]
+    _req(z_vals, torch.float32, (n, S), "z_vals")
+    _req(ray_d, torch.float32, (n, 3), "ray_d")
+    dev = raw.device
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n,), dtype=torch.float32, device=dev)
+    weights = torch.empty((n, S), dtype=torch.float32, device=dev)
+    depth = torch.empty((n,), dtype=torch.float32, device=dev)
+    check(_lib.lib().nb_composite(ptr(raw), ptr(z_vals), ptr(ray_d), n, S, 1 if white_bkgd else 0, ptr(rgb), ptr(disp),
+                                  ptr(acc), ptr(weights), ptr(depth), _stream()), "nb_composite")
+    return rgb, disp, acc, weights, depth
+
+
+# --------------------------------------------------------------------------------- encoder
+def scan_scratch(n, device):
+    return torch.empty(int(_lib.lib().nb_scan_scratch_size(int(n))), dtype=torch.uint8, device=device)
+
+
+def _i3(v):
+    return (C.c_int32 * 3)(int(v[0]), int(v[1]), int(v[2]))
+
+
+def enc_voxelize(coord, dhw):
+    """nb_enc_voxelize: coord [n,3] int32 (d,h,w) -> (grid [D,H,W] i32, rows_vert, rows_lin, n_rows[1])."""
+    _req(coord, torch.int32, (None, 3), "coord")
+    n = coord.shape[0]
+    dev = coord.device
+    grid = torch.empty([int(s) for s in dhw], dtype=torch.int32, device=dev)
+    rows_vert = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    rows_lin = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
+    n_rows = torch.zeros(1, dtype=torch.int32, device=dev)
+    scratch = scan_scratch(n, dev)
+    check(_lib.lib().nb_enc_voxelize(ptr(coord), n, _i3(dhw), ptr(grid), ptr(rows_vert), ptr(rows_lin), ptr(n_rows),
+                                     ptr(scratch), _stream()), "nb_enc_voxelize")
+    return grid, rows_vert, rows_lin, n_rows
+
+
+def down_dhw(dhw):
+    return [(int(s) - 1) // 2 + 1 for s in dhw]
+
+
+def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None):
+    """nb_enc_downsample_index -> (out_grid, out_lin, n_out[1], n_out_max, out_dhw)."""
+    _req(in_lin, torch.int32, (None,), "in_lin")
+    _req(n_in, torch.int32, (1,), "n_in")
+    dev = in_lin.device
+    out_dhw = down_dhw(in_dhw)
+    nvox = out_dhw[0] * out_dhw[1] * out_dhw[2]
+    n_out_max = max(min(8 * int(n_in_max), nvox), 1)
+    out_grid = torch.empty(out_dhw, dtype=torch.int32, device=dev)
+    out_lin = torch.zeros(n_out_max, dtype=torch.int32, device=dev)
+    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    if scratch is None:
+        scratch = scan_scratch(nvox, dev)
+    check(_lib.lib().nb_enc_downsample_index(ptr(in_lin), ptr(n_in), int(n_in_max), _i3(in_dhw), _i3(out_dhw),
+                                             ptr(out_grid), ptr(out_lin), ptr(n_out), n_out_max, ptr(scratch),
+                                             _stream()), "nb_enc_downsample_index")
+    return out_grid, out_lin, n_out, n_out_max, out_dhw
+
+
+def enc_conv(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, weight):
+    """nb_enc_conv -> (out_rows [n_out_max, Cout], stats [2*Cout] fp64)."""
+    _req(weight, torch.float32, (3, 3, 3, None, None), "conv weight")
+    cin, cout = int(weight.shape[3]), int(weight.shape[4])
+    _req(in_rows, torch.float32, (None, cin), "in_rows")
+    _req(in_grid, torch.int32, tuple(int(s) for s in in_dhw), "in_grid")
+    _req(out_lin, torch.int32, (None,), "out_lin")
+    _req(n_out, torch.int32, (1,), "n_out")
+    if out_lin.shape[0] < n_out_max:
+        raise ValueError("out_lin shorter than n_out_max")
+    dev = in_rows.device
+    out_rows = torch.empty((max(int(n_out_max), 1), cout), dtype=torch.float32, device=dev)
+    stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    check(_lib.lib().nb_enc_conv(ptr(in_rows), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out), int(n_out_max),
+                                 _i3(out_dhw), int(stride), ptr(weight), cin, cout, ptr(out_rows), ptr(stats),
+                                 _stream()), "nb_enc_conv")
+    return out_rows, stats
+
+
+def enc_bn_relu(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, running_var, training, eps,
+                rows_lin=None, dense=None):
+    """nb_enc_bn_relu (in place on rows) -> batch_stats [2C+1] = mean | biased var | n_rows."""
+    c = int(rows.shape[1])
+    _req(rows, torch.float32, (None, c), "rows")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _req(t, torch.float32, (c,), nm)
+    if stats is not None:
+        _req(stats, torch.float64, (2 * c,), "stats")
+    if dense is not None:
+        _req(dense, torch.float32, (None, None, None, c), "dense")
+        _req(rows_lin, torch.int32, (None,), "rows_lin")
+    batch_stats = torch.empty(2 * c + 1, dtype=torch.float32, device=rows.device)
+    check(_lib.lib().nb_enc_bn_relu(ptr(rows), ptr(n_rows), int(n_rows_max), c, ptr(stats), ptr(gamma), ptr(beta),
+                                    ptr(running_mean), ptr(running_var), 1 if training else 0, float(eps),
+                                    ptr(batch_stats), ptr(rows_lin), ptr(dense), _stream()), "nb_enc_bn_relu")
+    return batch_stats
+
+
+def enc_gather_codes(codes, rows_vert, n_rows, n_rows_max):
+    _req(codes, torch.float32, (None, None), "codes")
+    _req(rows_vert, torch.int32, (None,), "rows_vert")
+    c = int(codes.shape[1])
+    rows = torch.empty((max(int(n_rows_max), 1), c), dtype=torch.float32, device=codes.device)
+    check(_lib.lib().nb_enc_gather_codes(ptr(codes), ptr(rows_vert), ptr(n_rows), int(n_rows_max), c, ptr(rows),
+                                         _stream()), "nb_enc_gather_codes")
+    return rows
+
+
+# --------------------------------------------------------------------------------- ray generation
+def raygen(H, W, K, R, T, bounds, device):
+    """nb_raygen: K, R [3,3], T [3] host float64 arrays; bounds [2,3] host float32 (world AABB).
+    Returns device tensors (ray_o, ray_d, near, far, mask_at_box, n_rays[1]) with H*W capacity; the
+    first n_rays rows are valid."""
+    import numpy as np
+
+    K = np.asarray(K, np.float64).reshape(9)
+    R = np.asarray(R, np.float64).reshape(9)
+    T = np.asarray(T, np.float64).reshape(3)
+    b = np.asarray(bounds, np.float32).reshape(6)
+    n = int(H) * int(W)
+    ray_o = torch.empty((n, 3), dtype=torch.float32, device=device)
+    ray_d = torch.empty((n, 3), dtype=torch.float32, device=device)
+    near = torch.empty(n, dtype=torch.float32, device=device)
+    far = torch.empty(n, dtype=torch.float32, device=device)
+    mask = torch.empty(n, dtype=torch.uint8, device=device)
+    n_rays = torch.zeros(1, dtype=torch.int32, device=device)
+    scratch = scan_scratch(n, device)
+    with torch.cuda.device(device):
+        check(_lib.lib().nb_raygen(int(H), int(W), (C.c_double * 9)(*K), (C.c_double * 9)(*R), (C.c_double * 3)(*T),
+                                   (C.c_float * 6)(*b), ptr(ray_o), ptr(ray_d), ptr(near), ptr(far), ptr(mask),
+                                   ptr(n_rays), ptr(scratch), _stream()), "nb_raygen")
+    return ray_o, ray_d, near, far, mask, n_rays

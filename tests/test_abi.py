@@ -1,0 +1,75 @@
+"""CPU-side checks of the C-ABI boundary: the library builds/loads, exports every function that
+include/nb_hip.h declares, and the host wrappers fail loudly instead of falling back."""
+import ctypes as C
+import os
+
+import pytest
+import torch
+
+from neuralbody_amd import _lib, build, ops
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build(verbose=False)
+    return _lib.lib()
+
+
+def test_library_exports_every_header_symbol(lib):
+    names = _lib.header_functions()
+    assert len(names) >= 15
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.nb_abi_version() == 1
+
+
+def test_sizes_and_struct_layout(lib):
+    # 8*44*256 + 256 + 2*(8*32*256 + 256) + 256 + 4 + 8*32*256 + 4*44*256 + 128 + 384 + 4
+    assert lib.nb_mlp_pack_size() == 333320
+    assert lib.nb_mlp_latent_bias_size() == 256
+    assert C.sizeof(_lib.NbScene) == 168  # == sizeof(nb_scene) compiled with gcc (164 + tail padding)
+    assert _lib.NbScene.out_sh.offset == 152 and _lib.NbScene.R.offset == 80
+    assert C.sizeof(_lib.NbMlpParams) == 16 * 8
+    assert lib.nb_scan_scratch_size(0) >= 256 and lib.nb_scan_scratch_size(1 << 20) >= 2 * 4 * (1 << 20)
+
+
+def test_error_codes_without_touching_a_device(lib):
+    # NULL scene -> NB_EINVAL and a message, no crash, no launch
+    rc = lib.nb_march(None, None, None, None, None, None, None, 10, 64, None, None, 0, None, None, None, None, None,
+                      None, None)
+    assert rc == -1
+    assert b"nb_march" in lib.nb_last_error()
+    rc = lib.nb_composite(None, None, None, 4, 0, 0, None, None, None, None, None, None)
+    assert rc == -1
+    rc = lib.nb_enc_conv(None, None, (C.c_int32 * 3)(1, 1, 1), None, None, 0, (C.c_int32 * 3)(1, 1, 1), 1, None, 16,
+                         16, None, None, None)
+    assert rc == -1
+
+
+def test_wrappers_refuse_cpu_tensors():
+    with pytest.raises(_lib.NbError):
+        ops.composite(torch.zeros(2, 64, 4), torch.zeros(2, 64), torch.zeros(2, 3))
+    with pytest.raises(_lib.NbError):
+        ops.enc_voxelize(torch.zeros(10, 3, dtype=torch.int32), [32, 32, 32])
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.NbError):
+        _lib.lib()
+
+
+def test_network_state_dict_matches_reference_keys():
+    """120 entries with the reference's names/shapes (SURVEY.md §5 checkpoint row)."""
+    from neuralbody_amd import synthetic as syn
+    from neuralbody_amd.network import Network
+
+    sd_ref = syn.make_weights(0, num_train_frame=5)
+    net = Network(num_train_frame=5)
+    sd = net.state_dict()
+    assert len(sd) == 120
+    assert set(sd) == set(sd_ref)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(sd_ref[k].shape), k

@@ -1,0 +1,320 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every HIP entry point against the CPU oracle
+(oracle/neuralbody_oracle.py) on the same seeded inputs, and against the committed golden fixtures
+that tests/golden/make_golden.py produced by running the UNMODIFIED reference.  All calls go through
+the C ABI (neuralbody_amd.ops -> libnb_hip.so).
+
+Tolerances: RGB <= 1e-4 L-inf (BASELINE.json north_star); intermediate quantities are compared
+relative to max(1, |ref|) with the budgets written next to each check."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import scenes
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ALL = list(scenes.SCENES)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from neuralbody_amd import _lib
+
+    _lib.lib()  # fail loudly if libnb_hip.so is missing
+
+
+def _scene_with_oracle_volumes(name):
+    from neuralbody_amd import ops
+
+    r, sd, body, batch, cam, t_rand = scenes.build(name)
+    training = r["mode"] == "train"
+    sdt, vols, out_sh = H.oracle_volumes(sd, batch, training)
+    net = H.make_network(sd, DEV, training)
+    bd = H.device_batch(batch, DEV)
+    vols_dev = [v.to(DEV) for v in vols]  # NCDHW; Network converts to channels-last
+    sp = H.sp_input_of(bd, out_sh)
+    return r, sd, sdt, batch, bd, vols, vols_dev, sp, net, t_rand
+
+
+# ------------------------------------------------------------------------------------------- decode
+def test_decode_points_stages_against_oracle():
+    """nb_decode_points with the debug tap: gathered features (K3/K4), fc_2 output (K5), the merged
+    feature/latent layer, view_fc hidden (K6/K7) and raw, each against the oracle."""
+    from neuralbody_amd import ops
+    from oracle import neuralbody_oracle as orc
+
+    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, _ = _scene_with_oracle_volumes("small")
+    ns = r["n_samples"]
+    ray_o, ray_d = torch.from_numpy(batch["ray_o"]), torch.from_numpy(batch["ray_d"])
+    near, far = torch.from_numpy(batch["near"]), torch.from_numpy(batch["far"])
+    sel = slice(0, None, 5)
+    wpts, z = orc.get_sampling_points(ray_o[:, sel], ray_d[:, sel], near[:, sel], far[:, sel], ns)
+    vd = ray_d[:, sel] / torch.norm(ray_d[:, sel], dim=2, keepdim=True)
+    w = wpts.reshape(1, -1, 3)
+    v = vd[:, :, None].repeat(1, 1, ns, 1).reshape(1, -1, 3)
+    # a few points outside the volume exercise zero padding
+    w[0, :7] += torch.tensor([3.0, -2.0, 1.0])
+    sp_cpu = {"R": torch.from_numpy(batch["R"]), "Th": torch.from_numpy(batch["Th"]),
+              "bounds": torch.from_numpy(batch["bounds"]), "latent_index": torch.from_numpy(batch["latent_index"]),
+              "out_sh": sp["out_sh"]}
+    with torch.no_grad():
+        pp = orc.pts_to_can_pts(w, sp_cpu["R"], sp_cpu["Th"])
+        g = orc.get_grid_coords(pp, sp_cpu["bounds"], sp_cpu["out_sh"], (0.005,) * 3)[:, None, None]
+        feat = orc.interpolate_features(g, vols)[0].T  # [N,352]
+        h = torch.relu(torch.nn.functional.conv1d(feat.T[None], sdt["fc_0.weight"], sdt["fc_0.bias"]))
+        h = torch.relu(torch.nn.functional.conv1d(h, sdt["fc_1.weight"], sdt["fc_1.bias"]))
+        h3 = torch.relu(torch.nn.functional.conv1d(h, sdt["fc_2.weight"], sdt["fc_2.bias"]))
+        raw = orc.calculate_density_color(sdt, w, v, vols, sp_cpu)[0]
+        dens = orc.calculate_density(sdt, w, vols, sp_cpu)[0]
+    scene = net.make_scene(vols_dev, sp)
+    lb = net.latent_bias(bd["latent_index"])
+    out, dbg = ops.decode_points(scene, net.packed_weights(), lb, w[0].to(DEV).contiguous(), v[0].to(DEV).contiguous(),
+                                 debug=True)
+    torch.cuda.synchronize()
+    dbg = dbg.cpu().numpy()
+    H.assert_close(dbg[:, :352], feat.numpy(), 2e-5, "trilinear features")
+    assert np.abs(feat.numpy()).max() > 0.1 and (np.abs(feat.numpy()).sum(1) == 0).any()
+    H.assert_close(dbg[:, 352:608], h3[0].T.numpy(), 1e-4, "fc_2 output")
+    H.assert_close(out.cpu().numpy(), raw.numpy(), 2e-4, "raw (rgb logits, sigma)")
+    # public API paths
+    raw_api = net.calculate_density_color(w.to(DEV), v.to(DEV), vols_dev, sp)
+    assert raw_api.shape == (1, w.shape[1], 4)
+    assert torch.equal(raw_api[0], out)
+    dens_api = net.calculate_density(w.to(DEV), vols_dev, sp)
+    assert dens_api.shape == (1, w.shape[1], 1)
+    H.assert_close(dens_api[0].cpu().numpy(), dens.numpy(), 2e-4, "calculate_density")
+    # ragged size: n not a multiple of 32, and n == 0
+    part = ops.decode_points(scene, net.packed_weights(), lb, w[0, :77].to(DEV).contiguous(), v[0, :77].to(DEV).contiguous())
+    assert torch.equal(part, out[:77])
+    empty = ops.decode_points(scene, net.packed_weights(), lb, w[0, :0].to(DEV).contiguous(), v[0, :0].to(DEV).contiguous())
+    assert empty.shape == (0, 4)
+
+
+def test_decode_matches_reference_raw_subset():
+    """raw at the reference's own sample points (fixture: every 8th ray of scene 'small')."""
+    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, _ = _scene_with_oracle_volumes("small")
+    g = H.golden("small")
+    rend = H.make_renderer(net, r)
+    sel = slice(0, None, scenes.RAW_RAY_STRIDE)
+    wpts, z = rend.get_sampling_points(bd["ray_o"][:, sel], bd["ray_d"][:, sel], bd["near"][:, sel], bd["far"][:, sel])
+    vd = bd["ray_d"][:, sel] / torch.norm(bd["ray_d"][:, sel], dim=2, keepdim=True)
+    raw = rend.get_density_color(wpts, vd, lambda x, v: net.calculate_density_color(x, v, vols_dev, sp))
+    H.assert_close(raw.cpu().numpy(), g["raw_subset"], 3e-4, "raw vs reference")
+    dens = net.calculate_density(wpts.view(1, -1, 3), vols_dev, sp)
+    H.assert_close(dens.cpu().numpy(), g["density_subset"], 3e-4, "density vs reference")
+
+
+# ------------------------------------------------------------------------------------------- march
+@pytest.mark.parametrize("name", ALL)
+def test_march_on_oracle_volumes_matches_reference(name):
+    """nb_march fed with the oracle's feature volumes against the reference renderer's outputs."""
+    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, t_rand = _scene_with_oracle_volumes(name)
+    g = H.golden(name)
+    tr = None if t_rand is None else torch.from_numpy(t_rand)[0].to(DEV).contiguous()
+    out = net.render_rays(bd["ray_o"][0], bd["ray_d"][0], bd["near"][0], bd["far"][0], vols_dev, sp, r["n_samples"],
+                          t_rand=tr, white_bkgd=r["white_bkgd"], want_raw=True)
+    torch.cuda.synchronize()
+    H.assert_close(out["rgb_map"].cpu().numpy()[None], g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    H.assert_close(out["acc_map"].cpu().numpy()[None], g["acc_map"], 1e-4, "acc_map")
+    H.assert_close(out["weights"].cpu().numpy()[None], g["weights"], 1e-4, "weights")
+    H.assert_close(out["depth_map"].cpu().numpy()[None], g["depth_map"], 1e-4, "depth_map")
+    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 2e-4, "disp_map")
+    assert float(g["rgb_map"].max()) > 0.3, "fixture is degenerate"
+
+
+def test_composite_matches_oracle():
+    from neuralbody_amd import ops
+    from oracle import neuralbody_oracle as orc
+
+    rs = np.random.RandomState(5)
+    for n, S, white in ((37, 64, False), (5, 128, True), (3, 40, False), (1, 1, False)):
+        raw = (rs.standard_normal((n, S, 4)) * 3).astype(np.float32)
+        raw[0, :, 3] = -1.0  # a ray that hits nothing: acc = 0, disp = NaN (nerf_net_utils.py:44-45)
+        z = np.sort(rs.uniform(1, 3, (n, S)).astype(np.float32), axis=1)
+        d = rs.standard_normal((n, 3)).astype(np.float32)
+        ref = orc.raw2outputs(torch.from_numpy(raw), torch.from_numpy(z), torch.from_numpy(d), white)
+        got = ops.composite(torch.from_numpy(raw).to(DEV), torch.from_numpy(z).to(DEV), torch.from_numpy(d).to(DEV), white)
+        for a, b, nm in zip(got, ref, ("rgb", "disp", "acc", "weights", "depth")):
+            H.assert_close(a.cpu().numpy(), b.numpy(), 2e-6, "composite %s n=%d S=%d" % (nm, n, S))
+        assert np.isnan(got[1].cpu().numpy()[0])
+
+
+# ------------------------------------------------------------------------------------------- encoder
+@pytest.mark.parametrize("name", ["small", "small_eval", "full"])
+def test_encoder_matches_oracle_and_reference_probes(name):
+    """nb_enc_* (voxelise, 17 x [sparse conv, BN, ReLU], 4 x dense) against the oracle's dense
+    stand-in and the reference-generated probe values."""
+    from oracle import neuralbody_oracle as orc
+
+    r, sd, body, batch, cam, _ = scenes.build(name)
+    training = r["mode"] == "train"
+    g = H.golden(name)
+    sdt = orc.tensor_state_dict(sd)
+    stats = {}
+    with torch.no_grad():
+        out_sh = batch["out_sh"].max(0).tolist()
+        ref = orc.encode_sparse_voxels(sdt, torch.from_numpy(batch["coord"]), out_sh, training=training,
+                                       update_stats=stats)
+    net = H.make_network(sd, DEV, training)
+    bd = H.device_batch(batch, DEV)
+    from neuralbody_amd.renderer import Renderer
+
+    sp = Renderer(net).prepare_sp_input(bd)
+    vols = net.encode_sparse_voxels(sp)
+    torch.cuda.synchronize()
+    assert len(vols) == 4
+    for li, (v, rv) in enumerate(zip(vols, ref)):
+        assert tuple(v.shape) == tuple(rv.shape), (li, v.shape, rv.shape)
+        a = v.cpu().numpy()
+        b = rv.numpy()
+        assert np.array_equal(np.abs(a).sum(1) > 0, np.abs(b).sum(1) > 0), "active set differs at level %d" % li
+        H.assert_close(a, b, 2e-4, "volume level %d" % li)  # 17 fp32 conv+BN layers, different summation order
+        flat = a[0].transpose(1, 2, 3, 0).reshape(-1, a.shape[1])
+        H.assert_close(flat[g["vol%d_probe_idx" % li]], g["vol%d_probe_val" % li], 3e-4, "reference probes level %d" % li)
+        assert int((np.abs(flat).sum(1) > 0).sum()) == int(g["vol%d_nonzero_voxels" % li])
+    if training:
+        sd_after = net.state_dict()
+        for k, v in stats.items():
+            H.assert_close(sd_after[k].cpu().numpy(), v.numpy(), 2e-5, k)
+            H.assert_close(sd_after[k].cpu().numpy(), g["bn/" + k], 2e-5, k + " vs reference")
+        assert int(sd_after["xyzc_net.conv0.1.num_batches_tracked"]) == 1
+    else:
+        assert torch.equal(net.state_dict()["xyzc_net.conv0.1.running_mean"].cpu(),
+                           torch.from_numpy(sd["xyzc_net.conv0.1.running_mean"]))
+
+
+def test_encoder_edge_cases():
+    """duplicate coordinates (last vertex wins), all vertices in one voxel, voxels on the grid border."""
+    from neuralbody_amd import ops
+
+    coord = torch.tensor([[0, 0, 0], [31, 31, 31], [5, 6, 7], [5, 6, 7], [0, 0, 0]], dtype=torch.int32, device=DEV)
+    grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, [32, 32, 32])
+    torch.cuda.synchronize()
+    assert int(n_rows) == 3
+    assert sorted(rows_vert[:3].tolist()) == [1, 3, 4]
+    gv = grid.cpu().numpy()
+    assert (gv >= 0).sum() == 3 and gv[5, 6, 7] >= 0 and gv[31, 31, 31] >= 0
+    rv, rl = rows_vert[:3].tolist(), rows_lin[:3].tolist()
+    for v, lin in zip(rv, rl):
+        d, h, w = coord[v].tolist()
+        assert lin == (d * 32 + h) * 32 + w and gv[d, h, w] == rv.index(v)
+    og, ol, no, nmax, odhw = ops.enc_downsample_index(rows_lin, n_rows, 5, [32, 32, 32])
+    torch.cuda.synchronize()
+    ref_mask = torch.nn.functional.max_pool3d((torch.from_numpy(gv)[None, None] >= 0).float(), 3, 2, 1)[0, 0] > 0
+    assert odhw == [16, 16, 16]
+    assert np.array_equal(og.cpu().numpy() >= 0, ref_mask.numpy())
+    assert int(no) == int(ref_mask.sum())
+    lin = ol[:int(no)].cpu().numpy()
+    assert np.all(np.diff(lin) > 0), "rows must be numbered in linear voxel order"
+    assert np.array_equal(og.cpu().numpy().reshape(-1)[lin], np.arange(int(no)))
+    # empty input
+    grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord[:0].contiguous(), [32, 32, 32])
+    torch.cuda.synchronize()
+    assert int(n_rows) == 0 and int((grid >= 0).sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("name", ALL)
+def test_render_end_to_end_matches_reference(name):
+    """Renderer.render(batch) — encoder + march, all HIP — against the reference renderer's outputs."""
+    r, sd, body, batch, cam, t_rand = scenes.build(name)
+    g = H.golden(name)
+    net = H.make_network(sd, DEV, r["mode"] == "train")
+    rend = H.make_renderer(net, r)
+    bd = H.device_batch(batch, DEV)
+    tr = None if t_rand is None else torch.from_numpy(t_rand).to(DEV)
+    with torch.no_grad():
+        out = rend.render(bd, t_rand=tr)
+    torch.cuda.synchronize()
+    assert set(out) == {"rgb_map", "disp_map", "acc_map", "weights", "depth_map"}
+    n = batch["ray_o"].shape[1]
+    assert out["rgb_map"].shape == (1, n, 3) and out["weights"].shape == (1, n, r["n_samples"])
+    err = H.assert_close(out["rgb_map"].cpu().numpy(), g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    H.assert_close(out["acc_map"].cpu().numpy(), g["acc_map"], 2e-4, "acc_map")
+    H.assert_close(out["weights"].cpu().numpy(), g["weights"], 2e-4, "weights")
+    H.assert_close(out["depth_map"].cpu().numpy(), g["depth_map"], 2e-4, "depth_map")
+    print("%s: rgb L-inf vs reference %.2e over %d rays" % (name, err, n))
+    # unfused path of the overridable API (get_pixel_value) agrees with the fused march
+    if t_rand is None:
+        sp = rend.prepare_sp_input(bd)
+        vols = net.encode_sparse_voxels(sp) if r["mode"] != "train" else None
+        if vols is not None:
+            pv = rend.get_pixel_value(bd["ray_o"], bd["ray_d"], bd["near"], bd["far"], vols, sp, bd)
+            H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 2e-6, "fused vs unfused rgb")
+
+
+# ------------------------------------------------------------------------------------------- ray generation
+def test_raygen_matches_reference_golden():
+    from neuralbody_amd import ops
+    from neuralbody_amd import synthetic as syn
+
+    g = np.load(H.GOLDEN + "/raygen.npz")
+    for tag, body_kw, Hh, Ww, ff in (("a", dict(seed=3, box=(0.9, 1.7, 0.35), rh=(0.2, 0.4, 0.0), th=(0.3, 0.1, 0.2)), 40, 56, 1.1),
+                                     ("b", dict(seed=4, box=(0.3, 0.5, 0.2)), 33, 17, 3.0)):
+        body = syn.make_body(**body_kw)
+        K, R, T = syn.make_camera(body, Hh, Ww, focal_factor=ff, distance=2.2, yaw=-0.6, pitch=0.25)
+        ro, rd, near, far, mask, n = ops.raygen(Hh, Ww, K, R, T, body["can_bounds"], DEV)
+        torch.cuda.synchronize()
+        n = int(n)
+        mask = mask.cpu().numpy().astype(bool)
+        assert np.array_equal(mask, g[tag + "_mask"])
+        assert n == int(mask.sum())
+        # float64 ray construction + float32 slab test: identical up to the last float32 bit
+        np.testing.assert_allclose(rd[:n].cpu().numpy(), g[tag + "_img_ray_d"], rtol=3e-7, atol=1e-7)
+        np.testing.assert_allclose(near[:n].cpu().numpy(), g[tag + "_img_near"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(far[:n].cpu().numpy(), g[tag + "_img_far"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(ro[0].cpu().numpy(), g[tag + "_ray_o"], rtol=3e-7, atol=1e-7)
+        assert torch.equal(ro[:n], ro[:1].expand(n, 3))
+
+
+# ------------------------------------------------------------------------------------------- full size
+def test_full_size_properties_512():
+    """BASELINE.json headline shape (512x512, 64 samples, 6890 vertices): size-independent properties —
+    sharding invariance (any contiguous ray range reproduces the full render bit for bit), permutation
+    equivariance, sum(weights) == acc, finite outputs, and spot parity with the oracle on a ray sample."""
+    from neuralbody_amd import synthetic as syn
+    from neuralbody_amd.renderer import RenderConfig, Renderer
+    from oracle import neuralbody_oracle as orc
+
+    sd = syn.make_weights(0, num_train_frame=230)
+    body = syn.make_body(seed=0)
+    Hh = Ww = 512
+    K, R, T = syn.full_coverage_camera(body, Hh, Ww)
+    net = H.make_network(sd, DEV, True)
+    ro, rd, near, far, mask, n = [t for t in __import__("neuralbody_amd").ops.raygen(Hh, Ww, K, R, T, body["can_bounds"], DEV)]
+    n = int(n)
+    assert n == Hh * Ww and bool(mask.all())
+    batch = syn.make_batch(body, np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32), np.zeros(1, np.float32),
+                           np.zeros(1, np.float32), np.ones(1, bool))
+    bd = H.device_batch({k: v for k, v in batch.items() if k not in ("ray_o", "ray_d", "near", "far", "mask_at_box")}, DEV)
+    bd.update(ray_o=ro[None, :n], ray_d=rd[None, :n], near=near[None, :n], far=far[None, :n])
+    rend = Renderer(net, RenderConfig(N_samples=64))
+    net.eval()  # keep BN running stats fixed so repeated encodes are identical
+    with torch.no_grad():
+        full = rend.render(bd)
+        torch.cuda.synchronize()
+        rgb = full["rgb_map"][0]
+        assert torch.isfinite(rgb).all() and torch.isfinite(full["weights"]).all()
+        assert float(full["acc_map"].min()) >= 0 and float(full["acc_map"].max()) <= 1 + 1e-5
+        H.assert_close(full["weights"][0].sum(-1).cpu().numpy(), full["acc_map"][0].cpu().numpy(), 1e-5, "sum w == acc")
+        # sharding invariance on odd boundaries
+        for b, e in ((0, 1), (1000, 1037), (n - 77, n), (123457, 131072 + 33)):
+            part = rend.render(bd, ray_range=(b, e))
+            for k in full:
+                assert torch.equal(part[k][0], full[k][0, b:e]), (k, b, e)
+        # permutation equivariance
+        perm = torch.randperm(4096, device=DEV)
+        sub = {k: (v[:, perm] if k in ("ray_o", "ray_d", "near", "far") else v) for k, v in bd.items()}
+        sub_out = rend.render(sub)
+        assert torch.equal(sub_out["rgb_map"][0], full["rgb_map"][0, perm])
+    # spot parity against the oracle on 96 rays spread over the image
+    sel = np.linspace(0, n - 1, 96).astype(np.int64)
+    b_np = dict(batch)
+    b_np.update(ray_o=ro[sel].cpu().numpy()[None], ray_d=rd[sel].cpu().numpy()[None], near=near[sel].cpu().numpy()[None],
+                far=far[sel].cpu().numpy()[None])
+    with torch.no_grad():
+        ref = orc.render(orc.tensor_state_dict(sd), b_np, n_samples=64, training=False)
+    H.assert_close(rgb[sel].cpu().numpy()[None], ref["rgb_map"].numpy(), H.RGB_TOL, "512x512 spot rgb", rel=False)
