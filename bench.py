@@ -64,32 +64,46 @@ def build_scene(dev, H=512, W=512, n_samples=64):
 
 def cpu_baseline(sd, bd, vols, n_samples, budget_s=12.0, max_rays=8192):
     """The oracle (CPU restatement of the reference, chunked by 2048 rays like if_clight_renderer.py:107)
-    marching a bounded sample of the bench rays through the same feature volumes."""
+    marching a bounded sample of the bench rays through the same feature volumes.  torch's CPU thread
+    count is chosen by a short probe (on many-core hosts fewer threads than cores is faster); the count
+    used is reported as `cores`."""
     from oracle import neuralbody_oracle as orc
 
-    torch.set_num_threads(os.cpu_count() or 1)
     sdt = orc.tensor_state_dict(sd)
     vols_cpu = [v.detach().cpu().contiguous() for v in vols]  # NCDHW like the reference's .dense()
     n = bd["ray_o"].shape[1]
     sel = torch.linspace(0, n - 1, max_rays).long()
     b = {k: v.detach().cpu() for k, v in bd.items()}
+
+    def run(idx):
+        bb = dict(b)
+        bb.update(ray_o=b["ray_o"][:, idx], ray_d=b["ray_d"][:, idx], near=b["near"][:, idx], far=b["far"][:, idx])
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc.render(dict(sdt), bb, n_samples=n_samples, training=True, feature_volume=vols_cpu)
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    probe = {}
+    for nt in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+        torch.set_num_threads(nt)
+        run(sel[:128])  # warm-up (thread pool, allocator)
+        probe[nt] = run(sel[:256])
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
     done, t_total = 0, 0.0
-    with torch.no_grad():
-        for i in range(0, max_rays, 2048):
-            idx = sel[i:i + 2048]
-            bb = dict(b)
-            bb.update(ray_o=b["ray_o"][:, idx], ray_d=b["ray_d"][:, idx], near=b["near"][:, idx], far=b["far"][:, idx])
-            t0 = time.perf_counter()
-            orc.render({k: v for k, v in sdt.items()}, bb, n_samples=n_samples, training=True, feature_volume=vols_cpu)
-            dt = time.perf_counter() - t0
-            done += len(idx)
-            t_total += dt
-            if t_total > budget_s:
-                break
-    return {"value": done * n_samples / t_total, "unit": "ray-samples/s", "cores": torch.get_num_threads(),
+    for i in range(0, max_rays, 2048):
+        idx = sel[i:i + 2048]
+        t_total += run(idx)
+        done += len(idx)
+        if t_total > budget_s:
+            break
+    return {"value": done * n_samples / t_total, "unit": "ray-samples/s", "cores": best, "host_cores": ncpu,
             "kind": "port", "rays_per_s": done / t_total,
+            "thread_probe_s_per_256_rays": {str(k): round(v, 3) for k, v in probe.items()},
             "sample": "%d of the bench rays x %d samples, march only (K2-K8) on precomputed feature volumes, "
-                      "%.1f s of oracle/neuralbody_oracle.py (torch CPU %s)" % (done, n_samples, t_total, torch.__version__)}
+                      "%.1f s of oracle/neuralbody_oracle.py (torch CPU %s, %d threads)"
+                      % (done, n_samples, t_total, torch.__version__, best)}
 
 
 def main():

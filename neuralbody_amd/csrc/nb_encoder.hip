@@ -246,7 +246,8 @@ extern "C" {
 
 int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3], int32_t *grid, int32_t *rows_vert,
                     int32_t *rows_lin, int32_t *n_rows, void *scratch, void *stream) {
-    NB_REQUIRE(coord && dhw && grid && rows_vert && rows_lin && n_rows && scratch, "nb_enc_voxelize: NULL pointer");
+    NB_REQUIRE(dhw && grid && n_rows, "nb_enc_voxelize: NULL pointer");
+    NB_REQUIRE(n_verts == 0 || (coord && rows_vert && rows_lin && scratch), "nb_enc_voxelize: NULL pointer");
     NB_REQUIRE(n_verts >= 0 && dhw[0] > 0 && dhw[1] > 0 && dhw[2] > 0, "nb_enc_voxelize: bad sizes");
     NB_REQUIRE((long long)dhw[0] * dhw[1] * dhw[2] < (1LL << 31), "nb_enc_voxelize: grid too large for int32 indices");
     hipStream_t st = (hipStream_t)stream;

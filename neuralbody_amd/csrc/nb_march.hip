@@ -627,10 +627,10 @@ int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *o
 
 int nb_decode_points(const nb_scene *scene, const float *packed, const float *latent_bias, const float *wpts,
                      const float *viewdir, int64_t n, int density_only, float *raw_out, float *dbg, void *stream) {
-    NB_REQUIRE(scene && packed && raw_out, "nb_decode_points: NULL pointer");
+    NB_REQUIRE(scene && packed, "nb_decode_points: NULL scene / weights");
     NB_REQUIRE(n >= 0, "nb_decode_points: n = %lld", (long long)n);
     if (n == 0) return NB_OK;
-    NB_REQUIRE(wpts != nullptr, "nb_decode_points: wpts is NULL");
+    NB_REQUIRE(wpts && raw_out, "nb_decode_points: NULL wpts / raw_out");
     NB_REQUIRE(density_only || (viewdir && latent_bias), "nb_decode_points: viewdir / latent_bias required");
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;

@@ -21,7 +21,12 @@ SCENES = {
     "full": dict(weights_seed=1, num_train_frame=5,
                  body=dict(seed=1, box=(0.9, 1.7, 0.35), rh=(0.3, -0.2, 0.1), th=(0.1, 0.2, -0.3), layout="capsules"),
                  cam=dict(H=24, W=20, focal_factor=1.3, distance=2.5), n_samples=64,
-                 latent_index=2, mode="train", perturb=False, white_bkgd=False, probes=True),
+                 latent_index=2, mode="train", perturb=False, white_bkgd=False, probes=True,
+                 weights_kw=dict(alpha_bias=2.0)),  # empty space (all-zero features) gets sigma > 0: fog with holes
+    # ~20 % of the samples have sigma > 0: transmittance decays over many samples (stresses the compositing)
+    "small_dense": dict(weights_seed=2, num_train_frame=7, body=_SMALL_BODY, cam=_SMALL_CAM, n_samples=64,
+                        latent_index=5, mode="train", perturb=False, white_bkgd=True, probes=False,
+                        weights_kw=dict(alpha_bias=0.0, alpha_scale=12.0)),
 }
 N_PROBES = 160
 RAW_RAY_STRIDE = 8
@@ -30,7 +35,7 @@ RAW_RAY_STRIDE = 8
 def build(name):
     """-> (recipe, state_dict_np, body, batch_np, cam(K,R,T,H,W), t_rand or None)"""
     r = SCENES[name]
-    sd = syn.make_weights(r["weights_seed"], num_train_frame=r["num_train_frame"])
+    sd = syn.make_weights(r["weights_seed"], num_train_frame=r["num_train_frame"], **r.get("weights_kw", {}))
     body = syn.make_body(**r["body"])
     c = r["cam"]
     K, R, T = syn.make_camera(body, c["H"], c["W"], focal_factor=c["focal_factor"], distance=c["distance"])

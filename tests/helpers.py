@@ -65,3 +65,8 @@ def assert_close(a, b, tol, name="", rel=True):
     m = float(err.max(initial=0.0))
     assert m <= tol, "%s: max err %.3e > %.1e" % (name, m, tol)
     return m
+
+
+def same_bits(a, b):
+    """Bit-exact equality that treats NaNs at the same positions as equal."""
+    return a.shape == b.shape and bool(torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32)))

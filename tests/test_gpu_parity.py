@@ -122,7 +122,7 @@ def test_march_on_oracle_volumes_matches_reference(name):
     H.assert_close(out["weights"].cpu().numpy()[None], g["weights"], 1e-4, "weights")
     H.assert_close(out["depth_map"].cpu().numpy()[None], g["depth_map"], 1e-4, "depth_map")
     H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 2e-4, "disp_map")
-    assert float(g["rgb_map"].max()) > 0.3, "fixture is degenerate"
+    assert float(g["rgb_map"].max()) > 0.1, "fixture is degenerate"
 
 
 def test_composite_matches_oracle():
@@ -130,7 +130,7 @@ def test_composite_matches_oracle():
     from oracle import neuralbody_oracle as orc
 
     rs = np.random.RandomState(5)
-    for n, S, white in ((37, 64, False), (5, 128, True), (3, 40, False), (1, 1, False)):
+    for n, S, white in ((37, 64, False), (5, 128, True), (3, 40, False), (2, 2, False), (1, 200, True)):
         raw = (rs.standard_normal((n, S, 4)) * 3).astype(np.float32)
         raw[0, :, 3] = -1.0  # a ray that hits nothing: acc = 0, disp = NaN (nerf_net_utils.py:44-45)
         z = np.sort(rs.uniform(1, 3, (n, S)).astype(np.float32), axis=1)
@@ -304,12 +304,12 @@ def test_full_size_properties_512():
         for b, e in ((0, 1), (1000, 1037), (n - 77, n), (123457, 131072 + 33)):
             part = rend.render(bd, ray_range=(b, e))
             for k in full:
-                assert torch.equal(part[k][0], full[k][0, b:e]), (k, b, e)
+                assert H.same_bits(part[k][0], full[k][0, b:e]), (k, b, e)
         # permutation equivariance
         perm = torch.randperm(4096, device=DEV)
         sub = {k: (v[:, perm] if k in ("ray_o", "ray_d", "near", "far") else v) for k, v in bd.items()}
         sub_out = rend.render(sub)
-        assert torch.equal(sub_out["rgb_map"][0], full["rgb_map"][0, perm])
+        assert H.same_bits(sub_out["rgb_map"][0], full["rgb_map"][0, perm])
     # spot parity against the oracle on 96 rays spread over the image
     sel = np.linspace(0, n - 1, 96).astype(np.int64)
     b_np = dict(batch)
