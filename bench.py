@@ -37,7 +37,7 @@ EXEC_FLOP_PER_SAMPLE = 663296.0  # executed: feature_fc.latent_fc merged, latent
 PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
 
 
-def build_scene(dev, H=512, W=512, n_samples=64):
+def build_scene(dev, H=512, W=512, n_samples=64, precision=None):
     from neuralbody_amd import ops
     from neuralbody_amd import synthetic as syn
     from neuralbody_amd.network import Network
@@ -46,7 +46,7 @@ def build_scene(dev, H=512, W=512, n_samples=64):
     sd = syn.make_weights(0, num_train_frame=230)
     body = syn.make_body(seed=0)
     K, R, T = syn.full_coverage_camera(body, H, W)
-    net = Network(num_train_frame=230)
+    net = Network(num_train_frame=230, precision=precision)
     net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     net = net.to(dev)
     net.train()  # run.py:57,89 renders in train() mode: BatchNorm uses batch statistics
@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -136,7 +137,7 @@ def main():
     from neuralbody_amd.parallel import all_gather_tiles
 
     H = W = args.size
-    sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples)
+    sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
     S = args.samples
 
     def step():

@@ -30,7 +30,11 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 1
+#define NB_ABI_VERSION 2
+
+/* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
+#define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
+#define NB_PREC_BF16X3 1 /* bf16 hi+lo split of both operands, 3 products on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */
@@ -63,7 +67,8 @@ typedef struct nb_scene {
 /* ---------------------------------------------------------------------------------
  * Packed decoder weights.  nb_mlp_pack_size() floats; produced by nb_mlp_pack() from
  * the reference's parameter tensors (Conv1d(k=1) weights [out,in,1] viewed as [out,in]).
- * The packing re-orders every layer into MFMA A-operand fragment order and merges
+ * The blob holds both formats (fp32 fragments for NB_PREC_F32, a bf16 hi/lo fragment stream for
+ * NB_PREC_BF16X3).  The packing re-orders every layer into MFMA A-operand fragment order and merges
  * feature_fc with the first 256 columns of latent_fc (no activation sits between them,
  * latent_xyzc.py:106-111).  nb_mlp_latent_bias() folds the per-frame latent code
  * (latent_xyzc.py:108-111) into that merged layer's bias; call it whenever
@@ -101,7 +106,7 @@ int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *o
  * ------------------------------------------------------------------------------- */
 int nb_decode_points(const nb_scene *scene, const float *packed, const float *latent_bias,
                      const float *wpts, const float *viewdir, int64_t n, int density_only,
-                     float *raw_out, float *dbg, void *stream);
+                     float *raw_out, float *dbg, int precision, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * nb_march — the fused per-ray path: replaces Renderer.get_pixel_value
@@ -119,7 +124,7 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
              const float *ray_o, const float *ray_d, const float *near, const float *far,
              int64_t n_rays, int32_t n_samples, const float *t_vals, const float *t_rand,
              int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
-             float *depth_map, float *raw, void *stream);
+             float *depth_map, float *raw, int precision, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * nb_composite — raw2outputs alone (lib/networks/renderer/nerf_net_utils.py:6-51) for

@@ -9,6 +9,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libnb_hip.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
+ABI_VERSION = 2
+PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
 class NbScene(C.Structure):
@@ -45,9 +47,9 @@ SIGNATURES = {
     "nb_mlp_latent_bias_size": (_I64, []),
     "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
     "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),
-    "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, _P]),
+    "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
     "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_int, _P, _P, _P, _P,
-                           _P, _P, _P]),
+                           _P, _P, C.c_int, _P]),
     "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
     "nb_scan_scratch_size": (_I64, [_I64]),
     "nb_enc_voxelize": (C.c_int, [_P, _I32, _I32x3, _P, _P, _P, _P, _P, _P]),
@@ -88,8 +90,8 @@ def lib():
         fn = getattr(L, name)  # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if L.nb_abi_version() != 1:
-        raise NbError("libnb_hip.so ABI version %d, expected 1" % L.nb_abi_version())
+    if L.nb_abi_version() != ABI_VERSION:
+        raise NbError("libnb_hip.so ABI version %d, expected %d" % (L.nb_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

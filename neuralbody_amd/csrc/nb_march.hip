@@ -24,10 +24,10 @@
 //   lib/networks/embedder.py:10-36                            positional encoding
 //   lib/networks/renderer/nerf_net_utils.py:6-51              raw2outputs
 //   ATen grid_sampler_3d (trilinear, zeros padding, align_corners=True)
-#include "nb_common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+#include "nb_march_common.h"
+
+using namespace nbm;
 
 #ifndef NB_PF
 #define NB_PF 8
@@ -40,7 +40,6 @@ namespace {
 constexpr int G0 = 44;  // fc_0: 352 inputs = 176 K=2 chunks = 44 groups of 4 chunks
 constexpr int GH = 32;  // hidden 256 inputs = 128 chunks = 32 groups
 constexpr int GV = 44;  // view_fc: 128 chunks (latent_fc out) + 45 PE chunks + 3 zero chunks
-constexpr int N_PE = 45;
 constexpr int OFF_L0 = 0;
 constexpr int OFF_B0 = OFF_L0 + 8 * G0 * 256;
 constexpr int OFF_L1 = OFF_B0 + 256;
@@ -55,66 +54,6 @@ constexpr int OFF_BV = OFF_LV + 4 * GV * 256;
 constexpr int OFF_RW = OFF_BV + 128;  // rgb_fc weights [3][2][64]
 constexpr int OFF_RB = OFF_RW + 384;  // rgb_fc bias (4 floats, 3 used)
 constexpr int PACK_SIZE = OFF_RB + 4;
-
-// feature row (within a 32-row tile) held by accumulator register r of a lane with half index hi
-__host__ __device__ constexpr int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
-
-// channel layout of the gathered feature vector (latent_xyzc.py:63-71)
-__host__ __device__ constexpr int lvl_c(int l) { return l == 0 ? 32 : (l == 1 ? 64 : 128); }
-__host__ __device__ constexpr int lvl_chan_base(int l) { return l == 0 ? 0 : (l == 1 ? 32 : (l == 2 ? 96 : 224)); }
-__host__ __device__ constexpr int lvl_reg_base(int l) { return lvl_chan_base(l) / 2; }
-
-// input feature index (column of the layer's weight matrix) for chunk q, half hi -----------
-__host__ __device__ inline int col_feat(int q, int hi) {  // fc_0: q in [0,176)
-    int l = q < 16 ? 0 : (q < 48 ? 1 : (q < 112 ? 2 : 3));
-    return lvl_chan_base(l) + hi * (lvl_c(l) / 2) + (q - lvl_reg_base(l));
-}
-__host__ __device__ inline int col_hidden(int q, int hi) {  // q in [0,128): previous layer's tile t = q/16
-    return 32 * (q >> 4) + tile_row(q & 15, hi);
-}
-// view_fc column (346 = 256 + 27 + 63, latent_xyzc.py:113-118) for PE chunk c, -1 = zero pad
-__host__ __device__ inline int col_pe(int c, int hi) {
-    if (c < 12) {  // view direction, frequency k = c/3, axis a = c%3: hi=0 sin, hi=1 cos
-        int k = c / 3, a = c % 3;
-        return 256 + 3 + 6 * k + 3 * hi + a;
-    }
-    if (c < 42) {  // world xyz
-        int k = (c - 12) / 3, a = (c - 12) % 3;
-        return 256 + 27 + 3 + 6 * k + 3 * hi + a;
-    }
-    if (c < 45) {  // raw inputs: hi=0 viewdir_a, hi=1 xyz_a
-        int a = c - 42;
-        return hi ? (256 + 27 + a) : (256 + a);
-    }
-    return -1;
-}
-
-struct SceneDev {
-    const float *vol[4];
-    int dhw[4][3];
-    float R[9];
-    float Th[3];
-    float bmin[3];
-    float vs[3];
-    float osh[3];
-};
-
-struct MarchArgs {
-    SceneDev sc;
-    const float *pk;
-    const float *lb;
-    // ray mode
-    const float *ray_o, *ray_d, *near, *far, *t_vals, *t_rand;
-    float *rgb_map, *disp_map, *acc_map, *weights, *depth_map, *raw;
-    long long n_rays;
-    int n_samples;
-    int white_bkgd;
-    // point mode
-    const float *wpts, *viewdir;
-    float *raw_out, *dbg;
-    long long n_pts;
-    int n_wave_groups;
-};
 
 // ---------------------------------------------------------------- one MLP layer on MFMA
 // The A-operand stream of a layer is NT*NG consecutive 1-KiB fragments; it is software-pipelined
@@ -137,8 +76,6 @@ __device__ __forceinline__ void mlp_layer(const float *__restrict__ wp, const fl
                     b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            constexpr int dummy = 0;
-            (void)dummy;
             const int idx = t * NG + g;
             const f32x4 av = ring[idx % PF];
             if (idx + PF < TOTAL) ring[idx % PF] = a[(idx + PF) * 64];
@@ -167,89 +104,6 @@ __device__ __forceinline__ void dump_tiles(const f32x16 (&h)[NT], float *dst, in
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[32 * t + tile_row(r, hi)] = h[t][r];
-}
-
-// ---------------------------------------------------------------- positional encoding
-// embedder.py:26-36: [x, sin(x*2^k), cos(x*2^k)]_k ; x*2^k is exact in fp32.
-__device__ __forceinline__ void pe_view(float (&pe)[N_PE], float vx, float vy, float vz, int hi) {
-    const float v[3] = {vx, vy, vz};
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float s, c;
-            sincosf(v[a] * (float)(1 << k), &s, &c);
-            pe[3 * k + a] = hi ? c : s;
-        }
-}
-__device__ __forceinline__ void pe_xyz(float (&pe)[N_PE], float px, float py, float pz, float vx, float vy,
-                                       float vz, int hi) {
-    const float p[3] = {px, py, pz};
-    const float v[3] = {vx, vy, vz};
-#pragma unroll
-    for (int k = 0; k < 10; ++k)
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            float s, c;
-            sincosf(p[a] * (float)(1 << k), &s, &c);
-            pe[12 + 3 * k + a] = hi ? c : s;
-        }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) pe[42 + a] = hi ? p[a] : v[a];
-}
-
-// ---------------------------------------------------------------- trilinear gather (K3 + K4)
-// latent_xyzc.py:41-60 then grid_sample(align_corners=True, zeros) per level (:62-72).
-// Lane (j, hi) accumulates channels [hi*C/2, (hi+1)*C/2) of every level for sample j.
-__device__ __forceinline__ void gather_features(const SceneDev &sc, float px, float py, float pz, int hi,
-                                                float (&F)[176]) {
-    // (p - Th) @ R
-    const float qx = px - sc.Th[0], qy = py - sc.Th[1], qz = pz - sc.Th[2];
-    const float cx = fmaf(qz, sc.R[6], fmaf(qy, sc.R[3], qx * sc.R[0]));
-    const float cy = fmaf(qz, sc.R[7], fmaf(qy, sc.R[4], qx * sc.R[1]));
-    const float cz = fmaf(qz, sc.R[8], fmaf(qy, sc.R[5], qx * sc.R[2]));
-    // dhw = (xyz[[2,1,0]] - min_dhw) / voxel_size / out_sh * 2 - 1 ; back to xyz order for grid_sample
-    const float gd = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cz - sc.bmin[2], sc.vs[0]), sc.osh[0]), 2.f), 1.f);
-    const float gh = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cy - sc.bmin[1], sc.vs[1]), sc.osh[1]), 2.f), 1.f);
-    const float gw = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cx - sc.bmin[0], sc.vs[2]), sc.osh[2]), 2.f), 1.f);
-#pragma unroll
-    for (int i = 0; i < 176; ++i) F[i] = 0.f;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        const int C = lvl_c(l), HALF = C / 2, RB = lvl_reg_base(l);
-        const int D = sc.dhw[l][0], H = sc.dhw[l][1], W = sc.dhw[l][2];
-        // grid_sampler_unnormalize, align_corners=True: ((g + 1) / 2) * (size - 1)
-        float ix = __fmul_rn(__fdiv_rn(__fadd_rn(gw, 1.f), 2.f), (float)(W - 1));
-        float iy = __fmul_rn(__fdiv_rn(__fadd_rn(gh, 1.f), 2.f), (float)(H - 1));
-        float iz = __fmul_rn(__fdiv_rn(__fadd_rn(gd, 1.f), 2.f), (float)(D - 1));
-        // keep float->int conversion defined for far-away points (all corners are then out of bounds)
-        ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);
-        iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);
-        iz = fminf(fmaxf(iz, -2.f), (float)D + 1.f);
-        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-        const float wx[2] = {(fx + 1.f) - ix, ix - fx};
-        const float wy[2] = {(fy + 1.f) - iy, iy - fy};
-        const float wz[2] = {(fz + 1.f) - iz, iz - fz};
-        const float *vb = sc.vol[l] + hi * HALF;
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {  // tnw, tne, tsw, tse, bnw, bne, bsw, bse
-            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-            const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
-            const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
-            const float w = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
-            const int xc = min(max(xx, 0), W - 1), yc = min(max(yy, 0), H - 1), zc = min(max(zz, 0), D - 1);
-            const f32x4 *p = reinterpret_cast<const f32x4 *>(vb + ((size_t)(zc * H + yc) * W + xc) * C);
-#pragma unroll
-            for (int q = 0; q < HALF / 4; ++q) {
-                const f32x4 v = p[q];
-                F[RB + 4 * q + 0] = fmaf(w, v.x, F[RB + 4 * q + 0]);
-                F[RB + 4 * q + 1] = fmaf(w, v.y, F[RB + 4 * q + 1]);
-                F[RB + 4 * q + 2] = fmaf(w, v.z, F[RB + 4 * q + 2]);
-                F[RB + 4 * q + 3] = fmaf(w, v.w, F[RB + 4 * q + 3]);
-            }
-        }
-    }
 }
 
 // ---------------------------------------------------------------- per-sample decode
@@ -327,13 +181,6 @@ __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restri
     }
 }
 
-// XCD-aware wave-group remap: consecutive blocks land on different XCDs (block b -> XCD b % 8);
-// give every XCD a contiguous range of ray groups so neighbouring rays share one L2.
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int q = n / 8, r = n % 8, x = b % 8, i = b / 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
-}
-
 // ---------------------------------------------------------------- point-mode kernel
 template <bool DENSITY_ONLY, bool DBG>
 __global__ __launch_bounds__(256) void nb_points_kernel(MarchArgs a) {
@@ -366,11 +213,6 @@ __global__ __launch_bounds__(256) void nb_points_kernel(MarchArgs a) {
 }
 
 // ---------------------------------------------------------------- ray-mode kernel (march + composite)
-__device__ __forceinline__ float z_lin(float near, float far, float t) {
-    // near * (1 - t) + far * t   (if_clight_renderer.py:14), no contraction
-    return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
-}
-
 __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
     const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
     const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
@@ -398,7 +240,7 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
         return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), tr[s]));
     };
 
-    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, accw = 0.f;
+    RayAccum ra;
     float z_cur = z_at(0);
     for (int s = 0; s < S; ++s) {
         const float z_next = (s + 1 < S) ? z_at(s + 1) : 0.f;
@@ -413,38 +255,16 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
         int zero = 0;
         asm volatile("" : "+s"(zero));
         decode<false, false>(a.sc, a.pk + zero, a.lb + zero, px, py, pz, pe, lane, out, nullptr);
-        // raw2outputs (nerf_net_utils.py:19-46)
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
-        const float sig = fmaxf(out[3], 0.f);
-        const float alpha = 1.f - expf(-sig * dist);
-        const float w = alpha * T;
-        T = T * (__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
-        cr = fmaf(w, 1.f / (1.f + expf(-out[0])), cr);
-        cg = fmaf(w, 1.f / (1.f + expf(-out[1])), cg);
-        cb = fmaf(w, 1.f / (1.f + expf(-out[2])), cb);
-        depth = fmaf(w, z_cur, depth);
-        accw += w;
+        const float w = ra.add(out, z_cur, dist);
         if (valid && hi == 0) {
             a.weights[ray * S + s] = w;
             if (a.raw) *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
         }
         z_cur = z_next;
     }
-    if (valid && hi == 0) {
-        if (a.white_bkgd) {
-            cr += 1.f - accw;
-            cg += 1.f - accw;
-            cb += 1.f - accw;
-        }
-        a.rgb_map[ray * 3 + 0] = cr;
-        a.rgb_map[ray * 3 + 1] = cg;
-        a.rgb_map[ray * 3 + 2] = cb;
-        const float q = depth / accw;  // NaN when acc == 0: torch.max propagates it (nerf_net_utils.py:44-45)
-        a.disp_map[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
-        a.acc_map[ray] = accw;
-        a.depth_map[ray] = depth;
-    }
+    if (valid && hi == 0) ra.store(a, ray);
 }
 
 // ---------------------------------------------------------------- composite-only kernel (raw2outputs)
@@ -574,31 +394,11 @@ __global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__
     out[rel] = (float)s;
 }
 
-int fill_scene(const nb_scene *s, SceneDev *d) {
-    for (int l = 0; l < 4; ++l) {
-        NB_REQUIRE(s->vol[l] != nullptr, "nb_scene.vol[%d] is NULL", l);
-        d->vol[l] = s->vol[l];
-        for (int k = 0; k < 3; ++k) {
-            NB_REQUIRE(s->vol_dhw[l][k] >= 1, "nb_scene.vol_dhw[%d][%d] = %d", l, k, s->vol_dhw[l][k]);
-            d->dhw[l][k] = s->vol_dhw[l][k];
-        }
-    }
-    for (int k = 0; k < 9; ++k) d->R[k] = s->R[k];
-    for (int k = 0; k < 3; ++k) {
-        d->Th[k] = s->Th[k];
-        d->bmin[k] = s->bounds_min[k];
-        d->vs[k] = s->voxel_size[k];
-        d->osh[k] = (float)s->out_sh[k];
-        NB_REQUIRE(s->voxel_size[k] > 0.f && s->out_sh[k] > 0, "nb_scene voxel_size/out_sh must be positive");
-    }
-    return NB_OK;
-}
-
 }  // namespace
 
 extern "C" {
 
-int64_t nb_mlp_pack_size(void) { return PACK_SIZE; }
+int64_t nb_mlp_pack_size(void) { return PACK_SIZE + nbm::bf16_stream_floats(); }
 int64_t nb_mlp_latent_bias_size(void) { return 256; }
 
 static int check_params(const nb_mlp_params *p) {
@@ -614,7 +414,7 @@ int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream) {
     NB_REQUIRE(packed != nullptr, "nb_mlp_pack: packed is NULL");
     hipLaunchKernelGGL(nb_pack_kernel, dim3(nb_ceil_div(PACK_SIZE, 256)), dim3(256), 0, (hipStream_t)stream, *p, packed);
     NB_CHECK_LAUNCH("nb_pack_kernel");
-    return NB_OK;
+    return nbm::pack_bf16_stream(p, packed, (hipStream_t)stream);  // reads the merged layer from the fp32 section
 }
 
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream) {
@@ -626,12 +426,14 @@ int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *o
 }
 
 int nb_decode_points(const nb_scene *scene, const float *packed, const float *latent_bias, const float *wpts,
-                     const float *viewdir, int64_t n, int density_only, float *raw_out, float *dbg, void *stream) {
+                     const float *viewdir, int64_t n, int density_only, float *raw_out, float *dbg, int precision,
+                     void *stream) {
     NB_REQUIRE(scene && packed, "nb_decode_points: NULL scene / weights");
     NB_REQUIRE(n >= 0, "nb_decode_points: n = %lld", (long long)n);
     if (n == 0) return NB_OK;
     NB_REQUIRE(wpts && raw_out, "nb_decode_points: NULL wpts / raw_out");
     NB_REQUIRE(density_only || (viewdir && latent_bias), "nb_decode_points: viewdir / latent_bias required");
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3, "nb_decode_points: precision %d", precision);
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
     a.pk = packed;
@@ -643,6 +445,10 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
     a.dbg = dbg;
     const dim3 grid(nb_ceil_div(n, 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (precision == NB_PREC_BF16X3) {
+        if (!a.lb) a.lb = packed + OFF_B2;  // density only: the (unused) colour head still needs a readable bias
+        return nbm::launch_points_bf16(a, density_only, st);
+    }
     if (density_only) hipLaunchKernelGGL((nb_points_kernel<true, false>), grid, block, 0, st, a);
     else if (dbg) hipLaunchKernelGGL((nb_points_kernel<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((nb_points_kernel<false, false>), grid, block, 0, st, a);
@@ -653,7 +459,7 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias, const float *ray_o,
              const float *ray_d, const float *near, const float *far, int64_t n_rays, int32_t n_samples,
              const float *t_vals, const float *t_rand, int white_bkgd, float *rgb_map, float *disp_map,
-             float *acc_map, float *weights, float *depth_map, float *raw, void *stream) {
+             float *acc_map, float *weights, float *depth_map, float *raw, int precision, void *stream) {
     NB_REQUIRE(scene && packed && latent_bias, "nb_march: NULL scene / weights");
     NB_REQUIRE(n_rays >= 0 && n_samples >= 1, "nb_march: n_rays = %lld, n_samples = %d", (long long)n_rays, n_samples);
     if (n_rays == 0) return NB_OK;
@@ -661,24 +467,10 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     NB_REQUIRE(rgb_map && disp_map && acc_map && weights && depth_map, "nb_march: NULL output");
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
-    a.pk = packed;
-    a.lb = latent_bias;
-    a.ray_o = ray_o;
-    a.ray_d = ray_d;
-    a.near = near;
-    a.far = far;
-    a.t_vals = t_vals;
-    a.t_rand = t_rand;
-    a.rgb_map = rgb_map;
-    a.disp_map = disp_map;
-    a.acc_map = acc_map;
-    a.weights = weights;
-    a.depth_map = depth_map;
-    a.raw = raw;
-    a.n_rays = n_rays;
-    a.n_samples = n_samples;
-    a.white_bkgd = white_bkgd;
-    a.n_wave_groups = nb_ceil_div(n_rays, 128);
+    fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, white_bkgd,
+                    rgb_map, disp_map, acc_map, weights, depth_map, raw);
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3, "nb_march: precision %d", precision);
+    if (precision == NB_PREC_BF16X3) return nbm::launch_march_bf16(a, (hipStream_t)stream);
     hipLaunchKernelGGL(nb_march_kernel, dim3(a.n_wave_groups), dim3(256), 0, (hipStream_t)stream, a);
     NB_CHECK_LAUNCH("nb_march_kernel");
     return NB_OK;

@@ -1,0 +1,527 @@
+// nb_march_bf16.hip — split-bf16 ("bf16x3") decode / march kernels for gfx950 (MI355X).
+//
+// Same per-wave organisation as nb_march.hip (one wave = 32 sample columns, activations resident
+// in registers, layers computed transposed so the MFMA C/D fragment of layer l is the B operand of
+// layer l+1), but the GEMMs run on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA
+// rate) with BOTH operands split into bf16 hi + lo parts and three products per K-chunk
+//     W.X  ~=  W_hi.X_hi + W_hi.X_lo + W_lo.X_hi          (fp32 accumulate; the dropped W_lo.X_lo
+// term is 2^-16 relative), which keeps the renderer inside the 1e-4 RGB parity budget where a
+// single bf16 product does not (1.8e-4 single, 9e-7 split).
+//
+// Weight traffic: a wave consumes 2 KiB of weight fragments (A_hi + A_lo) per 3 MFMAs — 85 B/clk/CU,
+// more than the 64 B/clk vector L1 can deliver — so the weight stream goes through LDS: the four
+// waves of a workgroup march in lock step through ONE linear stream of 648 fragment records
+// (1.33 MB per depth step, identical every step), DMA'd by global_load_lds into a 6-slot ring of
+// 24-KiB pages (5 pages in flight ahead of the consumer) and read back with conflict-free
+// ds_read_b128.  One s_barrier per page (36 MFMAs) both publishes the landed page and retires the
+// slot that is refilled next; DMA completion is tracked with counted s_waitcnt vmcnt, never 0.
+#include <type_traits>
+
+#include "nb_march_common.h"
+
+using namespace nbm;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define NB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+namespace nbm {
+
+// --------------------------------------------------------------- weight stream geometry
+constexpr int REC_BYTES = 2048;  // one K=16 chunk of one 32-row tile: A_hi (1 KiB) + A_lo (1 KiB)
+constexpr int PAGE_RECS = 12;
+constexpr int PAGE_BYTES = PAGE_RECS * REC_BYTES;  // 24 KiB
+constexpr int N_SLOTS = 6;
+constexpr int AHEAD = 5;  // pages in flight ahead of the page being consumed
+constexpr int NC0 = 22, NCH = 16, NCV = 22;
+constexpr int REC_L0 = 0;
+constexpr int REC_L1 = REC_L0 + 8 * NC0;
+constexpr int REC_L2 = REC_L1 + 8 * NCH;
+constexpr int REC_L4 = REC_L2 + 8 * NCH;
+constexpr int REC_LV = REC_L4 + 8 * NCH;
+constexpr int N_RECS = REC_LV + 4 * NCV;  // 648
+constexpr int N_PAGES = N_RECS / PAGE_RECS;  // 54
+static_assert(N_RECS % PAGE_RECS == 0, "stream must be a whole number of pages");
+constexpr int DMA_PER_WAVE = PAGE_BYTES / 1024 / 4;  // 6 one-KiB pieces per wave per page
+
+}  // namespace nbm
+
+namespace {
+
+// small fp32 parameters are shared with the f32 blob (same accumulator layout): offsets in floats
+constexpr int F_OFF_B0 = 8 * 44 * 256;
+constexpr int F_OFF_B1 = F_OFF_B0 + 256 + 8 * 32 * 256;
+constexpr int F_OFF_B2 = F_OFF_B1 + 256 + 8 * 32 * 256;
+constexpr int F_OFF_AW = F_OFF_B2 + 256;
+constexpr int F_OFF_AB = F_OFF_AW + 256;
+constexpr int F_OFF_L4 = F_OFF_AB + 4;
+constexpr int F_OFF_LV = F_OFF_L4 + 8 * 32 * 256;
+constexpr int F_OFF_BV = F_OFF_LV + 4 * 44 * 256;
+constexpr int F_OFF_RW = F_OFF_BV + 128;
+constexpr int F_OFF_RB = F_OFF_RW + 384;
+constexpr int F_PACK_SIZE = F_OFF_RB + 4;
+
+// small fp32 parameters staged in LDS behind the ring (ordinary global loads next to in-flight LDS-DMA
+// make hipcc wait vmcnt(0), which would drain the weight pipeline at every tile): offsets in floats
+constexpr int P_B0 = 0, P_B1 = 256, P_B2 = 512, P_LB = 768, P_BV = 1024, P_AW = 1152, P_RW = 1408, P_AB = 1792,
+              P_RB = 1796, P_SIZE = 1800;
+constexpr int RING_BYTES = N_SLOTS * PAGE_BYTES;
+constexpr int LDS_BYTES = RING_BYTES + 8192;
+static_assert(P_SIZE * 4 <= 8192, "parameter region overflow");
+
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
+
+struct Ring {
+    const char *stream;  // global: N_RECS * REC_BYTES bytes, already advanced to this wave's share (uniform)
+    char *lds;           // N_SLOTS * PAGE_BYTES
+    int wave_off;        // byte offset of this wave's share inside a page (uniform)
+    int lane;
+};
+
+// All address arithmetic below is wave-uniform (SGPR) except the single lane * 16 term, so every DMA
+// is `global_load_lds_dwordx4 v_lane16, s[base]` — no per-DMA 64-bit VGPR address to keep alive.
+__device__ __forceinline__ void issue_page(const Ring &rg, int page) {
+    const int slot = page % N_SLOTS;
+    const char *sbase = rg.stream + (size_t)page * PAGE_BYTES;
+    char *dbase = rg.lds + slot * PAGE_BYTES + rg.wave_off;
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+        const char *src = sbase + i * 1024 + rg.lane * 16;
+        char *dst = dbase + i * 1024;  // wave-uniform; the DMA adds lane * 16
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    }
+}
+
+// Called before the first record of `page` is read.  My DMAs issued after that page's are those of
+// pages page+1 .. page+AHEAD-1: allow exactly that many to stay in flight, then rendezvous so that
+// every wave's share has landed (and every wave is done with the slot that gets refilled).
+__device__ __forceinline__ void turn_page(const Ring &rg, int page) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * DMA_PER_WAVE) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    issue_page(rg, (page + AHEAD) % N_PAGES);
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const Ring &rg, int rec, int lo) {
+    const int page = rec / PAGE_RECS;
+    const int off = (page % N_SLOTS) * PAGE_BYTES + (rec % PAGE_RECS) * REC_BYTES + lo * 1024;
+    return *reinterpret_cast<const bf16x8 *>(rg.lds + off + rg.lane * 16);
+}
+
+// split 8 fp32 values into bf16 hi (round to nearest even) and bf16 lo = rne(v - hi)
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)v[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(v[i] - (float)h);
+    }
+}
+
+__device__ __forceinline__ f32x16 bias_tile(const float *bp, int t, int hi) {
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(bp + (t * 2 + hi) * 16);
+    const f32x4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+    return f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+}
+
+// One layer: NT output tiles (processed in interleaved pairs: two independent accumulator chains),
+// NC K=16 chunks.  Stream order within a pair of tiles: (c, t0), (c, t1), (c+1, t0), ...
+// The LDS fragment reads run one record pair ahead of the MFMAs; sched_barrier pins that order
+// (left alone, the scheduler clusters hundreds of ds_reads and spills).
+struct Frag4 {
+    bf16x8 ah0, al0, ah1, al1;
+};
+
+template <int REC0>
+__device__ __forceinline__ Frag4 load_pair(const Ring &rg, int k) {
+    const int rec = REC0 + 2 * k;
+    Frag4 f;
+    if (rec % PAGE_RECS == 0) turn_page(rg, rec / PAGE_RECS);
+    f.ah0 = lds_frag(rg, rec, 0);
+    f.al0 = lds_frag(rg, rec, 1);
+    if ((rec + 1) % PAGE_RECS == 0) turn_page(rg, (rec + 1) / PAGE_RECS);
+    f.ah1 = lds_frag(rg, rec + 1, 0);
+    f.al1 = lds_frag(rg, rec + 1, 1);
+    return f;
+}
+
+template <int REC0, int NT, int NC>
+__device__ __forceinline__ void mlp_layer16(const Ring &rg, const float *bp, f32x16 (&acc)[NT],
+                                            const bf16x8 (&xh)[NC], const bf16x8 (&xl)[NC]) {
+    const int hi = rg.lane >> 5;
+    constexpr int NP = NT / 2 * NC;
+    Frag4 cur = load_pair<REC0>(rg, 0);
+    f32x16 c0, c1;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int tp = k / NC, c = k % NC;
+        if (c == 0) {
+            c0 = bias_tile(bp, 2 * tp, hi);
+            c1 = bias_tile(bp, 2 * tp + 1, hi);
+        }
+        Frag4 nxt = cur;
+        if (k + 1 < NP) nxt = load_pair<REC0>(rg, k + 1);
+        c0 = NB_MFMA16(cur.ah0, xh[c], c0);
+        c1 = NB_MFMA16(cur.ah1, xh[c], c1);
+        c0 = NB_MFMA16(cur.ah0, xl[c], c0);
+        c1 = NB_MFMA16(cur.ah1, xl[c], c1);
+        c0 = NB_MFMA16(cur.al0, xh[c], c0);
+        c1 = NB_MFMA16(cur.al1, xh[c], c1);
+        // issue the next pair's four fragment reads first, so six MFMAs (192 cycles) cover the LDS latency
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (c == NC - 1) {
+            acc[2 * tp] = c0;
+            acc[2 * tp + 1] = c1;
+        }
+        cur = nxt;
+    }
+}
+
+// relu + split of a finished layer into the next layer's B operands: chunk 2t+h <- registers 8h..8h+7 of tile t
+template <bool RELU>
+__device__ __forceinline__ void tiles_to_operands(const f32x16 (&acc)[8], bf16x8 (&xh)[16], bf16x8 (&xl)[16]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = RELU ? fmaxf(acc[t][8 * h + r], 0.f) : acc[t][8 * h + r];
+            split8(v, xh[2 * t + h], xl[2 * t + h]);
+        }
+}
+
+template <int NT>
+__device__ __forceinline__ void dump_tiles(const f32x16 (&h)[NT], float *dst, int hi, bool relu) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[32 * t + tile_row(r, hi)] = relu ? fmaxf(h[t][r], 0.f) : h[t][r];
+}
+
+template <bool DENSITY_ONLY, bool DBG>
+__device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, float px, float py, float pz,
+                                         float vx, float vy, float vz, float (&pe)[N_PE], float (&out)[4],
+                                         float *dbg) {
+    const int hi = rg.lane >> 5;
+    const float *prm = reinterpret_cast<const float *>(rg.lds + RING_BYTES);
+    f32x16 acc[8];
+    bf16x8 xh[16], xl[16];
+    {
+        bf16x8 fh[NC0], fl[NC0];
+        {
+            // level by level: gather (fp32) -> split into the bf16 B operands of fc_0, so only one level's
+            // accumulators are live on the VALU side at a time
+            const GridCoord g = grid_coords(sc, px, py, pz);
+            auto put = [&](auto &f, auto chunk0, auto nchunk, int dbg_base) {
+#pragma unroll
+                for (int c = 0; c < decltype(nchunk)::value; ++c) {
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = f[8 * c + r];
+                    split8(v, fh[decltype(chunk0)::value + c], fl[decltype(chunk0)::value + c]);
+                    if (DBG && dbg) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) dbg[col_feat(dbg_base + 8 * c + r, hi)] = v[r];
+                    }
+                }
+            };
+            {
+                float f[16];
+                gather_level<0>(sc, g, hi, f);
+                put(f, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, 0);
+            }
+            {
+                float f[32];
+                gather_level<1>(sc, g, hi, f);
+                put(f, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, 16);
+            }
+            {
+                float f[64];
+                gather_level<2>(sc, g, hi, f);
+                put(f, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{}, 48);
+            }
+            {
+                float f[64];
+                gather_level<3>(sc, g, hi, f);
+                put(f, std::integral_constant<int, 14>{}, std::integral_constant<int, 8>{}, 112);
+            }
+        }
+        mlp_layer16<REC_L0, 8, NC0>(rg, prm + P_B0, acc, fh, fl);
+    }
+    tiles_to_operands<true>(acc, xh, xl);
+    mlp_layer16<REC_L1, 8, NCH>(rg, prm + P_B1, acc, xh, xl);
+    tiles_to_operands<true>(acc, xh, xl);
+    mlp_layer16<REC_L2, 8, NCH>(rg, prm + P_B2, acc, xh, xl);
+    if (DBG && dbg) dump_tiles(acc, dbg + 352, hi, true);
+    // alpha_fc in fp32 on the VALU from the un-split fc_2 output
+    {
+        const f32x4 *aw = reinterpret_cast<const f32x4 *>(prm + P_AW + hi * 128);
+        float s = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 32; ++q4) {
+            const f32x4 w = aw[q4];
+            s = fmaf(w.x, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 0], 0.f), s);
+            s = fmaf(w.y, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 1], 0.f), s);
+            s = fmaf(w.z, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 2], 0.f), s);
+            s = fmaf(w.w, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 3], 0.f), s);
+        }
+        s += __shfl_xor(s, 32);
+        out[3] = s + prm[P_AB];
+    }
+    tiles_to_operands<true>(acc, xh, xl);
+    // the ring protocol needs every wave to walk the whole stream, so DENSITY_ONLY still runs the
+    // colour head (its result is simply not stored)
+    mlp_layer16<REC_L4, 8, NCH>(rg, prm + P_LB, acc, xh, xl);
+    if (DBG && dbg) dump_tiles(acc, dbg + 352 + 256, hi, false);
+    f32x16 v[4];
+    {
+        bf16x8 vh[NCV], vl[NCV];
+        {
+            bf16x8 gh[16], gl[16];
+            tiles_to_operands<false>(acc, gh, gl);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                vh[c] = gh[c];
+                vl[c] = gl[c];
+            }
+        }
+        // the 30 sin/cos of the world point are only needed here: computing them late keeps ~45 registers
+        // free during the gather and the trunk
+        if (!DENSITY_ONLY) pe_xyz(pe, px, py, pz, vx, vy, vz, hi);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {  // 45 positional-encoding slots, zero padded to 48
+            float t[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) t[r] = (8 * c + r < N_PE) ? pe[(8 * c + r < N_PE) ? 8 * c + r : 0] : 0.f;
+            split8(t, vh[16 + c], vl[16 + c]);
+        }
+        mlp_layer16<REC_LV, 4, NCV>(rg, prm + P_BV, v, vh, vl);
+    }
+    if (DBG && dbg) dump_tiles(v, dbg + 352 + 512, hi, true);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const f32x4 *rw = reinterpret_cast<const f32x4 *>(prm + P_RW + (ch * 2 + hi) * 64);
+        float s = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 16; ++q4) {
+            const f32x4 w = rw[q4];
+            s = fmaf(w.x, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 0], 0.f), s);
+            s = fmaf(w.y, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 1], 0.f), s);
+            s = fmaf(w.z, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 2], 0.f), s);
+            s = fmaf(w.w, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 3], 0.f), s);
+        }
+        s += __shfl_xor(s, 32);
+        out[ch] = s + prm[P_RB + ch];
+    }
+}
+
+__device__ __forceinline__ Ring ring_begin(const float *pk, const float *lb, char *lds) {
+    {
+        float *prm = reinterpret_cast<float *>(lds + RING_BYTES);
+        for (int i = threadIdx.x; i < P_SIZE; i += 256) {
+            float v;
+            if (i < P_B1) v = pk[F_OFF_B0 + i - P_B0];
+            else if (i < P_B2) v = pk[F_OFF_B1 + i - P_B1];
+            else if (i < P_LB) v = pk[F_OFF_B2 + i - P_B2];
+            else if (i < P_BV) v = lb[i - P_LB];
+            else if (i < P_AW) v = pk[F_OFF_BV + i - P_BV];
+            else if (i < P_RW) v = pk[F_OFF_AW + i - P_AW];
+            else if (i < P_AB) v = pk[F_OFF_RW + i - P_RW];
+            else if (i < P_RB) v = pk[F_OFF_AB + i - P_AB];
+            else v = pk[F_OFF_RB + i - P_RB];
+            prm[i] = v;
+        }
+        __syncthreads();
+    }
+    Ring rg;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    rg.wave_off = wave * (DMA_PER_WAVE * 1024);
+    rg.stream = reinterpret_cast<const char *>(pk + F_PACK_SIZE) + rg.wave_off;
+    rg.lds = lds;
+    rg.lane = threadIdx.x & 63;
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p) issue_page(rg, p);
+    return rg;
+}
+
+__device__ __forceinline__ void ring_end() {
+    // pages prefetched past the end of the work are still in flight: let them land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+}
+
+// ---------------------------------------------------------------- point mode
+template <bool DENSITY_ONLY, bool DBG>
+__global__ __launch_bounds__(256) void nb_points16_kernel(MarchArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const Ring rg = ring_begin(a.pk, a.lb, lds);
+    const int lane = rg.lane, j = lane & 31, hi = lane >> 5;
+    const long long wave = (long long)blockIdx.x * 4 + rg.wave_off / (DMA_PER_WAVE * 1024);
+    long long idx = wave * 32 + j;
+    const bool valid = idx < a.n_pts;  // whole waves past the end keep walking the ring (barriers!)
+    if (!valid) idx = a.n_pts - 1;
+    const float px = a.wpts[idx * 3 + 0], py = a.wpts[idx * 3 + 1], pz = a.wpts[idx * 3 + 2];
+    float pe[N_PE];
+#pragma unroll
+    for (int c = 0; c < N_PE; ++c) pe[c] = 0.f;
+    float v3[3] = {0.f, 0.f, 0.f};
+    if (!DENSITY_ONLY) {
+        const float vx = a.viewdir[idx * 3 + 0], vy = a.viewdir[idx * 3 + 1], vz = a.viewdir[idx * 3 + 2];
+        pe_view(pe, vx, vy, vz, hi);
+        v3[0] = vx;
+        v3[1] = vy;
+        v3[2] = vz;
+    }
+    float out[4];
+    float *dbg = (DBG && a.dbg && valid) ? a.dbg + idx * 992 : nullptr;
+    decode16<DENSITY_ONLY, DBG>(a.sc, rg, px, py, pz, v3[0], v3[1], v3[2], pe, out, dbg);
+    if (valid && hi == 0) {
+        if (DENSITY_ONLY) {
+            a.raw_out[idx] = out[3];
+        } else {
+            *reinterpret_cast<f32x4 *>(a.raw_out + idx * 4) = f32x4{out[0], out[1], out[2], out[3]};
+        }
+    }
+    ring_end();
+}
+
+// ---------------------------------------------------------------- ray mode
+__global__ __launch_bounds__(256) void nb_march16_kernel(MarchArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const Ring rg = ring_begin(a.pk, a.lb, lds);
+    const int lane = rg.lane, j = lane & 31, hi = lane >> 5;
+    const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
+    const long long wave = (long long)grp * 4 + rg.wave_off / (DMA_PER_WAVE * 1024);
+    long long ray = wave * 32 + j;
+    const bool valid = ray < a.n_rays;
+    if (!valid) ray = a.n_rays - 1;
+    const int S = a.n_samples;
+    const float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
+    const float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
+    const float near = a.near[ray], far = a.far[ray];
+    const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float vx = dx / dn, vy = dy / dn, vz = dz / dn;
+    float pe[N_PE];
+    pe_view(pe, vx, vy, vz, hi);
+    const float *tr = a.t_rand ? a.t_rand + ray * S : nullptr;
+
+    auto z_at = [&](int s) -> float {
+        const float zc = z_lin(near, far, a.t_vals[s]);
+        if (!tr) return zc;
+        const float lower = s == 0 ? zc : 0.5f * __fadd_rn(zc, z_lin(near, far, a.t_vals[s - 1]));
+        const float upper = s == S - 1 ? zc : 0.5f * __fadd_rn(z_lin(near, far, a.t_vals[s + 1]), zc);
+        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), tr[s]));
+    };
+
+    RayAccum ra;
+    float z_cur = z_at(0);
+    for (int s = 0; s < S; ++s) {
+        // The pages prefetched for this step's first layers were requested during the previous step and have
+        // landed by now; a compiler-visible vmcnt(0) here costs nothing and clears hipcc's "LDS-DMA pending"
+        // state, so the gather's ordinary loads below get counted waits instead of a drain per load.
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        const float z_next = (s + 1 < S) ? z_at(s + 1) : 0.f;
+        const float px = __fadd_rn(ox, __fmul_rn(dx, z_cur));
+        const float py = __fadd_rn(oy, __fmul_rn(dy, z_cur));
+        const float pz = __fadd_rn(oz, __fmul_rn(dz, z_cur));
+        float out[4];
+        // everything the weight stream touches is loop-invariant; an opaque zero keeps the (hundreds of)
+        // DMA source / destination addresses and small-parameter loads from being hoisted and spilled
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        Ring r2 = rg;
+        r2.stream = rg.stream + zero;
+        r2.wave_off = rg.wave_off + zero;
+        decode16<false, false>(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, nullptr);
+        float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
+        dist = __fmul_rn(dist, dn);
+        const float w = ra.add(out, z_cur, dist);
+        if (valid && hi == 0) {
+            a.weights[ray * S + s] = w;
+            if (a.raw) *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
+        }
+        z_cur = z_next;
+    }
+    if (valid && hi == 0) ra.store(a, ray);
+    ring_end();
+}
+
+// ---------------------------------------------------------------- weight stream packing
+__device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ void nb_pack16_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, unsigned short *__restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one (rec, lane, r) weight, writes hi and lo
+    if (e >= (long long)N_RECS * 64 * 8) return;
+    const int r = (int)(e & 7), lane = (int)((e >> 3) & 63), rec = (int)(e >> 9);
+    const int i = lane & 31, kg = lane >> 5;
+    // locate (layer, tile, chunk): within a layer records go pair by pair, (c, t0), (c, t1), ...
+    int base, nc, layer;
+    if (rec < REC_L1) { layer = 0; base = REC_L0; nc = NC0; }
+    else if (rec < REC_L2) { layer = 1; base = REC_L1; nc = NCH; }
+    else if (rec < REC_L4) { layer = 2; base = REC_L2; nc = NCH; }
+    else if (rec < REC_LV) { layer = 4; base = REC_L4; nc = NCH; }
+    else { layer = 5; base = REC_LV; nc = NCV; }
+    const int rel = rec - base, tp = rel / (2 * nc), c = (rel % (2 * nc)) >> 1, t = 2 * tp + (rel & 1);
+    const int row = 32 * t + i, q = 8 * c + r;
+    float w = 0.f;
+    if (layer == 0) w = p.fc0_w[row * 352 + col_feat(q, kg)];
+    else if (layer == 1) w = p.fc1_w[row * 256 + col_hidden(q, kg)];
+    else if (layer == 2) w = p.fc2_w[row * 256 + col_hidden(q, kg)];
+    else if (layer == 4) {
+        // merged latent_fc[:, :256] @ feature_fc, taken from the f32 blob (already computed in fp64 there):
+        // f32 layout ((t*32 + g)*64 + lane')*4 + e with chunk2 = 4g+e <-> column col_hidden(chunk2, hi')
+        const int col = col_hidden(q, kg);
+        // invert col_hidden: find (q2, hi2) with col_hidden(q2, hi2) == col
+        const int tt = col >> 5, rr = col & 31, hi2 = (rr >> 2) & 1, r2 = (rr & 3) + 4 * (rr >> 3);
+        const int q2 = 16 * tt + r2;
+        w = f32_blob[F_OFF_L4 + ((t * 32 + (q2 >> 2)) * 64 + (hi2 * 32 + i)) * 4 + (q2 & 3)];
+    } else {
+        const int col = q < 128 ? col_hidden(q, kg) : col_pe(q - 128, kg);
+        w = col < 0 ? 0.f : p.view_w[row * 346 + col];
+    }
+    const unsigned short h = bf16_rne_bits(w);
+    const float hf = __uint_as_float((unsigned)h << 16);
+    const unsigned short l = bf16_rne_bits(w - hf);
+    unsigned short *recp = out + (size_t)rec * (REC_BYTES / 2);
+    recp[lane * 8 + r] = h;
+    recp[512 + lane * 8 + r] = l;
+}
+
+}  // namespace
+
+namespace nbm {
+
+long long bf16_stream_floats() { return (long long)N_RECS * REC_BYTES / 4; }
+
+int pack_bf16_stream(const nb_mlp_params *p, float *packed, hipStream_t st) {
+    const long long n = (long long)N_RECS * 64 * 8;
+    hipLaunchKernelGGL(nb_pack16_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, st, *p, packed,
+                       reinterpret_cast<unsigned short *>(packed + F_PACK_SIZE));
+    NB_CHECK_LAUNCH("nb_pack16_kernel");
+    return NB_OK;
+}
+
+int launch_points_bf16(const MarchArgs &a, int density_only, hipStream_t st) {
+    const dim3 grid(nb_ceil_div(a.n_pts, 128)), block(256);
+    if (density_only) hipLaunchKernelGGL((nb_points16_kernel<true, false>), grid, block, 0, st, a);
+    else if (a.dbg) hipLaunchKernelGGL((nb_points16_kernel<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((nb_points16_kernel<false, false>), grid, block, 0, st, a);
+    NB_CHECK_LAUNCH("nb_points16_kernel");
+    return NB_OK;
+}
+
+int launch_march_bf16(const MarchArgs &a, hipStream_t st) {
+    hipLaunchKernelGGL(nb_march16_kernel, dim3(a.n_wave_groups), dim3(256), 0, st, a);
+    NB_CHECK_LAUNCH("nb_march16_kernel");
+    return NB_OK;
+}
+
+}  // namespace nbm

@@ -1,0 +1,298 @@
+// nb_march_common.h — device code shared by the f32 (nb_march.hip) and split-bf16 (nb_march_bf16.hip)
+// decode / march kernels: scene + argument structs, feature-vector layout, trilinear gather,
+// positional encoding, sampling helpers, XCD-aware block remap.
+#pragma once
+#include "nb_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace nbm {
+
+constexpr int N_PE = 45;
+
+// feature row (within a 32-row tile) held by accumulator register r of a lane with half index hi
+__host__ __device__ constexpr int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// channel layout of the gathered feature vector (latent_xyzc.py:63-71)
+__host__ __device__ constexpr int lvl_c(int l) { return l == 0 ? 32 : (l == 1 ? 64 : 128); }
+__host__ __device__ constexpr int lvl_chan_base(int l) { return l == 0 ? 0 : (l == 1 ? 32 : (l == 2 ? 96 : 224)); }
+__host__ __device__ constexpr int lvl_reg_base(int l) { return lvl_chan_base(l) / 2; }
+
+// fc_0 input column held in gather register q (0..175) of a lane with half index hi
+__host__ __device__ inline int col_feat(int q, int hi) {
+    int l = q < 16 ? 0 : (q < 48 ? 1 : (q < 112 ? 2 : 3));
+    return lvl_chan_base(l) + hi * (lvl_c(l) / 2) + (q - lvl_reg_base(l));
+}
+// input column for accumulator element q = 16 * tile + r of the previous layer
+__host__ __device__ inline int col_hidden(int q, int hi) { return 32 * (q >> 4) + tile_row(q & 15, hi); }
+// view_fc column (346 = 256 + 27 + 63, latent_xyzc.py:113-118) for PE slot c, -1 = zero pad
+__host__ __device__ inline int col_pe(int c, int hi) {
+    if (c < 12) {  // view direction, frequency k = c/3, axis a = c%3: hi=0 sin, hi=1 cos
+        int k = c / 3, a = c % 3;
+        return 256 + 3 + 6 * k + 3 * hi + a;
+    }
+    if (c < 42) {  // world xyz
+        int k = (c - 12) / 3, a = (c - 12) % 3;
+        return 256 + 27 + 3 + 6 * k + 3 * hi + a;
+    }
+    if (c < 45) {  // raw inputs: hi=0 viewdir_a, hi=1 xyz_a
+        int a = c - 42;
+        return hi ? (256 + 27 + a) : (256 + a);
+    }
+    return -1;
+}
+
+struct SceneDev {
+    const float *vol[4];
+    int dhw[4][3];
+    float R[9];
+    float Th[3];
+    float bmin[3];
+    float vs[3];
+    float osh[3];
+};
+
+struct MarchArgs {
+    SceneDev sc;
+    const float *pk;  // packed decoder weights (format depends on the kernel family)
+    const float *lb;
+    // ray mode
+    const float *ray_o, *ray_d, *near, *far, *t_vals, *t_rand;
+    float *rgb_map, *disp_map, *acc_map, *weights, *depth_map, *raw;
+    long long n_rays;
+    int n_samples;
+    int white_bkgd;
+    // point mode
+    const float *wpts, *viewdir;
+    float *raw_out, *dbg;
+    long long n_pts;
+    int n_wave_groups;
+};
+
+// ---------------------------------------------------------------- positional encoding
+// embedder.py:26-36: [x, sin(x*2^k), cos(x*2^k)]_k ; x*2^k is exact in fp32.
+__device__ __forceinline__ void pe_view(float (&pe)[N_PE], float vx, float vy, float vz, int hi) {
+    const float v[3] = {vx, vy, vz};
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float s, c;
+            sincosf(v[a] * (float)(1 << k), &s, &c);
+            pe[3 * k + a] = hi ? c : s;
+        }
+}
+__device__ __forceinline__ void pe_xyz(float (&pe)[N_PE], float px, float py, float pz, float vx, float vy,
+                                       float vz, int hi) {
+    const float p[3] = {px, py, pz};
+    const float v[3] = {vx, vy, vz};
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float s, c;
+            sincosf(p[a] * (float)(1 << k), &s, &c);
+            pe[12 + 3 * k + a] = hi ? c : s;
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) pe[42 + a] = hi ? p[a] : v[a];
+}
+
+// ---------------------------------------------------------------- trilinear gather (K3 + K4)
+// latent_xyzc.py:41-60 then grid_sample(align_corners=True, zeros) per level (:62-72).
+// Lane (j, hi) accumulates channels [hi*C/2, (hi+1)*C/2) of every level for sample j.
+struct GridCoord {
+    float gw, gh, gd;  // normalised [-1,1] coordinates in grid_sample's x (W), y (H), z (D) order
+};
+
+__device__ __forceinline__ GridCoord grid_coords(const SceneDev &sc, float px, float py, float pz) {
+    // (p - Th) @ R
+    const float qx = px - sc.Th[0], qy = py - sc.Th[1], qz = pz - sc.Th[2];
+    const float cx = fmaf(qz, sc.R[6], fmaf(qy, sc.R[3], qx * sc.R[0]));
+    const float cy = fmaf(qz, sc.R[7], fmaf(qy, sc.R[4], qx * sc.R[1]));
+    const float cz = fmaf(qz, sc.R[8], fmaf(qy, sc.R[5], qx * sc.R[2]));
+    // dhw = (xyz[[2,1,0]] - min_dhw) / voxel_size / out_sh * 2 - 1 ; back to xyz order for grid_sample
+    GridCoord g;
+    g.gd = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cz - sc.bmin[2], sc.vs[0]), sc.osh[0]), 2.f), 1.f);
+    g.gh = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cy - sc.bmin[1], sc.vs[1]), sc.osh[1]), 2.f), 1.f);
+    g.gw = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cx - sc.bmin[0], sc.vs[2]), sc.osh[2]), 2.f), 1.f);
+    return g;
+}
+
+// One pyramid level.  The 8 corners x 16 channels of a group are fetched as 32 independent 16-byte
+// loads BEFORE any of them is consumed (memory-level parallelism: the gather is L2-latency bound),
+// then blended in the reference's corner order tnw, tne, tsw, tse, bnw, bne, bsw, bse.
+template <int L>
+__device__ __forceinline__ void gather_level(const SceneDev &sc, const GridCoord &g, int hi,
+                                             float (&out)[lvl_c(L) / 2]) {
+    constexpr int C = lvl_c(L), HALF = C / 2;
+    const int D = sc.dhw[L][0], H = sc.dhw[L][1], W = sc.dhw[L][2];
+    // grid_sampler_unnormalize, align_corners=True: ((g + 1) / 2) * (size - 1)
+    float ix = __fmul_rn(__fdiv_rn(__fadd_rn(g.gw, 1.f), 2.f), (float)(W - 1));
+    float iy = __fmul_rn(__fdiv_rn(__fadd_rn(g.gh, 1.f), 2.f), (float)(H - 1));
+    float iz = __fmul_rn(__fdiv_rn(__fadd_rn(g.gd, 1.f), 2.f), (float)(D - 1));
+    // keep float->int conversion defined for far-away points (all corners are then out of bounds)
+    ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);
+    iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);
+    iz = fminf(fmaxf(iz, -2.f), (float)D + 1.f);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx[2] = {(fx + 1.f) - ix, ix - fx};
+    const float wy[2] = {(fy + 1.f) - iy, iy - fy};
+    const float wz[2] = {(fz + 1.f) - iz, iz - fz};
+    const float *vb = sc.vol[L] + hi * HALF;
+    const f32x4 *cp[8];
+    float cw[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+        const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
+        cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
+        const int xc = min(max(xx, 0), W - 1), yc = min(max(yy, 0), H - 1), zc = min(max(zz, 0), D - 1);
+        cp[corner] = reinterpret_cast<const f32x4 *>(vb + ((size_t)(zc * H + yc) * W + xc) * C);
+    }
+#pragma unroll
+    for (int grp = 0; grp < HALF / 16; ++grp) {
+        f32x4 v[8][4];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[corner][q] = cp[corner][grp * 4 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                a.x = fmaf(cw[corner], v[corner][q].x, a.x);
+                a.y = fmaf(cw[corner], v[corner][q].y, a.y);
+                a.z = fmaf(cw[corner], v[corner][q].z, a.z);
+                a.w = fmaf(cw[corner], v[corner][q].w, a.w);
+            }
+            out[grp * 16 + q * 4 + 0] = a.x;
+            out[grp * 16 + q * 4 + 1] = a.y;
+            out[grp * 16 + q * 4 + 2] = a.z;
+            out[grp * 16 + q * 4 + 3] = a.w;
+        }
+        // 32 VMEM reads, then the 128 FMAs that consume them; nothing moves across the group boundary
+        __builtin_amdgcn_sched_group_barrier(0x020, 32, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 128, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__device__ __forceinline__ void gather_features(const SceneDev &sc, float px, float py, float pz, int hi,
+                                                float (&F)[176]) {
+    const GridCoord g = grid_coords(sc, px, py, pz);
+    float f0[16], f1[32], f2[64], f3[64];
+    gather_level<0>(sc, g, hi, f0);
+    gather_level<1>(sc, g, hi, f1);
+    gather_level<2>(sc, g, hi, f2);
+    gather_level<3>(sc, g, hi, f3);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) F[i] = f0[i];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) F[16 + i] = f1[i];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) F[48 + i] = f2[i];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) F[112 + i] = f3[i];
+}
+
+// XCD-aware wave-group remap: consecutive blocks land on different XCDs (block b -> XCD b % 8);
+// give every XCD a contiguous range of ray groups so neighbouring rays share one L2.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    const int q = n / 8, r = n % 8, x = b % 8, i = b / 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}
+
+__device__ __forceinline__ float z_lin(float near, float far, float t) {
+    // near * (1 - t) + far * t   (if_clight_renderer.py:14), no contraction
+    return __fadd_rn(__fmul_rn(near, __fsub_rn(1.f, t)), __fmul_rn(far, t));
+}
+
+
+// raw2outputs (nerf_net_utils.py:19-46) for one sample, carried front to back
+struct RayAccum {
+    float T = 1.f, cr = 0.f, cg = 0.f, cb = 0.f, depth = 0.f, accw = 0.f;
+    __device__ __forceinline__ float add(const float (&out)[4], float z_cur, float dist_scaled) {
+        const float sig = fmaxf(out[3], 0.f);
+        const float alpha = 1.f - expf(-sig * dist_scaled);
+        const float w = alpha * T;
+        T = T * (__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
+        cr = fmaf(w, 1.f / (1.f + expf(-out[0])), cr);
+        cg = fmaf(w, 1.f / (1.f + expf(-out[1])), cg);
+        cb = fmaf(w, 1.f / (1.f + expf(-out[2])), cb);
+        depth = fmaf(w, z_cur, depth);
+        accw += w;
+        return w;
+    }
+    __device__ __forceinline__ void store(const MarchArgs &a, long long ray) {
+        if (a.white_bkgd) {
+            cr += 1.f - accw;
+            cg += 1.f - accw;
+            cb += 1.f - accw;
+        }
+        a.rgb_map[ray * 3 + 0] = cr;
+        a.rgb_map[ray * 3 + 1] = cg;
+        a.rgb_map[ray * 3 + 2] = cb;
+        const float q = depth / accw;  // NaN when acc == 0: torch.max propagates it (nerf_net_utils.py:44-45)
+        a.disp_map[ray] = 1.f / ((q != q) ? q : fmaxf(1e-10f, q));
+        a.acc_map[ray] = accw;
+        a.depth_map[ray] = depth;
+    }
+};
+
+inline int fill_scene(const nb_scene *s, SceneDev *d) {
+    for (int l = 0; l < 4; ++l) {
+        NB_REQUIRE(s->vol[l] != nullptr, "nb_scene.vol[%d] is NULL", l);
+        d->vol[l] = s->vol[l];
+        for (int k = 0; k < 3; ++k) {
+            NB_REQUIRE(s->vol_dhw[l][k] >= 1, "nb_scene.vol_dhw[%d][%d] = %d", l, k, s->vol_dhw[l][k]);
+            d->dhw[l][k] = s->vol_dhw[l][k];
+        }
+    }
+    for (int k = 0; k < 9; ++k) d->R[k] = s->R[k];
+    for (int k = 0; k < 3; ++k) {
+        d->Th[k] = s->Th[k];
+        d->bmin[k] = s->bounds_min[k];
+        d->vs[k] = s->voxel_size[k];
+        d->osh[k] = (float)s->out_sh[k];
+        NB_REQUIRE(s->voxel_size[k] > 0.f && s->out_sh[k] > 0, "nb_scene voxel_size/out_sh must be positive");
+    }
+    return NB_OK;
+}
+
+
+inline void fill_march_args(MarchArgs &a, const float *packed, const float *latent_bias, const float *ray_o,
+                            const float *ray_d, const float *near, const float *far, long long n_rays, int n_samples,
+                            const float *t_vals, const float *t_rand, int white_bkgd, float *rgb_map, float *disp_map,
+                            float *acc_map, float *weights, float *depth_map, float *raw) {
+    a.pk = packed;
+    a.lb = latent_bias;
+    a.ray_o = ray_o;
+    a.ray_d = ray_d;
+    a.near = near;
+    a.far = far;
+    a.t_vals = t_vals;
+    a.t_rand = t_rand;
+    a.rgb_map = rgb_map;
+    a.disp_map = disp_map;
+    a.acc_map = acc_map;
+    a.weights = weights;
+    a.depth_map = depth_map;
+    a.raw = raw;
+    a.n_rays = n_rays;
+    a.n_samples = n_samples;
+    a.white_bkgd = white_bkgd;
+    a.n_wave_groups = nb_ceil_div(n_rays, 128);
+}
+
+// split-bf16 kernel family (nb_march_bf16.hip)
+long long bf16_stream_floats();
+int pack_bf16_stream(const nb_mlp_params *p, float *packed, hipStream_t st);
+int launch_points_bf16(const MarchArgs &a, int density_only, hipStream_t st);
+int launch_march_bf16(const MarchArgs &a, hipStream_t st);
+
+}  // namespace nbm

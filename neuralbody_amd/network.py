@@ -14,6 +14,7 @@ Kept from the reference:
 New: `render_rays(...)`, the fused march used by `Renderer.render` (one launch for all rays).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -30,6 +31,7 @@ ENCODER_BLOCKS = [
 ]
 DENSE_AFTER = ("conv1", "conv2", "conv3", "conv4")  # latent_xyzc.py:188-201
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
+DEFAULT_PRECISION = "f32"
 
 
 class SparseConv3dParam(nn.Module):
@@ -109,8 +111,13 @@ _MLP_NAMES = {"fc0": "fc_0", "fc1": "fc_1", "fc2": "fc_2", "alpha": "alpha_fc", 
 
 
 class Network(nn.Module):
-    def __init__(self, num_train_frame, voxel_size=(0.005, 0.005, 0.005), xyz_res=10, view_res=4):
+    def __init__(self, num_train_frame, voxel_size=(0.005, 0.005, 0.005), xyz_res=10, view_res=4, precision=None):
         super().__init__()
+        # decoder GEMM arithmetic: "bf16x3" (split-bf16 MFMA, 3 products, fp32 accumulate) or "f32" (exact
+        # fp32 MFMA); both stay inside the 1e-4 RGB parity budget, see DESIGN.md
+        self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
+        if self.precision not in ("f32", "bf16x3"):
+            raise ValueError("precision must be 'f32' or 'bf16x3'")
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -201,7 +208,8 @@ class Network(nn.Module):
         if n_batch != 1:
             raise NotImplementedError("batch size 1 only")
         p = wpts.reshape(-1, 3).float().contiguous()
-        out = ops.decode_points(scene, self.packed_weights(), None, p, None, density_only=True)
+        out = ops.decode_points(scene, self.packed_weights(), None, p, None, density_only=True,
+                                precision=self.precision)
         return out.view(1, -1, 1)
 
     def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
@@ -211,7 +219,7 @@ class Network(nn.Module):
         p = wpts.reshape(-1, 3).float().contiguous()
         v = viewdir.reshape(-1, 3).float().contiguous()
         lb = self.latent_bias(sp_input["latent_index"])
-        out = ops.decode_points(scene, self.packed_weights(), lb, p, v)
+        out = ops.decode_points(scene, self.packed_weights(), lb, p, v, precision=self.precision)
         return out.view(1, -1, 4)
 
     def forward(self, sp_input, grid_coords, viewdir, light_pts):
@@ -234,4 +242,4 @@ class Network(nn.Module):
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._host_cache[key] = t_vals
         return ops.march(scene, self.packed_weights(), lb, ray_o, ray_d, near, far, t_vals, t_rand,
-                         white_bkgd=white_bkgd, want_raw=want_raw)
+                         white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision)

@@ -112,7 +112,7 @@ def mlp_latent_bias(params, latent_row, out=None):
     return out
 
 
-def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=False, debug=False):
+def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=False, debug=False, precision="f32"):
     """nb_decode_points: wpts [n,3] (+ viewdir [n,3]) -> raw [n,4] (or sigma [n,1])."""
     sc, _keep = scene
     _req(packed, torch.float32, (mlp_pack_size(),), "packed")
@@ -124,12 +124,13 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
     out = torch.empty((n, 1 if density_only else 4), dtype=torch.float32, device=wpts.device)
     dbg = torch.zeros((n, DBG_WIDTH), dtype=torch.float32, device=wpts.device) if debug else None
     check(_lib.lib().nb_decode_points(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(wpts), ptr(viewdir), n,
-                                      1 if density_only else 0, ptr(out), ptr(dbg), _stream()), "nb_decode_points")
+                                      1 if density_only else 0, ptr(out), ptr(dbg), _lib.PRECISIONS[precision],
+                                      _stream()), "nb_decode_points")
     return (out, dbg) if debug else out
 
 
 def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=None, white_bkgd=False,
-          want_raw=False):
+          want_raw=False, precision="f32"):
     """nb_march: all rays of one batch element -> dict of per-ray outputs."""
     sc, _keep = scene
     _req(packed, torch.float32, (mlp_pack_size(),), "packed")
@@ -156,7 +157,7 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
         ev[0].record()
     check(_lib.lib().nb_march(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(ray_o), ptr(ray_d), ptr(near), ptr(far),
                               n, S, ptr(t_vals), ptr(t_rand), 1 if white_bkgd else 0, ptr(rgb), ptr(disp), ptr(acc),
-                              ptr(weights), ptr(depth), ptr(raw), _stream()), "nb_march")
+                              ptr(weights), ptr(depth), ptr(raw), _lib.PRECISIONS[precision], _stream()), "nb_march")
     if ev is not None:
         ev[1].record()
         MARCH_EVENTS.append(ev)

@@ -18,10 +18,10 @@ def device_batch(batch_np, dev="cuda:0"):
     return {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in batch_np.items()}
 
 
-def make_network(sd_np, dev="cuda:0", train=True):
+def make_network(sd_np, dev="cuda:0", train=True, precision="f32"):
     from neuralbody_amd.network import Network
 
-    net = Network(num_train_frame=sd_np["latent.weight"].shape[0])
+    net = Network(num_train_frame=sd_np["latent.weight"].shape[0], precision=precision)
     sd = {k: torch.from_numpy(np.array(v)) for k, v in sd_np.items()}
     missing = net.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 ALL = list(scenes.SCENES)
+PRECISIONS = ["f32", "bf16x3"]
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -26,13 +27,13 @@ def _need_gpu():
     _lib.lib()  # fail loudly if libnb_hip.so is missing
 
 
-def _scene_with_oracle_volumes(name):
+def _scene_with_oracle_volumes(name, precision="f32"):
     from neuralbody_amd import ops
 
     r, sd, body, batch, cam, t_rand = scenes.build(name)
     training = r["mode"] == "train"
     sdt, vols, out_sh = H.oracle_volumes(sd, batch, training)
-    net = H.make_network(sd, DEV, training)
+    net = H.make_network(sd, DEV, training, precision)
     bd = H.device_batch(batch, DEV)
     vols_dev = [v.to(DEV) for v in vols]  # NCDHW; Network converts to channels-last
     sp = H.sp_input_of(bd, out_sh)
@@ -40,13 +41,14 @@ def _scene_with_oracle_volumes(name):
 
 
 # ------------------------------------------------------------------------------------------- decode
-def test_decode_points_stages_against_oracle():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_decode_points_stages_against_oracle(precision):
     """nb_decode_points with the debug tap: gathered features (K3/K4), fc_2 output (K5), the merged
     feature/latent layer, view_fc hidden (K6/K7) and raw, each against the oracle."""
     from neuralbody_amd import ops
     from oracle import neuralbody_oracle as orc
 
-    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, _ = _scene_with_oracle_volumes("small")
+    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, _ = _scene_with_oracle_volumes("small", precision)
     ns = r["n_samples"]
     ray_o, ray_d = torch.from_numpy(batch["ray_o"]), torch.from_numpy(batch["ray_d"])
     near, far = torch.from_numpy(batch["near"]), torch.from_numpy(batch["far"])
@@ -72,7 +74,7 @@ def test_decode_points_stages_against_oracle():
     scene = net.make_scene(vols_dev, sp)
     lb = net.latent_bias(bd["latent_index"])
     out, dbg = ops.decode_points(scene, net.packed_weights(), lb, w[0].to(DEV).contiguous(), v[0].to(DEV).contiguous(),
-                                 debug=True)
+                                 debug=True, precision=precision)
     torch.cuda.synchronize()
     dbg = dbg.cpu().numpy()
     H.assert_close(dbg[:, :352], feat.numpy(), 2e-5, "trilinear features")
@@ -87,9 +89,11 @@ def test_decode_points_stages_against_oracle():
     assert dens_api.shape == (1, w.shape[1], 1)
     H.assert_close(dens_api[0].cpu().numpy(), dens.numpy(), 2e-4, "calculate_density")
     # ragged size: n not a multiple of 32, and n == 0
-    part = ops.decode_points(scene, net.packed_weights(), lb, w[0, :77].to(DEV).contiguous(), v[0, :77].to(DEV).contiguous())
+    part = ops.decode_points(scene, net.packed_weights(), lb, w[0, :77].to(DEV).contiguous(), v[0, :77].to(DEV).contiguous(),
+                             precision=precision)
     assert torch.equal(part, out[:77])
-    empty = ops.decode_points(scene, net.packed_weights(), lb, w[0, :0].to(DEV).contiguous(), v[0, :0].to(DEV).contiguous())
+    empty = ops.decode_points(scene, net.packed_weights(), lb, w[0, :0].to(DEV).contiguous(), v[0, :0].to(DEV).contiguous(),
+                              precision=precision)
     assert empty.shape == (0, 4)
 
 
@@ -108,10 +112,11 @@ def test_decode_matches_reference_raw_subset():
 
 
 # ------------------------------------------------------------------------------------------- march
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ALL)
-def test_march_on_oracle_volumes_matches_reference(name):
+def test_march_on_oracle_volumes_matches_reference(name, precision):
     """nb_march fed with the oracle's feature volumes against the reference renderer's outputs."""
-    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, t_rand = _scene_with_oracle_volumes(name)
+    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, t_rand = _scene_with_oracle_volumes(name, precision)
     g = H.golden(name)
     tr = None if t_rand is None else torch.from_numpy(t_rand)[0].to(DEV).contiguous()
     out = net.render_rays(bd["ray_o"][0], bd["ray_d"][0], bd["near"][0], bd["far"][0], vols_dev, sp, r["n_samples"],
@@ -217,12 +222,13 @@ def test_encoder_edge_cases():
 
 
 # ------------------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ALL)
-def test_render_end_to_end_matches_reference(name):
+def test_render_end_to_end_matches_reference(name, precision):
     """Renderer.render(batch) — encoder + march, all HIP — against the reference renderer's outputs."""
     r, sd, body, batch, cam, t_rand = scenes.build(name)
     g = H.golden(name)
-    net = H.make_network(sd, DEV, r["mode"] == "train")
+    net = H.make_network(sd, DEV, r["mode"] == "train", precision)
     rend = H.make_renderer(net, r)
     bd = H.device_batch(batch, DEV)
     tr = None if t_rand is None else torch.from_numpy(t_rand).to(DEV)
@@ -236,7 +242,7 @@ def test_render_end_to_end_matches_reference(name):
     H.assert_close(out["acc_map"].cpu().numpy(), g["acc_map"], 2e-4, "acc_map")
     H.assert_close(out["weights"].cpu().numpy(), g["weights"], 2e-4, "weights")
     H.assert_close(out["depth_map"].cpu().numpy(), g["depth_map"], 2e-4, "depth_map")
-    print("%s: rgb L-inf vs reference %.2e over %d rays" % (name, err, n))
+    print("%s/%s: rgb L-inf vs reference %.2e over %d rays" % (name, precision, err, n))
     # unfused path of the overridable API (get_pixel_value) agrees with the fused march
     if t_rand is None:
         sp = rend.prepare_sp_input(bd)
@@ -271,7 +277,8 @@ def test_raygen_matches_reference_golden():
 
 
 # ------------------------------------------------------------------------------------------- full size
-def test_full_size_properties_512():
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_properties_512(precision):
     """BASELINE.json headline shape (512x512, 64 samples, 6890 vertices): size-independent properties —
     sharding invariance (any contiguous ray range reproduces the full render bit for bit), permutation
     equivariance, sum(weights) == acc, finite outputs, and spot parity with the oracle on a ray sample."""
@@ -283,7 +290,7 @@ def test_full_size_properties_512():
     body = syn.make_body(seed=0)
     Hh = Ww = 512
     K, R, T = syn.full_coverage_camera(body, Hh, Ww)
-    net = H.make_network(sd, DEV, True)
+    net = H.make_network(sd, DEV, True, precision)
     ro, rd, near, far, mask, n = [t for t in __import__("neuralbody_amd").ops.raygen(Hh, Ww, K, R, T, body["can_bounds"], DEV)]
     n = int(n)
     assert n == Hh * Ww and bool(mask.all())
