@@ -17,7 +17,8 @@ SCENES = {
     "small_perturb": dict(weights_seed=0, num_train_frame=7, body=_SMALL_BODY, cam=_SMALL_CAM, n_samples=64,
                           latent_index=6, mode="train", perturb=True, white_bkgd=False, probes=False),
     "small_eval": dict(weights_seed=0, num_train_frame=7, body=_SMALL_BODY, cam=_SMALL_CAM, n_samples=64,
-                       latent_index=1, mode="eval", perturb=False, white_bkgd=True, probes=True),
+                       latent_index=1, mode="eval", perturb=False, white_bkgd=True, probes=True,
+                       weights_kw=dict(alpha_bias=0.7)),  # eval-mode BN squashes the features: centre sigma on 0
     "full": dict(weights_seed=1, num_train_frame=5,
                  body=dict(seed=1, box=(0.9, 1.7, 0.35), rh=(0.3, -0.2, 0.1), th=(0.1, 0.2, -0.3), layout="capsules"),
                  cam=dict(H=24, W=20, focal_factor=1.3, distance=2.5), n_samples=64,

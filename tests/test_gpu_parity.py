@@ -79,15 +79,19 @@ def test_decode_points_stages_against_oracle(precision):
     dbg = dbg.cpu().numpy()
     H.assert_close(dbg[:, :352], feat.numpy(), 2e-5, "trilinear features")
     assert np.abs(feat.numpy()).max() > 0.1 and (np.abs(feat.numpy()).sum(1) == 0).any()
-    H.assert_close(dbg[:, 352:608], h3[0].T.numpy(), 1e-4, "fc_2 output")
-    H.assert_close(out.cpu().numpy(), raw.numpy(), 2e-4, "raw (rgb logits, sigma)")
+    # raw logits reach |20| with the synthetic alpha_fc x20 / rgb_fc x8 gains; the split-bf16 path carries ~2^-16
+    # relative error per GEMM term (dropped lo.lo product), the fp32 path only summation-order noise
+    tol_h, tol_raw = (1e-4, 2e-4) if precision == "f32" else (3e-4, 1e-3)
+    e_h = H.assert_close(dbg[:, 352:608], h3[0].T.numpy(), tol_h, "fc_2 output")
+    e_raw = H.assert_close(out.cpu().numpy(), raw.numpy(), tol_raw, "raw (rgb logits, sigma)")
+    print("%s: fc_2 err %.2e, raw err %.2e (rel. to max(1,|ref|))" % (precision, e_h, e_raw))
     # public API paths
     raw_api = net.calculate_density_color(w.to(DEV), v.to(DEV), vols_dev, sp)
     assert raw_api.shape == (1, w.shape[1], 4)
     assert torch.equal(raw_api[0], out)
     dens_api = net.calculate_density(w.to(DEV), vols_dev, sp)
     assert dens_api.shape == (1, w.shape[1], 1)
-    H.assert_close(dens_api[0].cpu().numpy(), dens.numpy(), 2e-4, "calculate_density")
+    H.assert_close(dens_api[0].cpu().numpy(), dens.numpy(), tol_raw, "calculate_density")
     # ragged size: n not a multiple of 32, and n == 0
     part = ops.decode_points(scene, net.packed_weights(), lb, w[0, :77].to(DEV).contiguous(), v[0, :77].to(DEV).contiguous(),
                              precision=precision)
@@ -122,11 +126,12 @@ def test_march_on_oracle_volumes_matches_reference(name, precision):
     out = net.render_rays(bd["ray_o"][0], bd["ray_d"][0], bd["near"][0], bd["far"][0], vols_dev, sp, r["n_samples"],
                           t_rand=tr, white_bkgd=r["white_bkgd"], want_raw=True)
     torch.cuda.synchronize()
-    H.assert_close(out["rgb_map"].cpu().numpy()[None], g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    e = H.assert_close(out["rgb_map"].cpu().numpy()[None], g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    print("march %s/%s: rgb L-inf vs reference %.2e" % (name, precision, e))
     H.assert_close(out["acc_map"].cpu().numpy()[None], g["acc_map"], 1e-4, "acc_map")
     H.assert_close(out["weights"].cpu().numpy()[None], g["weights"], 1e-4, "weights")
     H.assert_close(out["depth_map"].cpu().numpy()[None], g["depth_map"], 1e-4, "depth_map")
-    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 2e-4, "disp_map")
+    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 3e-4, "disp_map")
     assert float(g["rgb_map"].max()) > 0.1, "fixture is degenerate"
 
 
