@@ -52,7 +52,8 @@ def test_oracle_render_matches_reference_golden(name, golden_dir):
                          t_rand=None if t_rand is None else torch.from_numpy(t_rand),
                          white_bkgd=r["white_bkgd"], feature_volume=vols)
     for k in ("rgb_map", "disp_map", "acc_map", "weights", "depth_map"):
-        _close(out[k].numpy(), g[k], name=k)
+        # disp = 1 / (depth / acc) divides two fp32 sums whose summation order differs with the chunk shape
+        _close(out[k].numpy(), g[k], tol=2e-5 if k == "disp_map" else TOL, name=k)
     if "raw_subset" in g:
         ns = r["n_samples"]
         raw = out["raw"].view(1, -1, ns, 4)[:, ::scenes.RAW_RAY_STRIDE].reshape(1, -1, 4)
