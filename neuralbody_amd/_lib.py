@@ -5,7 +5,7 @@ import os
 import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libnb_hip.so")
+LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip.so")  # NB_LIB_PATH: experiment builds
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4

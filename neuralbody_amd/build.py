@@ -12,11 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libnb_hip.so")
-STAMP = os.path.join(LIB_DIR, "libnb_hip.stamp")
+# experiments: NB_EXTRA_FLAGS="-DNB_ABL_..." NB_LIB_SUFFIX=_abl builds lib/libnb_hip_abl.so (see _lib.py NB_LIB_PATH)
+SUFFIX = os.environ.get("NB_LIB_SUFFIX", "")
+LIB_PATH = os.path.join(LIB_DIR, "libnb_hip%s.so" % SUFFIX)
+STAMP = os.path.join(LIB_DIR, "libnb_hip%s.stamp" % SUFFIX)
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
-         "-Wno-unused-result"]
+         "-Wno-unused-result"] + os.environ.get("NB_EXTRA_FLAGS", "").split()
 
 
 def sources():
@@ -54,7 +56,7 @@ def build(force=False, verbose=True):
         hipcc = "hipcc"
     objs, procs = [], []
     for src in sources():
-        obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + SUFFIX + ".o")
         objs.append(obj)
         cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
         if verbose:

@@ -11,9 +11,9 @@
 // Weight traffic: a wave consumes 2 KiB of weight fragments (A_hi + A_lo) per 3 MFMAs — 85 B/clk/CU,
 // more than the 64 B/clk vector L1 can deliver — so the weight stream goes through LDS: the four
 // waves of a workgroup march in lock step through ONE linear stream of 648 fragment records
-// (1.33 MB per depth step, identical every step), DMA'd by global_load_lds into a 6-slot ring of
-// 24-KiB pages (5 pages in flight ahead of the consumer) and read back with conflict-free
-// ds_read_b128.  One s_barrier per page (36 MFMAs) both publishes the landed page and retires the
+// (1.33 MB per depth step, identical every step), DMA'd by global_load_lds into a 5-slot ring of
+// 20-KiB pages (4 pages in flight ahead of the consumer) and read back with conflict-free
+// ds_read_b128.  One s_barrier per page (30 MFMAs) both publishes the landed page and retires the
 // slot that is refilled next; DMA completion is tracked with counted s_waitcnt vmcnt, never 0.
 #include <type_traits>
 
@@ -29,20 +29,23 @@ namespace nbm {
 
 // --------------------------------------------------------------- weight stream geometry
 constexpr int REC_BYTES = 2048;  // one K=16 chunk of one 32-row tile: A_hi (1 KiB) + A_lo (1 KiB)
-constexpr int PAGE_RECS = 12;
-constexpr int PAGE_BYTES = PAGE_RECS * REC_BYTES;  // 24 KiB
-constexpr int N_SLOTS = 6;
-constexpr int AHEAD = 5;  // pages in flight ahead of the page being consumed
+constexpr int PAGE_RECS = 10;
+constexpr int PAGE_BYTES = PAGE_RECS * REC_BYTES;  // 20 KiB
+constexpr int N_SLOTS = 5;
+constexpr int AHEAD = 4;  // pages in flight ahead of the page being consumed
 constexpr int NC0 = 22, NCH = 16, NCV = 22;
 constexpr int REC_L0 = 0;
 constexpr int REC_L1 = REC_L0 + 8 * NC0;
 constexpr int REC_L2 = REC_L1 + 8 * NCH;
 constexpr int REC_L4 = REC_L2 + 8 * NCH;
 constexpr int REC_LV = REC_L4 + 8 * NCH;
-constexpr int N_RECS = REC_LV + 4 * NCV;  // 648
-constexpr int N_PAGES = N_RECS / PAGE_RECS;  // 54
-static_assert(N_RECS % PAGE_RECS == 0, "stream must be a whole number of pages");
-constexpr int DMA_PER_WAVE = PAGE_BYTES / 1024 / 4;  // 6 one-KiB pieces per wave per page
+constexpr int N_RECS = REC_LV + 4 * NCV;  // 648 records carry weights
+constexpr int N_RECS_PAD = 650;           // + 2 zero records so that the page count is a multiple of the ring size
+constexpr int N_PAGES = N_RECS_PAD / PAGE_RECS;  // 65
+static_assert(N_RECS_PAD % PAGE_RECS == 0 && N_RECS_PAD >= N_RECS, "stream must be a whole number of pages");
+static_assert(N_PAGES % N_SLOTS == 0, "page p must always land in slot p % N_SLOTS, also across the step wrap-around");
+static_assert(PAGE_RECS % 2 == 0, "record pairs must not straddle pages");
+constexpr int DMA_PER_WAVE = PAGE_BYTES / 1024 / 4;  // 5 one-KiB pieces per wave per page
 
 }  // namespace nbm
 
@@ -66,7 +69,10 @@ constexpr int F_PACK_SIZE = F_OFF_RB + 4;
 constexpr int P_B0 = 0, P_B1 = 256, P_B2 = 512, P_LB = 768, P_BV = 1024, P_AW = 1152, P_RW = 1408, P_AB = 1792,
               P_RB = 1796, P_SIZE = 1800;
 constexpr int RING_BYTES = N_SLOTS * PAGE_BYTES;
-constexpr int LDS_BYTES = RING_BYTES + 8192;
+constexpr int PARAM_BYTES = 8192;
+constexpr int TILE_BYTES = 8192;  // per-wave voxel tile of the cooperative gather
+constexpr int LDS_BYTES = RING_BYTES + PARAM_BYTES + 4 * TILE_BYTES;
+static_assert(LDS_BYTES <= 163840, "LDS budget (160 KiB per workgroup)");
 static_assert(P_SIZE * 4 <= 8192, "parameter region overflow");
 
 typedef const void __attribute__((address_space(1))) *gptr_t;
@@ -74,9 +80,10 @@ typedef void __attribute__((address_space(3))) *lptr_t;
 
 struct Ring {
     const char *stream;  // global: N_RECS * REC_BYTES bytes, already advanced to this wave's share (uniform)
-    char *lds;           // N_SLOTS * PAGE_BYTES
+    char *lds;           // [ring N_SLOTS * PAGE_BYTES][params][4 x voxel tile]
     int wave_off;        // byte offset of this wave's share inside a page (uniform)
     int lane;
+    char *tile;          // this wave's voxel tile
 };
 
 // All address arithmetic below is wave-uniform (SGPR) except the single lane * 16 term, so every DMA
@@ -97,9 +104,15 @@ __device__ __forceinline__ void issue_page(const Ring &rg, int page) {
 // pages page+1 .. page+AHEAD-1: allow exactly that many to stay in flight, then rendezvous so that
 // every wave's share has landed (and every wave is done with the slot that gets refilled).
 __device__ __forceinline__ void turn_page(const Ring &rg, int page) {
+#if defined(NB_ABL_NOWAIT) || defined(NB_ABL_NODMA)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * DMA_PER_WAVE) : "memory");
+#endif
     asm volatile("s_barrier" ::: "memory");
+#ifndef NB_ABL_NODMA
     issue_page(rg, (page + AHEAD) % N_PAGES);
+#endif
 }
 
 __device__ __forceinline__ bf16x8 lds_frag(const Ring &rg, int rec, int lo) {
@@ -107,6 +120,19 @@ __device__ __forceinline__ bf16x8 lds_frag(const Ring &rg, int rec, int lo) {
     const int off = (page % N_SLOTS) * PAGE_BYTES + (rec % PAGE_RECS) * REC_BYTES + lo * 1024;
     return *reinterpret_cast<const bf16x8 *>(rg.lds + off + rg.lane * 16);
 }
+
+#ifdef NB_ABL_NOGATHER
+template <int L, int B>
+__device__ __forceinline__ void fake_level(const SceneDev &sc, const GridCoord &g, const WaveBox &, int hi, int, char *,
+                                           float (&out)[lvl_c(L) / 2]) {
+#pragma unroll
+    for (int i = 0; i < lvl_c(L) / 2; ++i) out[i] = g.gw * (float)(i + 1) + g.gh;
+}
+#endif
+#ifdef NB_ABL_NOMFMA
+#undef NB_MFMA16
+#define NB_MFMA16(a, b, c) (c)
+#endif
 
 // split 8 fp32 values into bf16 hi (round to nearest even) and bf16 lo = rne(v - hi)
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
@@ -215,6 +241,7 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
             // level by level: gather (fp32) -> split into the bf16 B operands of fc_0, so only one level's
             // accumulators are live on the VALU side at a time
             const GridCoord g = grid_coords(sc, px, py, pz);
+            const WaveBox wb = wave_box(g);
             auto put = [&](auto &f, auto chunk0, auto nchunk, int dbg_base) {
 #pragma unroll
                 for (int c = 0; c < decltype(nchunk)::value; ++c) {
@@ -228,26 +255,32 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
                     }
                 }
             };
+#ifdef NB_ABL_NOGATHER
+#define gather_level_coop fake_level
+#endif
             {
                 float f[16];
-                gather_level<0>(sc, g, hi, f);
+                gather_level_coop<0, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
                 put(f, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, 0);
             }
             {
                 float f[32];
-                gather_level<1>(sc, g, hi, f);
+                gather_level_coop<1, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
                 put(f, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, 16);
             }
             {
                 float f[64];
-                gather_level<2>(sc, g, hi, f);
+                gather_level_coop<2, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
                 put(f, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{}, 48);
             }
             {
                 float f[64];
-                gather_level<3>(sc, g, hi, f);
+                gather_level_coop<3, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
                 put(f, std::integral_constant<int, 14>{}, std::integral_constant<int, 8>{}, 112);
             }
+#ifdef NB_ABL_NOGATHER
+#undef gather_level_coop
+#endif
         }
         mlp_layer16<REC_L0, 8, NC0>(rg, prm + P_B0, acc, fh, fl);
     }
@@ -290,7 +323,12 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
         }
         // the 30 sin/cos of the world point are only needed here: computing them late keeps ~45 registers
         // free during the gather and the trunk
+#ifdef NB_ABL_NOPE
+#pragma unroll
+        for (int c = 12; c < N_PE; ++c) pe[c] = px * (float)c;
+#else
         if (!DENSITY_ONLY) pe_xyz(pe, px, py, pz, vx, vy, vz, hi);
+#endif
 #pragma unroll
         for (int c = 0; c < 6; ++c) {  // 45 positional-encoding slots, zero padded to 48
             float t[8];
@@ -342,6 +380,7 @@ __device__ __forceinline__ Ring ring_begin(const float *pk, const float *lb, cha
     rg.stream = reinterpret_cast<const char *>(pk + F_PACK_SIZE) + rg.wave_off;
     rg.lds = lds;
     rg.lane = threadIdx.x & 63;
+    rg.tile = lds + RING_BYTES + PARAM_BYTES + wave * TILE_BYTES;
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p) issue_page(rg, p);
     return rg;
@@ -459,8 +498,14 @@ __device__ __forceinline__ unsigned short bf16_rne_bits(float f) {
 
 __global__ void nb_pack16_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, unsigned short *__restrict__ out) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // one (rec, lane, r) weight, writes hi and lo
-    if (e >= (long long)N_RECS * 64 * 8) return;
+    if (e >= (long long)N_RECS_PAD * 64 * 8) return;
     const int r = (int)(e & 7), lane = (int)((e >> 3) & 63), rec = (int)(e >> 9);
+    if (rec >= N_RECS) {  // padding records: never multiplied, zero for determinism
+        unsigned short *padp = out + (size_t)rec * (REC_BYTES / 2);
+        padp[lane * 8 + r] = 0;
+        padp[512 + lane * 8 + r] = 0;
+        return;
+    }
     const int i = lane & 31, kg = lane >> 5;
     // locate (layer, tile, chunk): within a layer records go pair by pair, (c, t0), (c, t1), ...
     int base, nc, layer;
@@ -499,10 +544,10 @@ __global__ void nb_pack16_kernel(nb_mlp_params p, const float *__restrict__ f32_
 
 namespace nbm {
 
-long long bf16_stream_floats() { return (long long)N_RECS * REC_BYTES / 4; }
+long long bf16_stream_floats() { return (long long)N_RECS_PAD * REC_BYTES / 4; }
 
 int pack_bf16_stream(const nb_mlp_params *p, float *packed, hipStream_t st) {
-    const long long n = (long long)N_RECS * 64 * 8;
+    const long long n = (long long)N_RECS_PAD * 64 * 8;
     hipLaunchKernelGGL(nb_pack16_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, st, *p, packed,
                        reinterpret_cast<unsigned short *>(packed + F_PACK_SIZE));
     NB_CHECK_LAUNCH("nb_pack16_kernel");

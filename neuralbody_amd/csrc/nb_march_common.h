@@ -92,7 +92,11 @@ __device__ __forceinline__ void pe_xyz(float (&pe)[N_PE], float px, float py, fl
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float s, c;
+#ifdef NB_ABL_FASTSIN
+            __sincosf(p[a] * (float)(1 << k), &s, &c);
+#else
             sincosf(p[a] * (float)(1 << k), &s, &c);
+#endif
             pe[12 + 3 * k + a] = hi ? c : s;
         }
 #pragma unroll
@@ -151,7 +155,12 @@ __device__ __forceinline__ void gather_level(const SceneDev &sc, const GridCoord
         const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
         cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
         const int xc = min(max(xx, 0), W - 1), yc = min(max(yy, 0), H - 1), zc = min(max(zz, 0), D - 1);
+#ifdef NB_ABL_SAMEVOX
+        cp[corner] = reinterpret_cast<const f32x4 *>(
+            vb + ((size_t)__builtin_amdgcn_readfirstlane((zc * H + yc) * W + xc)) * C);
+#else
         cp[corner] = reinterpret_cast<const f32x4 *>(vb + ((size_t)(zc * H + yc) * W + xc) * C);
+#endif
     }
 #pragma unroll
     for (int grp = 0; grp < HALF / 16; ++grp) {
@@ -179,6 +188,125 @@ __device__ __forceinline__ void gather_level(const SceneDev &sc, const GridCoord
         __builtin_amdgcn_sched_group_barrier(0x020, 32, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 128, 0);
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---------------------------------------------------------------- cooperative (coalesced) gather
+// Neighbouring rays at the same depth step touch the same few voxels (a 512x512 view spaces rays
+// ~3.5 mm apart; level-3/4 voxels are 4-8 cm).  The per-lane gather above issues one cache-line
+// request per lane per instruction (64 distinct lines -> TA address-rate bound); here the wave first
+// fetches the bounding box of voxels it needs ONCE, fully coalesced (consecutive lanes read consecutive
+// 16-byte pieces of a voxel's channel vector), into a wave-private LDS tile, and every lane then reads
+// its 8 corners from LDS.  Falls back to the per-lane gather when the box does not fit (random rays).
+__device__ __forceinline__ float wave_min32(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;  // lanes j and j+32 hold the same sample, so 5 butterfly steps cover the wave
+}
+__device__ __forceinline__ float wave_max32(float v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+struct WaveBox {
+    GridCoord lo, hi;  // component-wise min / max of the normalised coordinates over the wave
+};
+
+__device__ __forceinline__ WaveBox wave_box(const GridCoord &g) {
+    WaveBox b;
+    b.lo.gw = wave_min32(g.gw);
+    b.lo.gh = wave_min32(g.gh);
+    b.lo.gd = wave_min32(g.gd);
+    b.hi.gw = wave_max32(g.gw);
+    b.hi.gh = wave_max32(g.gh);
+    b.hi.gd = wave_max32(g.gd);
+    return b;
+}
+
+__device__ __forceinline__ float unnorm_clamped(float gcoord, int size) {
+    float i = __fmul_rn(__fdiv_rn(__fadd_rn(gcoord, 1.f), 2.f), (float)(size - 1));
+    return fminf(fmaxf(i, -2.f), (float)size + 1.f);
+}
+
+template <int L, int BUF_BYTES>
+__device__ __forceinline__ void gather_level_coop(const SceneDev &sc, const GridCoord &g, const WaveBox &wb, int hi,
+                                                  int lane, char *buf, float (&out)[lvl_c(L) / 2]) {
+    constexpr int C = lvl_c(L), HALF = C / 2, PC = C / 4;  // PC 16-byte pieces per voxel
+    constexpr int MAX_IT = BUF_BYTES / 1024;
+    const int D = sc.dhw[L][0], H = sc.dhw[L][1], W = sc.dhw[L][2];
+    // index box of the wave (monotone in the normalised coordinate, same formula as the per-lane indices)
+    const int xlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gw, W)), 0), W - 1));
+    const int ylo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gh, H)), 0), H - 1));
+    const int zlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gd, D)), 0), D - 1));
+    const int xhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gw, W)) + 1, 0), W - 1));
+    const int yhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gh, H)) + 1, 0), H - 1));
+    const int zhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gd, D)) + 1, 0), D - 1));
+    const int nx = xhi - xlo + 1, ny = yhi - ylo + 1, nz = zhi - zlo + 1;
+    const int pieces = nx * ny * nz * PC;
+    if (pieces > BUF_BYTES / 16) {  // wave-uniform
+        gather_level<L>(sc, g, hi, out);
+        return;
+    }
+    // ---- fill the tile: piece p = (voxel v, 16-byte quad q) -> buf[p * 16]
+    {
+        const float rcp_xy = 1.f / (float)(nx * ny), rcp_x = 1.f / (float)nx;
+        f32x4 t[MAX_IT];
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            if (it * 64 < pieces) {  // wave-uniform
+                const int p = min(it * 64 + lane, pieces - 1);
+                const int v = p / PC, q = p % PC;
+                const int vz = (int)(((float)v + 0.5f) * rcp_xy);
+                const int r = v - vz * nx * ny;
+                const int vy = (int)(((float)r + 0.5f) * rcp_x);
+                const int vx = r - vy * nx;
+                const size_t lin = ((size_t)((zlo + vz) * H + (ylo + vy))) * W + (xlo + vx);
+                t[it] = *reinterpret_cast<const f32x4 *>(sc.vol[L] + lin * C + q * 4);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            if (it * 64 < pieces) {
+                const int p = it * 64 + lane;
+                if (p < pieces) *reinterpret_cast<f32x4 *>(buf + p * 16) = t[it];
+            }
+        }
+    }
+    // ---- per-lane corners from LDS (same index / weight arithmetic as gather_level)
+    const float ix = unnorm_clamped(g.gw, W), iy = unnorm_clamped(g.gh, H), iz = unnorm_clamped(g.gd, D);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx[2] = {(fx + 1.f) - ix, ix - fx};
+    const float wy[2] = {(fy + 1.f) - iy, iy - fy};
+    const float wz[2] = {(fz + 1.f) - iz, iz - fz};
+    const f32x4 *cp[8];
+    float cw[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+        const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
+        cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
+        const int xc = min(max(xx, xlo), xhi), yc = min(max(yy, ylo), yhi), zc = min(max(zz, zlo), zhi);
+        const int lv = ((zc - zlo) * ny + (yc - ylo)) * nx + (xc - xlo);
+        cp[corner] = reinterpret_cast<const f32x4 *>(buf + (lv * C + hi * HALF) * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < HALF / 4; ++q) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const f32x4 v = cp[corner][q];
+            a.x = fmaf(cw[corner], v.x, a.x);
+            a.y = fmaf(cw[corner], v.y, a.y);
+            a.z = fmaf(cw[corner], v.z, a.z);
+            a.w = fmaf(cw[corner], v.w, a.w);
+        }
+        out[q * 4 + 0] = a.x;
+        out[q * 4 + 1] = a.y;
+        out[q * 4 + 2] = a.z;
+        out[q * 4 + 3] = a.w;
     }
 }
 
