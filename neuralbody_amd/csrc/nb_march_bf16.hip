@@ -45,6 +45,7 @@ constexpr int N_PAGES = N_RECS_PAD / PAGE_RECS;  // 65
 static_assert(N_RECS_PAD % PAGE_RECS == 0 && N_RECS_PAD >= N_RECS, "stream must be a whole number of pages");
 static_assert(N_PAGES % N_SLOTS == 0, "page p must always land in slot p % N_SLOTS, also across the step wrap-around");
 static_assert(PAGE_RECS % 2 == 0, "record pairs must not straddle pages");
+static_assert(PAGE_RECS / 2 == PAGE_BYTES / 1024 / 4, "one DMA piece per record pair refills a page exactly");
 constexpr int DMA_PER_WAVE = PAGE_BYTES / 1024 / 4;  // 5 one-KiB pieces per wave per page
 
 }  // namespace nbm
@@ -84,25 +85,28 @@ struct Ring {
     int wave_off;        // byte offset of this wave's share inside a page (uniform)
     int lane;
     char *tile;          // this wave's voxel tile
+    int base03, base34;  // lane * 16 (+ 3 pages): opaque byte offsets of ring slots 0-2 / 3-4
 };
 
 // All address arithmetic below is wave-uniform (SGPR) except the single lane * 16 term, so every DMA
 // is `global_load_lds_dwordx4 v_lane16, s[base]` — no per-DMA 64-bit VGPR address to keep alive.
-__device__ __forceinline__ void issue_page(const Ring &rg, int page) {
+__device__ __forceinline__ void issue_piece(const Ring &rg, int page, int i) {
     const int slot = page % N_SLOTS;
-    const char *sbase = rg.stream + (size_t)page * PAGE_BYTES;
-    char *dbase = rg.lds + slot * PAGE_BYTES + rg.wave_off;
+    const char *src = rg.stream + (size_t)page * PAGE_BYTES + i * 1024 + rg.lane * 16;
+    char *dst = rg.lds + slot * PAGE_BYTES + rg.wave_off + i * 1024;  // wave-uniform; the DMA adds lane * 16
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ void issue_page(const Ring &rg, int page) {
 #pragma unroll
-    for (int i = 0; i < DMA_PER_WAVE; ++i) {
-        const char *src = sbase + i * 1024 + rg.lane * 16;
-        char *dst = dbase + i * 1024;  // wave-uniform; the DMA adds lane * 16
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-    }
+    for (int i = 0; i < DMA_PER_WAVE; ++i) issue_piece(rg, page, i);
 }
 
 // Called before the first record of `page` is read.  My DMAs issued after that page's are those of
 // pages page+1 .. page+AHEAD-1: allow exactly that many to stay in flight, then rendezvous so that
-// every wave's share has landed (and every wave is done with the slot that gets refilled).
+// every wave's share has landed (and every wave is done with the slot that gets refilled), then refill
+// that slot with page + AHEAD in one burst.  (Measured alternative, -DNB_DMA_SPREAD: one DMA piece per
+// record pair instead of a burst per page — 39.4 vs 32.1 ms per 512x512x64 image, i.e. slower.)
 __device__ __forceinline__ void turn_page(const Ring &rg, int page) {
 #if defined(NB_ABL_NOWAIT) || defined(NB_ABL_NODMA)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -110,15 +114,17 @@ __device__ __forceinline__ void turn_page(const Ring &rg, int page) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * DMA_PER_WAVE) : "memory");
 #endif
     asm volatile("s_barrier" ::: "memory");
-#ifndef NB_ABL_NODMA
+#if !defined(NB_ABL_NODMA) && !defined(NB_DMA_SPREAD)
     issue_page(rg, (page + AHEAD) % N_PAGES);
 #endif
 }
 
+// ds_read_b128 carries a 16-bit immediate offset: two opaque base registers (slots 0-2 and slots 3-4)
+// reach the whole ring with base + immediate, instead of one VALU address computation per read
 __device__ __forceinline__ bf16x8 lds_frag(const Ring &rg, int rec, int lo) {
-    const int page = rec / PAGE_RECS;
-    const int off = (page % N_SLOTS) * PAGE_BYTES + (rec % PAGE_RECS) * REC_BYTES + lo * 1024;
-    return *reinterpret_cast<const bf16x8 *>(rg.lds + off + rg.lane * 16);
+    const int page = rec / PAGE_RECS, slot = page % N_SLOTS;
+    const int off = (slot % 3) * PAGE_BYTES + (rec % PAGE_RECS) * REC_BYTES + lo * 1024;
+    return *reinterpret_cast<const bf16x8 *>(rg.lds + (slot < 3 ? rg.base03 : rg.base34) + off);
 }
 
 #ifdef NB_ABL_NOGATHER
@@ -163,6 +169,9 @@ __device__ __forceinline__ Frag4 load_pair(const Ring &rg, int k) {
     const int rec = REC0 + 2 * k;
     Frag4 f;
     if (rec % PAGE_RECS == 0) turn_page(rg, rec / PAGE_RECS);
+#if defined(NB_DMA_SPREAD) && !defined(NB_ABL_NODMA)
+    issue_piece(rg, (rec / PAGE_RECS + AHEAD) % N_PAGES, (rec % PAGE_RECS) / 2);  // after the page's barrier
+#endif
     f.ah0 = lds_frag(rg, rec, 0);
     f.al0 = lds_frag(rg, rec, 1);
     if ((rec + 1) % PAGE_RECS == 0) turn_page(rg, (rec + 1) / PAGE_RECS);
@@ -171,7 +180,9 @@ __device__ __forceinline__ Frag4 load_pair(const Ring &rg, int k) {
     return f;
 }
 
-template <int REC0, int NT, int NC>
+// INIT: start the NT accumulator tiles from the bias; otherwise continue accumulating into `acc`
+// (a layer whose K range is consumed in several phases: fc_0 level by level, view_fc in two parts).
+template <int REC0, int NT, int NC, bool INIT = true>
 __device__ __forceinline__ void mlp_layer16(const Ring &rg, const float *bp, f32x16 (&acc)[NT],
                                             const bf16x8 (&xh)[NC], const bf16x8 (&xl)[NC]) {
     const int hi = rg.lane >> 5;
@@ -182,8 +193,13 @@ __device__ __forceinline__ void mlp_layer16(const Ring &rg, const float *bp, f32
     for (int k = 0; k < NP; ++k) {
         const int tp = k / NC, c = k % NC;
         if (c == 0) {
-            c0 = bias_tile(bp, 2 * tp, hi);
-            c1 = bias_tile(bp, 2 * tp + 1, hi);
+            if (INIT) {
+                c0 = bias_tile(bp, 2 * tp, hi);
+                c1 = bias_tile(bp, 2 * tp + 1, hi);
+            } else {
+                c0 = acc[2 * tp];
+                c1 = acc[2 * tp + 1];
+            }
         }
         Frag4 nxt = cur;
         if (k + 1 < NP) nxt = load_pair<REC0>(rg, k + 1);
@@ -227,6 +243,22 @@ __device__ __forceinline__ void dump_tiles(const f32x16 (&h)[NT], float *dst, in
         for (int r = 0; r < 16; ++r) dst[32 * t + tile_row(r, hi)] = relu ? fmaxf(h[t][r], 0.f) : h[t][r];
 }
 
+template <int NCL>
+__device__ __forceinline__ void feats_to_operands(const float (&f)[8 * NCL], bf16x8 (&fh)[NCL], bf16x8 (&fl)[NCL],
+                                                  float *dbg, int dbg_base, int hi) {
+#pragma unroll
+    for (int c = 0; c < NCL; ++c) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = f[8 * c + r];
+        split8(v, fh[c], fl[c]);
+        if (dbg) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) dbg[col_feat(dbg_base + 8 * c + r, hi)] = v[r];
+        }
+    }
+}
+
 template <bool DENSITY_ONLY, bool DBG>
 __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, float px, float py, float pz,
                                          float vx, float vy, float vz, float (&pe)[N_PE], float (&out)[4],
@@ -236,53 +268,45 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
     f32x16 acc[8];
     bf16x8 xh[16], xl[16];
     {
-        bf16x8 fh[NC0], fl[NC0];
-        {
-            // level by level: gather (fp32) -> split into the bf16 B operands of fc_0, so only one level's
-            // accumulators are live on the VALU side at a time
-            const GridCoord g = grid_coords(sc, px, py, pz);
-            const WaveBox wb = wave_box(g);
-            auto put = [&](auto &f, auto chunk0, auto nchunk, int dbg_base) {
-#pragma unroll
-                for (int c = 0; c < decltype(nchunk)::value; ++c) {
-                    float v[8];
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = f[8 * c + r];
-                    split8(v, fh[decltype(chunk0)::value + c], fl[decltype(chunk0)::value + c]);
-                    if (DBG && dbg) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) dbg[col_feat(dbg_base + 8 * c + r, hi)] = v[r];
-                    }
-                }
-            };
+        // fc_0 level by level: gather one pyramid level (fp32), split it into bf16 B operands and
+        // accumulate its K range into all 8 output tiles before touching the next level, so only one
+        // level's features are ever live (the weight stream is ordered to match, see nb_pack16_kernel)
+        const GridCoord g = grid_coords(sc, px, py, pz);
+        const WaveBox wb = wave_box(g);
 #ifdef NB_ABL_NOGATHER
 #define gather_level_coop fake_level
 #endif
-            {
-                float f[16];
-                gather_level_coop<0, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
-                put(f, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, 0);
-            }
-            {
-                float f[32];
-                gather_level_coop<1, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
-                put(f, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, 16);
-            }
-            {
-                float f[64];
-                gather_level_coop<2, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
-                put(f, std::integral_constant<int, 6>{}, std::integral_constant<int, 8>{}, 48);
-            }
-            {
-                float f[64];
-                gather_level_coop<3, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
-                put(f, std::integral_constant<int, 14>{}, std::integral_constant<int, 8>{}, 112);
-            }
+        {
+            float f[16];
+            bf16x8 fh[2], fl[2];
+            gather_level_coop<0, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
+            feats_to_operands<2>(f, fh, fl, DBG ? dbg : nullptr, 0, hi);
+            mlp_layer16<REC_L0 + 8 * 0, 8, 2, true>(rg, prm + P_B0, acc, fh, fl);
+        }
+        {
+            float f[32];
+            bf16x8 fh[4], fl[4];
+            gather_level_coop<1, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
+            feats_to_operands<4>(f, fh, fl, DBG ? dbg : nullptr, 16, hi);
+            mlp_layer16<REC_L0 + 8 * 2, 8, 4, false>(rg, prm + P_B0, acc, fh, fl);
+        }
+        {
+            float f[64];
+            bf16x8 fh[8], fl[8];
+            gather_level_coop<2, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
+            feats_to_operands<8>(f, fh, fl, DBG ? dbg : nullptr, 48, hi);
+            mlp_layer16<REC_L0 + 8 * 6, 8, 8, false>(rg, prm + P_B0, acc, fh, fl);
+        }
+        {
+            float f[64];
+            bf16x8 fh[8], fl[8];
+            gather_level_coop<3, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
+            feats_to_operands<8>(f, fh, fl, DBG ? dbg : nullptr, 112, hi);
+            mlp_layer16<REC_L0 + 8 * 14, 8, 8, false>(rg, prm + P_B0, acc, fh, fl);
+        }
 #ifdef NB_ABL_NOGATHER
 #undef gather_level_coop
 #endif
-        }
-        mlp_layer16<REC_L0, 8, NC0>(rg, prm + P_B0, acc, fh, fl);
     }
     tiles_to_operands<true>(acc, xh, xl);
     mlp_layer16<REC_L1, 8, NCH>(rg, prm + P_B1, acc, xh, xl);
@@ -301,7 +325,7 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
             s = fmaf(w.z, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 2], 0.f), s);
             s = fmaf(w.w, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 3], 0.f), s);
         }
-        s += __shfl_xor(s, 32);
+        s = add_halves(s);
         out[3] = s + prm[P_AB];
     }
     tiles_to_operands<true>(acc, xh, xl);
@@ -309,19 +333,12 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
     // colour head (its result is simply not stored)
     mlp_layer16<REC_L4, 8, NCH>(rg, prm + P_LB, acc, xh, xl);
     if (DBG && dbg) dump_tiles(acc, dbg + 352 + 256, hi, false);
+    // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings
     f32x16 v[4];
+    tiles_to_operands<false>(acc, xh, xl);
+    mlp_layer16<REC_LV, 4, 16, true>(rg, prm + P_BV, v, xh, xl);
     {
-        bf16x8 vh[NCV], vl[NCV];
-        {
-            bf16x8 gh[16], gl[16];
-            tiles_to_operands<false>(acc, gh, gl);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                vh[c] = gh[c];
-                vl[c] = gl[c];
-            }
-        }
-        // the 30 sin/cos of the world point are only needed here: computing them late keeps ~45 registers
+        // the 30 sin/cos of the world point are only needed here: computing them late keeps registers
         // free during the gather and the trunk
 #ifdef NB_ABL_NOPE
 #pragma unroll
@@ -329,15 +346,21 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
 #else
         if (!DENSITY_ONLY) pe_xyz(pe, px, py, pz, vx, vy, vz, hi);
 #endif
+        bf16x8 ph[6], pl[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {  // 45 positional-encoding slots, zero padded to 48
             float t[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) t[r] = (8 * c + r < N_PE) ? pe[(8 * c + r < N_PE) ? 8 * c + r : 0] : 0.f;
-            split8(t, vh[16 + c], vl[16 + c]);
+            split8(t, ph[c], pl[c]);
         }
-        mlp_layer16<REC_LV, 4, NCV>(rg, prm + P_BV, v, vh, vl);
+        mlp_layer16<REC_LV + 4 * 16, 4, 6, false>(rg, prm + P_BV, v, ph, pl);
     }
+#if defined(NB_DMA_SPREAD) && !defined(NB_ABL_NODMA)
+    // the two padding records form the 325th record pair of the step: issue the DMA piece that rides on it
+    static_assert(N_RECS_PAD - N_RECS == 2, "exactly one padding pair");
+    issue_piece(rg, (N_RECS / PAGE_RECS + AHEAD) % N_PAGES, (N_RECS % PAGE_RECS) / 2);
+#endif
     if (DBG && dbg) dump_tiles(v, dbg + 352 + 512, hi, true);
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -351,7 +374,7 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
             s = fmaf(w.z, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 2], 0.f), s);
             s = fmaf(w.w, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 3], 0.f), s);
         }
-        s += __shfl_xor(s, 32);
+        s = add_halves(s);
         out[ch] = s + prm[P_RB + ch];
     }
 }
@@ -381,6 +404,9 @@ __device__ __forceinline__ Ring ring_begin(const float *pk, const float *lb, cha
     rg.lds = lds;
     rg.lane = threadIdx.x & 63;
     rg.tile = lds + RING_BYTES + PARAM_BYTES + wave * TILE_BYTES;
+    rg.base03 = rg.lane * 16;
+    rg.base34 = rg.lane * 16 + 3 * PAGE_BYTES;
+    asm volatile("" : "+v"(rg.base03), "+v"(rg.base34));
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p) issue_page(rg, p);
     return rg;
@@ -467,13 +493,20 @@ __global__ __launch_bounds__(256) void nb_march16_kernel(MarchArgs a) {
         const float py = __fadd_rn(oy, __fmul_rn(dy, z_cur));
         const float pz = __fadd_rn(oz, __fmul_rn(dz, z_cur));
         float out[4];
-        // everything the weight stream touches is loop-invariant; an opaque zero keeps the (hundreds of)
-        // DMA source / destination addresses and small-parameter loads from being hoisted and spilled
-        int zero = 0;
-        asm volatile("" : "+s"(zero));
-        Ring r2 = rg;
+        // Everything derived from the lane id, the ray id and the stream base is loop-invariant; left alone,
+        // LICM hoists hundreds of such values (DMA addresses, LDS bases, output pointers) out of the depth
+        // loop and the allocator spills them, reloading each behind a vmcnt(0).  Laundering the roots through
+        // an empty asm makes the compiler recompute them (a few ALU ops) inside the body instead.
+        int zero = 0, lane_i = rg.lane;
+        asm volatile("" : "+s"(zero), "+v"(lane_i));
+        Ring r2;
+        r2.lds = rg.lds;
+        r2.lane = lane_i;
         r2.stream = rg.stream + zero;
         r2.wave_off = rg.wave_off + zero;
+        r2.tile = rg.tile + zero;
+        r2.base03 = lane_i * 16;
+        r2.base34 = lane_i * 16 + 3 * PAGE_BYTES;
         decode16<false, false>(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, nullptr);
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
@@ -514,7 +547,20 @@ __global__ void nb_pack16_kernel(nb_mlp_params p, const float *__restrict__ f32_
     else if (rec < REC_L4) { layer = 2; base = REC_L2; nc = NCH; }
     else if (rec < REC_LV) { layer = 4; base = REC_L4; nc = NCH; }
     else { layer = 5; base = REC_LV; nc = NCV; }
-    const int rel = rec - base, tp = rel / (2 * nc), c = (rel % (2 * nc)) >> 1, t = 2 * tp + (rel & 1);
+    // records of a layer phase go tile pair by tile pair: (c, t0), (c, t1), (c+1, t0), ...  fc_0 is split
+    // into four K phases (one per pyramid level), view_fc into two (latent-layer outputs, encodings)
+    int rel = rec - base, c0 = 0, n = nc, nt = (layer == 5) ? 4 : 8;
+    if (layer == 0) {
+        if (rel < 8 * 2) { c0 = 0; n = 2; }
+        else if (rel < 8 * 6) { c0 = 2; n = 4; }
+        else if (rel < 8 * 14) { c0 = 6; n = 8; }
+        else { c0 = 14; n = 8; }
+    } else if (layer == 5) {
+        if (rel < 4 * 16) { c0 = 0; n = 16; }
+        else { c0 = 16; n = 6; }
+    }
+    rel -= nt * c0;
+    const int tp = rel / (2 * n), c = c0 + ((rel % (2 * n)) >> 1), t = 2 * tp + (rel & 1);
     const int row = 32 * t + i, q = 8 * c + r;
     float w = 0.f;
     if (layer == 0) w = p.fc0_w[row * 352 + col_feat(q, kg)];
