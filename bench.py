@@ -12,10 +12,10 @@ seed 0).  One STEP = `Renderer.render(batch)` for one view per GPU: structured-l
 (weak scaling): rank r marches view r, then the rendered RGB tiles are all-gathered over RCCL.
 
 The JSON line also carries
-  roofline     — the dominant kernel (nb_march_kernel): algorithmic MLP flops (859 904 per ray-sample,
-                 SURVEY.md §8(d)) / its average launch duration measured with HIP events inside the timed
-                 region, against the dense fp32-MFMA peak (157.3 TFLOP/s; the kernel computes in exact fp32
-                 with v_mfma_f32_32x32x2_f32).
+  roofline     — the dominant kernel (nb_march16_kernel, or nb_march_kernel with --precision f32): algorithmic MLP
+                 flops (859 904 per ray-sample) / its average launch duration measured with HIP
+                 events inside the timed region, against the dense MFMA peak of the arithmetic it runs on
+                 (2.5 PFLOP/s bf16 for the default split-bf16 path, 157.3 TFLOP/s for exact fp32).
   cpu_baseline — the CPU restatement of the reference (oracle/, torch CPU, all host cores) marching a
                  bounded sample of the same rays through the same feature volumes.
 """
@@ -32,9 +32,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FLOP_PER_SAMPLE = 859904.0      # MLP MACs x 2 as the reference layers are written
-EXEC_FLOP_PER_SAMPLE = 663296.0  # executed: feature_fc.latent_fc merged, latent folded into a bias
-PEAK_F32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 matrix peak
+FLOP_PER_SAMPLE = 859904.0  # MLP MACs x 2 as the reference layers are written
+# per precision: (dtype tag, kernel, executed MFMA flop/sample, dense MFMA peak TFLOP/s from MI355X_MICROARCH.md)
+PRECISION_INFO = {
+    # feature_fc.latent_fc merged, latent folded into a bias: 331 648 MAC/sample on v_mfma_f32_32x32x2_f32
+    "f32": ("f32", "nb_march_kernel", 663296.0, 157.3),
+    # the same layers as 1944 v_mfma_f32_32x32x16_bf16 per 32 samples (bf16 hi/lo split: 3 products, K padded to 16)
+    "bf16x3": ("bf16", "nb_march16_kernel", 1944 * 32768 / 32.0, 2500.0),
+}
 
 
 def build_scene(dev, H=512, W=512, n_samples=64, precision=None):
@@ -171,23 +176,30 @@ def main():
 
     total_rays = n_rays * world * args.steps
     samples_per_s = total_rays * S / elapsed
+    dtype, kernel_name, exec_flop, peak = PRECISION_INFO[net.precision]
     achieved_tflops = FLOP_PER_SAMPLE * n_rays * S / (march_ms * 1e-3) / 1e12
     result = {
         "metric": "ray_samples_per_sec", "value": samples_per_s, "unit": "ray-samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "rays_per_sec": total_rays / elapsed,
         "config": {"workload": "synthetic 6890-vertex SMPL scene, %dx%d full-coverage view, %d samples/ray, "
                                "Renderer.render = encoder + fused march, one view per GPU per step" % (H, W, S),
                    "rays_per_view": n_rays, "out_sh": [int(s) for s in body["out_sh"]],
+                   "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                                  "bf16x3": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
+                                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate"}[net.precision],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "kernel": "nb_march_kernel", "achieved": achieved_tflops,
-                     "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F32_MFMA_TFLOPS,
+        "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
+                     "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
                      "traffic": None, "avg_launch_ms": march_ms,
-                     "executed_tflops": EXEC_FLOP_PER_SAMPLE * n_rays * S / (march_ms * 1e-3) / 1e12,
-                     "note": "achieved = 859904 algorithmic flop/sample x %d samples/launch / avg launch time; the kernel "
-                             "executes 663296 flop/sample (feature_fc.latent_fc merged, latent folded into a bias), so "
-                             "executed_tflops/peak is the MFMA-pipe occupancy" % (n_rays * S)},
+                     "executed_tflops": exec_flop * n_rays * S / (march_ms * 1e-3) / 1e12,
+                     "executed_frac": exec_flop * n_rays * S / (march_ms * 1e-3) / 1e12 / peak,
+                     "note": "achieved = 859904 algorithmic flop/sample x %d samples/launch / avg launch time (HIP events); "
+                             "the kernel issues %.0f MFMA flop/sample (merged feature_fc.latent_fc layer%s), so "
+                             "executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~219 MB/launch "
+                             "(<0.1%% of the launch time at 8 TB/s), PMC traffic not collected"
+                             % (n_rays * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.precision == "bf16x3" else "")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         with torch.no_grad():
