@@ -62,8 +62,9 @@ def build_scene(dev, H=512, W=512, n_samples=64, precision=None):
                            np.zeros(1, np.float32), np.ones(1, bool))
     bd = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in batch.items()
           if k not in ("ray_o", "ray_d", "near", "far", "mask_at_box")}
-    bd.update(ray_o=ro[None, :n], ray_d=rd[None, :n], near=near[None, :n], far=far[None, :n])
-    rend = Renderer(net, RenderConfig(N_samples=n_samples, perturb=0.0))
+    bd.update(ray_o=ro[None, :n], ray_d=rd[None, :n], near=near[None, :n], far=far[None, :n],
+              mask_at_box=mask[None].bool())
+    rend = Renderer(net, RenderConfig(N_samples=n_samples, perturb=0.0, H=H, W=W))
     return sd, body, net, rend, bd, n
 
 

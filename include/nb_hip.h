@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 2
+#define NB_ABI_VERSION 4
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -117,13 +117,16 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
  *   ray_o, ray_d dev [n_rays,3]; near, far dev [n_rays]
  *   t_vals  dev [n_samples]  = torch.linspace(0,1,n_samples)   (if_clight_renderer.py:13)
  *   t_rand  dev [n_rays,n_samples] in [0,1) or NULL            (stratified jitter, :16-23)
+ *   ray_order dev [n_rays] int32 permutation or NULL: lane slot i marches ray ray_order[i].  Results are
+ *           written at the ray's own index, so this only changes WHICH rays share a wavefront (e.g. 8x4
+ *           pixel tiles instead of row segments, for gather locality); outputs are bit-identical.
  *   outputs dev: rgb_map [n_rays,3], disp_map/acc_map/depth_map [n_rays],
  *           weights [n_rays,n_samples]; raw (optional, may be NULL) [n_rays,n_samples,4]
  * ------------------------------------------------------------------------------- */
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias,
              const float *ray_o, const float *ray_d, const float *near, const float *far,
              int64_t n_rays, int32_t n_samples, const float *t_vals, const float *t_rand,
-             int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
+             const int32_t *ray_order, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
              float *depth_map, float *raw, int precision, void *stream);
 
 /* ---------------------------------------------------------------------------------
@@ -175,14 +178,16 @@ int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_d
                 int32_t cout, float *out_rows, double *stats, void *stream);
 
 /* BatchNorm1d(eps=1e-3) over active rows + ReLU, in place (latent_xyzc.py:208-274).
- * training != 0: normalise with the batch statistics in `stats` (biased variance) and
- * write [mean | biased var | n_rows] (2*C+1 floats) to batch_stats (dev, may be NULL);
+ * training != 0: normalise with the batch statistics in `stats` (biased variance), write
+ * [mean | biased var | n_rows] (2*C+1 floats) to batch_stats (dev, may be NULL when momentum < 0)
+ * and, when momentum >= 0, update running_mean / running_var in place like nn.BatchNorm1d
+ * (unbiased variance, latent_xyzc.py:215 momentum 0.01);
  * training == 0: use running_mean / running_var.
  * dense (dev or NULL): channels-last [D,H,W,C] volume receiving the rows (.dense(),
  * latent_xyzc.py:189-201); it must have been zero-filled by the caller. */
 int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c,
                    const double *stats, const float *gamma, const float *beta,
-                   const float *running_mean, const float *running_var, int training, float eps,
+                   float *running_mean, float *running_var, int training, float eps, float momentum,
                    float *batch_stats, const int32_t *rows_lin, float *dense, void *stream);
 
 /* Embedding lookup of the per-vertex codes (latent_xyzc.py:33-34): rows[r,:] = c[rows_vert[r],:] */

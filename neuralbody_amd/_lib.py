@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 2
+ABI_VERSION = 4
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
@@ -48,14 +48,14 @@ SIGNATURES = {
     "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
     "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),
     "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
-    "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, C.c_int, _P, _P, _P, _P,
+    "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.c_int, _P, _P, _P, _P,
                            _P, _P, C.c_int, _P]),
     "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
     "nb_scan_scratch_size": (_I64, [_I64]),
     "nb_enc_voxelize": (C.c_int, [_P, _I32, _I32x3, _P, _P, _P, _P, _P, _P]),
     "nb_enc_downsample_index": (C.c_int, [_P, _P, _I32, _I32x3, _I32x3, _P, _P, _P, _I32, _P, _P]),
     "nb_enc_conv": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _P]),
-    "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, _P, _P, _P, _P]),
+    "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P]),
     "nb_enc_gather_codes": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_raygen": (C.c_int, [_I32, _I32, C.c_double * 9, C.c_double * 9, C.c_double * 3, C.c_float * 6, _P, _P, _P,
                             _P, _P, _P, _P, _P]),

@@ -110,7 +110,10 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_
                                                    const int *__restrict__ n_out, Dims go, int stride,
                                                    const float *__restrict__ weight, float *__restrict__ out_rows,
                                                    double *__restrict__ stats) {
-    constexpr int NT = (COUT + 31) / 32, HALF = CIN / 2;
+    // one wave = 32 output rows x 32 output channels (blockIdx.y selects the channel tile): the deep levels have
+    // few rows (1.6 k - 13 k), so splitting Cout across waves is what fills the 1024 SIMDs
+    constexpr int NT = 1, HALF = CIN / 2;
+    const int ct = blockIdx.y;  // channel tile
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = *n_out;
@@ -148,12 +151,12 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_
 #pragma unroll
             for (int c = 0; c < HALF; ++c) A[c] = 0.f;
         }
-        const float *wo = weight + ((size_t)o * CIN + hi * HALF) * COUT + i;  // B[k=hi][j=i]
+        const float *wo = weight + ((size_t)o * CIN + hi * HALF) * COUT + ct * 32 + i;  // B[k=hi][j=i]
 #pragma unroll
         for (int c = 0; c < HALF; ++c) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const int co = t * 32 + i;
+                const int co = (ct + t) * 32 + i;
                 const float b = (COUT % 32 == 0 || co < COUT) ? wo[(size_t)c * COUT + t * 32] : 0.f;
                 acc[t] = NB_MFMA(A[c], b, acc[t]);
             }
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_
     // D fragment: lane (j = i, hi) holds channel t*32 + j of rows row0 + tile_row(r, hi)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int co = t * 32 + i;
+        const int co = (ct + t) * 32 + i;
         const bool cok = (COUT % 32 == 0) || co < COUT;
         double s = 0.0, ss = 0.0;
 #pragma unroll
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_
 // ------------------------------------------------------------------ BatchNorm1d + ReLU (+ .dense())
 __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__ n_rows, int C,
                                const double *__restrict__ stats, const float *__restrict__ gamma,
-                               const float *__restrict__ beta, const float *__restrict__ rmean,
-                               const float *__restrict__ rvar, int training, float eps,
+                               const float *__restrict__ beta, float *__restrict__ rmean,
+                               float *__restrict__ rvar, int training, float eps, float momentum,
                                float *__restrict__ batch_stats, const int *__restrict__ rows_lin,
                                float *__restrict__ dense) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -198,8 +201,14 @@ __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__
             batch_stats[2 * C] = (float)n;
         } else if (training && n > 0) {
             const double m = stats[idx] / n;
+            const double var = fmax(stats[C + idx] / n - m * m, 0.0);
             batch_stats[idx] = (float)m;
-            batch_stats[C + idx] = (float)fmax(stats[C + idx] / n - m * m, 0.0);
+            batch_stats[C + idx] = (float)var;
+            if (momentum >= 0.f) {  // nn.BatchNorm1d bookkeeping: unbiased variance into running_var
+                const float unb = (float)(var * ((double)n / (double)(n > 1 ? n - 1 : 1)));
+                rmean[idx] = (1.f - momentum) * rmean[idx] + momentum * (float)m;
+                rvar[idx] = (1.f - momentum) * rvar[idx] + momentum * unb;
+            }
         } else {
             batch_stats[idx] = 0.f;
             batch_stats[C + idx] = 0.f;
@@ -236,7 +245,7 @@ __global__ void gather_codes_kernel(const float *__restrict__ codes, const int *
 template <int CIN, int COUT>
 void launch_conv(int n_out_max, hipStream_t st, const float *in_rows, const int *in_grid, Dims gi, const int *out_lin,
                  const int *n_out, Dims go, int stride, const float *weight, float *out_rows, double *stats) {
-    hipLaunchKernelGGL((conv_kernel<CIN, COUT>), dim3(nb_ceil_div(n_out_max, 128)), dim3(256), 0, st, in_rows, in_grid,
+    hipLaunchKernelGGL((conv_kernel<CIN, COUT>), dim3(nb_ceil_div(n_out_max, 128), (COUT + 31) / 32), dim3(256), 0, st, in_rows, in_grid,
                        gi, out_lin, n_out, go, stride, weight, out_rows, stats);
 }
 
@@ -325,16 +334,18 @@ int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_d
 }
 
 int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c, const double *stats,
-                   const float *gamma, const float *beta, const float *running_mean, const float *running_var,
-                   int training, float eps, float *batch_stats, const int32_t *rows_lin, float *dense, void *stream) {
+                   const float *gamma, const float *beta, float *running_mean, float *running_var, int training,
+                   float eps, float momentum, float *batch_stats, const int32_t *rows_lin, float *dense, void *stream) {
     NB_REQUIRE(rows && n_rows && gamma && beta, "nb_enc_bn_relu: NULL pointer");
     NB_REQUIRE(training ? stats != nullptr : (running_mean && running_var), "nb_enc_bn_relu: statistics missing");
+    NB_REQUIRE(!(training && momentum >= 0.f) || (running_mean && running_var && batch_stats),
+               "nb_enc_bn_relu: running statistics / batch_stats required to update them");
     NB_REQUIRE(!dense || rows_lin, "nb_enc_bn_relu: rows_lin required with dense");
     NB_REQUIRE(c > 0 && n_rows_max >= 0, "nb_enc_bn_relu: bad sizes");
     const long long total = (long long)n_rows_max * c;
     const long long threads = total > c + 1 ? total : c + 1;
     hipLaunchKernelGGL(bn_relu_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_rows,
-                       c, stats, gamma, beta, running_mean, running_var, training, eps, batch_stats, rows_lin, dense);
+                       c, stats, gamma, beta, running_mean, running_var, training, eps, momentum, batch_stats, rows_lin, dense);
     NB_CHECK_LAUNCH("nb_enc_bn_relu");
     return NB_OK;
 }

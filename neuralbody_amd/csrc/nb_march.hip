@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
     long long ray = wave * 32 + j;
     const bool valid = ray < a.n_rays;
     if (!valid) ray = a.n_rays - 1;
+    if (a.ray_order) ray = a.ray_order[ray];
     const int S = a.n_samples;
     const float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
     const float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
@@ -458,7 +459,8 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
 
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias, const float *ray_o,
              const float *ray_d, const float *near, const float *far, int64_t n_rays, int32_t n_samples,
-             const float *t_vals, const float *t_rand, int white_bkgd, float *rgb_map, float *disp_map,
+             const float *t_vals, const float *t_rand, const int32_t *ray_order, int white_bkgd, float *rgb_map,
+             float *disp_map,
              float *acc_map, float *weights, float *depth_map, float *raw, int precision, void *stream) {
     NB_REQUIRE(scene && packed && latent_bias, "nb_march: NULL scene / weights");
     NB_REQUIRE(n_rays >= 0 && n_samples >= 1, "nb_march: n_rays = %lld, n_samples = %d", (long long)n_rays, n_samples);
@@ -467,7 +469,8 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     NB_REQUIRE(rgb_map && disp_map && acc_map && weights && depth_map, "nb_march: NULL output");
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
-    fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, white_bkgd,
+    fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, ray_order,
+                    white_bkgd,
                     rgb_map, disp_map, acc_map, weights, depth_map, raw);
     NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3, "nb_march: precision %d", precision);
     if (precision == NB_PREC_BF16X3) return nbm::launch_march_bf16(a, (hipStream_t)stream);

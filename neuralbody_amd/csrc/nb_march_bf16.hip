@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256) void nb_march16_kernel(MarchArgs a) {
     long long ray = wave * 32 + j;
     const bool valid = ray < a.n_rays;
     if (!valid) ray = a.n_rays - 1;
+    if (a.ray_order) ray = a.ray_order[ray];
     const int S = a.n_samples;
     const float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
     const float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];

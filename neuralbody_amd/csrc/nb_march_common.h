@@ -59,6 +59,7 @@ struct MarchArgs {
     const float *lb;
     // ray mode
     const float *ray_o, *ray_d, *near, *far, *t_vals, *t_rand;
+    const int *ray_order;  // optional slot -> ray permutation
     float *rgb_map, *disp_map, *acc_map, *weights, *depth_map, *raw;
     long long n_rays;
     int n_samples;
@@ -417,7 +418,8 @@ inline int fill_scene(const nb_scene *s, SceneDev *d) {
 
 inline void fill_march_args(MarchArgs &a, const float *packed, const float *latent_bias, const float *ray_o,
                             const float *ray_d, const float *near, const float *far, long long n_rays, int n_samples,
-                            const float *t_vals, const float *t_rand, int white_bkgd, float *rgb_map, float *disp_map,
+                            const float *t_vals, const float *t_rand, const int *ray_order, int white_bkgd,
+                            float *rgb_map, float *disp_map,
                             float *acc_map, float *weights, float *depth_map, float *raw) {
     a.pk = packed;
     a.lb = latent_bias;
@@ -427,6 +429,7 @@ inline void fill_march_args(MarchArgs &a, const float *packed, const float *late
     a.far = far;
     a.t_vals = t_vals;
     a.t_rand = t_rand;
+    a.ray_order = ray_order;
     a.rgb_map = rgb_map;
     a.disp_map = disp_map;
     a.acc_map = acc_map;

@@ -87,22 +87,14 @@ class SparseConvNet(nn.Module):
                 if name in DENSE_AFTER and j == n - 1:
                     dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
                     volumes.append(dense)
-                bstats = ops.enc_bn_relu(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
-                                         bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense)
+                ops.enc_bn_relu(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
+                                bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
+                                momentum=bn.momentum if training else -1.0)  # running stats updated in-kernel
                 if training:
-                    bn_updates.append((bn, bstats))
+                    bn_updates.append(bn.num_batches_tracked)
                 rows, grid, rows_lin, n_rows, n_max, dhw = new_rows, out_grid, out_lin, n_out, n_out_max, out_dhw
         if training:
-            # nn.BatchNorm1d bookkeeping (momentum 0.01, unbiased variance into running_var); tiny
-            # device-side vector updates, no host sync
-            with torch.no_grad():
-                for bn, bs in bn_updates:
-                    c = bn.num_features
-                    n = bs[2 * c]
-                    unbias = n / torch.clamp(n - 1.0, min=1.0)
-                    bn.running_mean.mul_(1 - bn.momentum).add_(bs[:c], alpha=bn.momentum)
-                    bn.running_var.mul_(1 - bn.momentum).add_(bs[c:2 * c] * unbias, alpha=bn.momentum)
-                    bn.num_batches_tracked += 1
+            torch._foreach_add_(bn_updates, 1)  # nn.BatchNorm1d bookkeeping, one fused launch
         return volumes
 
 
@@ -232,7 +224,7 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ fused march
     def render_rays(self, ray_o, ray_d, near, far, feature_volume, sp_input, n_samples, t_rand=None,
-                    white_bkgd=False, want_raw=False):
+                    white_bkgd=False, want_raw=False, ray_order=None):
         """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
         scene = self.make_scene(feature_volume, sp_input)
         lb = self.latent_bias(sp_input["latent_index"])
@@ -242,4 +234,4 @@ class Network(nn.Module):
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._host_cache[key] = t_vals
         return ops.march(scene, self.packed_weights(), lb, ray_o, ray_d, near, far, t_vals, t_rand,
-                         white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision)
+                         white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision, ray_order=ray_order)

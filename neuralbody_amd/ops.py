@@ -130,7 +130,7 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
 
 
 def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=None, white_bkgd=False,
-          want_raw=False, precision="f32"):
+          want_raw=False, precision="f32", ray_order=None):
     """nb_march: all rays of one batch element -> dict of per-ray outputs."""
     sc, _keep = scene
     _req(packed, torch.float32, (mlp_pack_size(),), "packed")
@@ -144,6 +144,8 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
     S = t_vals.shape[0]
     if t_rand is not None:
         _req(t_rand, torch.float32, (n, S), "t_rand")
+    if ray_order is not None:
+        _req(ray_order, torch.int32, (n,), "ray_order")
     dev = ray_o.device
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     disp = torch.empty((n,), dtype=torch.float32, device=dev)
@@ -156,7 +158,8 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     check(_lib.lib().nb_march(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(ray_o), ptr(ray_d), ptr(near), ptr(far),
-                              n, S, ptr(t_vals), ptr(t_rand), 1 if white_bkgd else 0, ptr(rgb), ptr(disp), ptr(acc),
+                              n, S, ptr(t_vals), ptr(t_rand), ptr(ray_order), 1 if white_bkgd else 0, ptr(rgb), ptr(disp),
+                              ptr(acc),
                               ptr(weights), ptr(depth), ptr(raw), _lib.PRECISIONS[precision], _stream()), "nb_march")
     if ev is not None:
         ev[1].record()
@@ -251,8 +254,9 @@ def enc_conv(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, strid
 
 
 def enc_bn_relu(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, running_var, training, eps,
-                rows_lin=None, dense=None):
-    """nb_enc_bn_relu (in place on rows) -> batch_stats [2C+1] = mean | biased var | n_rows."""
+                rows_lin=None, dense=None, momentum=-1.0):
+    """nb_enc_bn_relu (in place on rows) -> batch_stats [2C+1] = mean | biased var | n_rows.
+    momentum >= 0 (training only): running_mean / running_var are updated in place by the kernel."""
     c = int(rows.shape[1])
     _req(rows, torch.float32, (None, c), "rows")
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
@@ -265,7 +269,8 @@ def enc_bn_relu(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, runn
     batch_stats = torch.empty(2 * c + 1, dtype=torch.float32, device=rows.device)
     check(_lib.lib().nb_enc_bn_relu(ptr(rows), ptr(n_rows), int(n_rows_max), c, ptr(stats), ptr(gamma), ptr(beta),
                                     ptr(running_mean), ptr(running_var), 1 if training else 0, float(eps),
-                                    ptr(batch_stats), ptr(rows_lin), ptr(dense), _stream()), "nb_enc_bn_relu")
+                                    float(momentum), ptr(batch_stats), ptr(rows_lin), ptr(dense), _stream()),
+          "nb_enc_bn_relu")
     return batch_stats
 
 
@@ -303,3 +308,14 @@ def raygen(H, W, K, R, T, bounds, device):
                                    (C.c_float * 6)(*b), ptr(ray_o), ptr(ray_d), ptr(near), ptr(far), ptr(mask),
                                    ptr(n_rays), ptr(scratch), _stream()), "nb_raygen")
     return ray_o, ray_d, near, far, mask, n_rays
+
+
+def tile_order(pix, width, tile_w=8, tile_h=4):
+    """Permutation (int32) that groups rays into tile_w x tile_h pixel tiles: `pix` are the linear pixel
+    ids (row-major, image `width`) of the rays.  32 consecutive slots = one wavefront = one compact tile, so
+    the rays a wave marches together touch the same few voxels on every pyramid level."""
+    py, px = torch.div(pix, width, rounding_mode="floor"), pix % width
+    n_tx = (width + tile_w - 1) // tile_w
+    key = ((torch.div(py, tile_h, rounding_mode="floor") * n_tx + torch.div(px, tile_w, rounding_mode="floor"))
+           * (tile_w * tile_h) + (py % tile_h) * tile_w + (px % tile_w))
+    return torch.argsort(key).to(torch.int32)

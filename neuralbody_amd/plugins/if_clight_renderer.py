@@ -20,6 +20,8 @@ class _LiveCfg:
     perturb = property(lambda self: float(cfg.perturb))
     raw_noise_std = property(lambda self: float(cfg.raw_noise_std))
     white_bkgd = property(lambda self: bool(cfg.white_bkgd))
+    H = property(lambda self: int(cfg.H * cfg.ratio))  # image_rays geometry, lib/utils/render_utils.py:121-122
+    W = property(lambda self: int(cfg.W * cfg.ratio))
 
 
 class Renderer(_Renderer):

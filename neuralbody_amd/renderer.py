@@ -17,7 +17,10 @@ from . import ops
 class RenderConfig:
     """The cfg keys the hot path reads."""
 
-    def __init__(self, N_samples=64, perturb=0.0, raw_noise_std=0.0, white_bkgd=False):
+    def __init__(self, N_samples=64, perturb=0.0, raw_noise_std=0.0, white_bkgd=False, H=None, W=None):
+        # H, W (optional): image size of the view the rays come from (cfg.H * cfg.ratio in the reference); when
+        # batch['mask_at_box'] covers H*W pixels, rays are grouped into 8x4 pixel tiles per wavefront
+        self.H, self.W = H, W
         self.N_samples = int(N_samples)
         self.perturb = float(perturb)
         self.raw_noise_std = float(raw_noise_std)
@@ -103,7 +106,26 @@ class Renderer:
             tr = t_rand[0, b:e].float().contiguous()
         else:
             tr = None
+        ray_order = self._tile_order(batch, n_pixel, b, e)
         ret = self.net.render_rays(ray_o[0, b:e].contiguous(), ray_d[0, b:e].contiguous(), near[0, b:e].contiguous(),
                                    far[0, b:e].contiguous(), feature_volume, sp_input, self.cfg.N_samples, t_rand=tr,
-                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw)
+                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw, ray_order=ray_order)
         return {k: v[None] for k, v in ret.items()}
+
+    def _tile_order(self, batch, n_pixel, b, e):
+        """slot -> ray permutation grouping the rays [b, e) into 8x4 pixel tiles (None when the image geometry
+        is unknown: the march then takes the rays in list order).  Pure index plumbing; results do not change."""
+        H, W = getattr(self.cfg, "H", None), getattr(self.cfg, "W", None)
+        mask = batch.get("mask_at_box")
+        if not H or not W or mask is None or mask.numel() != int(H) * int(W) or e - b < 64:
+            return None
+        key = (mask.data_ptr(), mask._version, int(W), b, e)
+        cached = getattr(self, "_order_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        pix = torch.nonzero(mask.reshape(-1), as_tuple=False).reshape(-1)
+        if pix.numel() != n_pixel:
+            return None
+        order = ops.tile_order(pix[b:e], int(W))
+        self._order_cache = (key, order)
+        return order

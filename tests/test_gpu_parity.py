@@ -317,6 +317,14 @@ def test_full_size_properties_512(precision):
             part = rend.render(bd, ray_range=(b, e))
             for k in full:
                 assert H.same_bits(part[k][0], full[k][0, b:e]), (k, b, e)
+        # grouping rays into 8x4 pixel tiles per wavefront (ray_order) changes nothing but locality
+        bd_t = dict(bd, mask_at_box=mask[None].bool())
+        tiled = Renderer(net, RenderConfig(N_samples=64, H=Hh, W=Ww)).render(bd_t)
+        assert Renderer(net, RenderConfig(N_samples=64, H=Hh, W=Ww))._tile_order(bd_t, n, 0, n) is not None
+        for k in full:
+            assert H.same_bits(tiled[k], full[k]), "tiled ray order changed " + k
+        part = Renderer(net, RenderConfig(N_samples=64, H=Hh, W=Ww)).render(bd_t, ray_range=(1000, 9000))
+        assert H.same_bits(part["rgb_map"][0], full["rgb_map"][0, 1000:9000])
         # permutation equivariance
         perm = torch.randperm(4096, device=DEV)
         sub = {k: (v[:, perm] if k in ("ray_o", "ray_d", "near", "far") else v) for k, v in bd.items()}
