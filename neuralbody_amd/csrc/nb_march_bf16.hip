@@ -29,10 +29,16 @@ namespace nbm {
 
 // --------------------------------------------------------------- weight stream geometry
 constexpr int REC_BYTES = 2048;  // one K=16 chunk of one 32-row tile: A_hi (1 KiB) + A_lo (1 KiB)
-constexpr int PAGE_RECS = 10;
+// ring geometry (measured: 10-record pages x 5 slots 30.45 ms vs 20-record pages x 3 slots 30.85 ms per image)
+#ifndef NB_PAGE_RECS
+#define NB_PAGE_RECS 10
+#define NB_N_SLOTS 5
+#define NB_N_RECS_PAD 650
+#endif
+constexpr int PAGE_RECS = NB_PAGE_RECS;
 constexpr int PAGE_BYTES = PAGE_RECS * REC_BYTES;  // 20 KiB
-constexpr int N_SLOTS = 5;
-constexpr int AHEAD = 4;  // pages in flight ahead of the page being consumed
+constexpr int N_SLOTS = NB_N_SLOTS;
+constexpr int AHEAD = N_SLOTS - 1;  // pages in flight ahead of the page being consumed
 constexpr int NC0 = 22, NCH = 16, NCV = 22;
 constexpr int REC_L0 = 0;
 constexpr int REC_L1 = REC_L0 + 8 * NC0;
@@ -40,12 +46,12 @@ constexpr int REC_L2 = REC_L1 + 8 * NCH;
 constexpr int REC_L4 = REC_L2 + 8 * NCH;
 constexpr int REC_LV = REC_L4 + 8 * NCH;
 constexpr int N_RECS = REC_LV + 4 * NCV;  // 648 records carry weights
-constexpr int N_RECS_PAD = 650;           // + 2 zero records so that the page count is a multiple of the ring size
+constexpr int N_RECS_PAD = NB_N_RECS_PAD;  // + zero records so that the page count is a multiple of the ring size
 constexpr int N_PAGES = N_RECS_PAD / PAGE_RECS;  // 65
 static_assert(N_RECS_PAD % PAGE_RECS == 0 && N_RECS_PAD >= N_RECS, "stream must be a whole number of pages");
 static_assert(N_PAGES % N_SLOTS == 0, "page p must always land in slot p % N_SLOTS, also across the step wrap-around");
 static_assert(PAGE_RECS % 2 == 0, "record pairs must not straddle pages");
-static_assert(PAGE_RECS / 2 == PAGE_BYTES / 1024 / 4, "one DMA piece per record pair refills a page exactly");
+
 constexpr int DMA_PER_WAVE = PAGE_BYTES / 1024 / 4;  // 5 one-KiB pieces per wave per page
 
 }  // namespace nbm
@@ -85,7 +91,7 @@ struct Ring {
     int wave_off;        // byte offset of this wave's share inside a page (uniform)
     int lane;
     char *tile;          // this wave's voxel tile
-    int base03, base34;  // lane * 16 (+ 3 pages): opaque byte offsets of ring slots 0-2 / 3-4
+    int base[N_SLOTS];   // lane * 16 + slot * PAGE_BYTES: opaque byte offsets of the ring slots
 };
 
 // All address arithmetic below is wave-uniform (SGPR) except the single lane * 16 term, so every DMA
@@ -113,18 +119,21 @@ __device__ __forceinline__ void turn_page(const Ring &rg, int page) {
 #else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((AHEAD - 1) * DMA_PER_WAVE) : "memory");
 #endif
+#ifndef NB_ABL_NOBARRIER
     asm volatile("s_barrier" ::: "memory");
+#endif
 #if !defined(NB_ABL_NODMA) && !defined(NB_DMA_SPREAD)
     issue_page(rg, (page + AHEAD) % N_PAGES);
 #endif
 }
 
-// ds_read_b128 carries a 16-bit immediate offset: two opaque base registers (slots 0-2 and slots 3-4)
-// reach the whole ring with base + immediate, instead of one VALU address computation per read
+// ds_read_b128 carries a 16-bit immediate offset: one opaque base register per ring slot reaches every
+// fragment with base + immediate, instead of one VALU address computation per read
+static_assert(PAGE_BYTES <= 65536, "a page must be addressable with the 16-bit ds_read offset");
 __device__ __forceinline__ bf16x8 lds_frag(const Ring &rg, int rec, int lo) {
     const int page = rec / PAGE_RECS, slot = page % N_SLOTS;
-    const int off = (slot % 3) * PAGE_BYTES + (rec % PAGE_RECS) * REC_BYTES + lo * 1024;
-    return *reinterpret_cast<const bf16x8 *>(rg.lds + (slot < 3 ? rg.base03 : rg.base34) + off);
+    const int off = (rec % PAGE_RECS) * REC_BYTES + lo * 1024;
+    return *reinterpret_cast<const bf16x8 *>(rg.lds + rg.base[slot] + off);
 }
 
 #ifdef NB_ABL_NOGATHER
@@ -142,6 +151,13 @@ __device__ __forceinline__ void fake_level(const SceneDev &sc, const GridCoord &
 
 // split 8 fp32 values into bf16 hi (round to nearest even) and bf16 lo = rne(v - hi)
 __device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+#ifdef NB_ABL_NOCONV
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const f4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    hi = __builtin_bit_cast(bf16x8, a);
+    lo = __builtin_bit_cast(bf16x8, b);
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const __bf16 h = (__bf16)v[i];
@@ -358,7 +374,6 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
     }
 #if defined(NB_DMA_SPREAD) && !defined(NB_ABL_NODMA)
     // the two padding records form the 325th record pair of the step: issue the DMA piece that rides on it
-    static_assert(N_RECS_PAD - N_RECS == 2, "exactly one padding pair");
     issue_piece(rg, (N_RECS / PAGE_RECS + AHEAD) % N_PAGES, (N_RECS % PAGE_RECS) / 2);
 #endif
     if (DBG && dbg) dump_tiles(v, dbg + 352 + 512, hi, true);
@@ -404,9 +419,11 @@ __device__ __forceinline__ Ring ring_begin(const float *pk, const float *lb, cha
     rg.lds = lds;
     rg.lane = threadIdx.x & 63;
     rg.tile = lds + RING_BYTES + PARAM_BYTES + wave * TILE_BYTES;
-    rg.base03 = rg.lane * 16;
-    rg.base34 = rg.lane * 16 + 3 * PAGE_BYTES;
-    asm volatile("" : "+v"(rg.base03), "+v"(rg.base34));
+#pragma unroll
+    for (int sl = 0; sl < N_SLOTS; ++sl) {
+        rg.base[sl] = rg.lane * 16 + sl * PAGE_BYTES;
+        asm volatile("" : "+v"(rg.base[sl]));
+    }
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p) issue_page(rg, p);
     return rg;
@@ -506,8 +523,11 @@ __global__ __launch_bounds__(256) void nb_march16_kernel(MarchArgs a) {
         r2.stream = rg.stream + zero;
         r2.wave_off = rg.wave_off + zero;
         r2.tile = rg.tile + zero;
-        r2.base03 = lane_i * 16;
-        r2.base34 = lane_i * 16 + 3 * PAGE_BYTES;
+#pragma unroll
+        for (int sl = 0; sl < N_SLOTS; ++sl) {
+            r2.base[sl] = lane_i * 16 + sl * PAGE_BYTES;
+            asm volatile("" : "+v"(r2.base[sl]));  // keep base + immediate addressing (do not fold into per-read adds)
+        }
         decode16<false, false>(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, nullptr);
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
