@@ -175,6 +175,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
+    # read from inside the process); the committed summary is quoted when it matches the workload
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_march16_traffic.json")
+    if net.precision == "bf16x3" and (H, W, S) == (512, 512, 64) and os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)["hbm_bytes_per_launch"]
     total_rays = n_rays * world * args.steps
     samples_per_s = total_rays * S / elapsed
     dtype, kernel_name, exec_flop, peak = PRECISION_INFO[net.precision]
@@ -193,13 +200,14 @@ def main():
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
-                     "traffic": None, "avg_launch_ms": march_ms,
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_march16_traffic.json)",
+                     "avg_launch_ms": march_ms,
                      "executed_tflops": exec_flop * n_rays * S / (march_ms * 1e-3) / 1e12,
                      "executed_frac": exec_flop * n_rays * S / (march_ms * 1e-3) / 1e12 / peak,
                      "note": "achieved = 859904 algorithmic flop/sample x %d samples/launch / avg launch time (HIP events); "
                              "the kernel issues %.0f MFMA flop/sample (merged feature_fc.latent_fc layer%s), so "
                              "executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~219 MB/launch "
-                             "(<0.1%% of the launch time at 8 TB/s), PMC traffic not collected"
+                             "(<0.1%% of the launch time at 8 TB/s)"
                              % (n_rays * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.precision == "bf16x3" else "")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
     };
 
     RayAccum ra;
+    WeightStore wstore;
     float z_cur = z_at(0);
     for (int s = 0; s < S; ++s) {
         const float z_next = (s + 1 < S) ? z_at(s + 1) : 0.f;
@@ -259,10 +260,9 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
         const float w = ra.add(out, z_cur, dist);
-        if (valid && hi == 0) {
-            a.weights[ray * S + s] = w;
-            if (a.raw) *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
-        }
+        wstore.push(a, ray, s, S, hi, valid, w);
+        if (valid && hi == 0 && a.raw)
+            *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
         z_cur = z_next;
     }
     if (valid && hi == 0) ra.store(a, ray);

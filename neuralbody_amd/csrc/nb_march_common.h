@@ -395,6 +395,27 @@ struct RayAccum {
     }
 };
 
+// `weights` [n_rays, S] is written one value per ray per depth step; a 4-byte store per lane at a 4*S-byte
+// stride turns into one partial HBM sector write each (measured: WRITE_SIZE 739 MB per 512x512x64 launch
+// for 67 MB of payload).  Each lane therefore keeps four consecutive steps in registers — the hi = 0 half
+// of a sample column steps 8m..8m+3, the hi = 1 half steps 8m+4..8m+7 — and stores them as one aligned
+// 16-byte vector, so a ray's two halves fill a 32-byte sector together.
+struct WeightStore {
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    __device__ __forceinline__ void push(const MarchArgs &a, long long ray, int s, int S, int hi, bool valid, float w) {
+        if ((S & 7) != 0) {  // wave-uniform: odd sample counts take the simple path
+            if (valid && hi == 0) a.weights[ray * S + s] = w;
+            return;
+        }
+        const int slot = s & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (slot == hi * 4 + i) q[i] = w;
+        if (slot == 7 && valid)
+            *reinterpret_cast<f32x4 *>(a.weights + ray * S + (s - 7) + hi * 4) = f32x4{q[0], q[1], q[2], q[3]};
+    }
+};
+
 inline int fill_scene(const nb_scene *s, SceneDev *d) {
     for (int l = 0; l < 4; ++l) {
         NB_REQUIRE(s->vol[l] != nullptr, "nb_scene.vol[%d] is NULL", l);

@@ -135,6 +135,52 @@ def test_march_on_oracle_volumes_matches_reference(name, precision):
     assert float(g["rgb_map"].max()) > 0.1, "fixture is degenerate"
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_march_edge_cases(precision):
+    """Ragged and degenerate inputs: ray counts around the 32-ray wavefront / 128-ray workgroup granularity
+    (0, 1, 31, 33, 129), sample counts that are not a multiple of 8 (scalar weight-store path) or tiny (S=2),
+    rays that miss the volume completely (zero features everywhere), white background."""
+    from oracle import neuralbody_oracle as orc
+
+    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, _ = _scene_with_oracle_volumes("small_dense", precision)
+    n_all = batch["ray_o"].shape[1]
+    ro, rd, ne, fa = bd["ray_o"][0], bd["ray_d"][0], bd["near"][0], bd["far"][0]
+    full = net.render_rays(ro, rd, ne, fa, vols_dev, sp, 64, white_bkgd=True)
+    for n in (0, 1, 31, 33, 129):
+        part = net.render_rays(ro[:n].contiguous(), rd[:n].contiguous(), ne[:n].contiguous(), fa[:n].contiguous(),
+                               vols_dev, sp, 64, white_bkgd=True)
+        for k in full:
+            assert part[k].shape[0] == n
+            assert H.same_bits(part[k], full[k][:n]), (k, n)
+    # an explicit identity / reversed ray_order changes nothing
+    perm = torch.arange(n_all - 1, -1, -1, dtype=torch.int32, device=DEV)
+    rev = net.render_rays(ro, rd, ne, fa, vols_dev, sp, 64, white_bkgd=True, ray_order=perm)
+    assert H.same_bits(rev["rgb_map"], full["rgb_map"]) and H.same_bits(rev["weights"], full["weights"])
+    # other sample counts against the oracle
+    sub = slice(0, 160)
+    for S in (2, 20, 40):
+        b_np = dict(batch)
+        for k in ("ray_o", "ray_d", "near", "far"):
+            b_np[k] = batch[k][:, sub]
+        with torch.no_grad():
+            ref = orc.render(sdt, b_np, n_samples=S, training=True, feature_volume=vols, white_bkgd=True)
+        got = net.render_rays(ro[sub].contiguous(), rd[sub].contiguous(), ne[sub].contiguous(), fa[sub].contiguous(),
+                              vols_dev, sp, S, white_bkgd=True)
+        H.assert_close(got["rgb_map"].cpu().numpy()[None], ref["rgb_map"].numpy(), H.RGB_TOL, "rgb S=%d" % S, rel=False)
+        H.assert_close(got["weights"].cpu().numpy()[None], ref["weights"].numpy(), 2e-4, "weights S=%d" % S)
+    # rays pointing away from the body: every sample lies outside the volume -> all features are zero padding
+    away = {k: torch.from_numpy(batch[k][:, :64].copy()) for k in ("ray_o", "ray_d", "near", "far")}
+    away["ray_d"] = -away["ray_d"]
+    b_np = dict(batch)
+    b_np.update({k: v.numpy() for k, v in away.items()})
+    with torch.no_grad():
+        ref = orc.render(sdt, b_np, n_samples=64, training=True, feature_volume=vols, white_bkgd=True)
+    got = net.render_rays(away["ray_o"][0].to(DEV), away["ray_d"][0].to(DEV), away["near"][0].to(DEV),
+                          away["far"][0].to(DEV), vols_dev, sp, 64, white_bkgd=True)
+    H.assert_close(got["rgb_map"].cpu().numpy()[None], ref["rgb_map"].numpy(), H.RGB_TOL, "rgb of rays that miss", rel=False)
+    H.assert_close(got["acc_map"].cpu().numpy()[None], ref["acc_map"].numpy(), 1e-4, "acc of rays that miss")
+
+
 def test_composite_matches_oracle():
     from neuralbody_amd import ops
     from oracle import neuralbody_oracle as orc
