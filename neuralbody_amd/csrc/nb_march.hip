@@ -109,15 +109,17 @@ __device__ __forceinline__ void dump_tiles(const f32x16 (&h)[NT], float *dst, in
 // ---------------------------------------------------------------- per-sample decode
 // Returns sigma in out[3] and (unless DENSITY_ONLY) rgb logits in out[0..2]; both half-waves
 // of a sample column receive the same values.
+constexpr int F32_TILE_BYTES = 16384;  // per-wave voxel tile of the cooperative gather (this kernel has no other LDS use)
+
 template <bool DENSITY_ONLY, bool DBG>
 __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restrict__ pk, const float *__restrict__ lb,
-                                       float px, float py, float pz, const float (&pe)[N_PE], int lane,
+                                       float px, float py, float pz, const float (&pe)[N_PE], int lane, char *tile,
                                        float (&out)[4], float *dbg) {
     const int hi = lane >> 5;
     f32x16 h[8], acc[8];
     {
         float F[176];
-        gather_features(sc, px, py, pz, hi, F);
+        gather_features<F32_TILE_BYTES>(sc, px, py, pz, hi, lane, tile, F);
         if (DBG && dbg) {
 #pragma unroll
             for (int q = 0; q < 176; ++q) dbg[col_feat(q, hi)] = F[q];
@@ -148,7 +150,7 @@ __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restri
             s = fmaf(w.z, h[q4 >> 2][(q4 & 3) * 4 + 2], s);
             s = fmaf(w.w, h[q4 >> 2][(q4 & 3) * 4 + 3], s);
         }
-        s += __shfl_xor(s, 32);
+        s = add_halves(s);
         out[3] = s + pk[OFF_AB];
     }
     if (DENSITY_ONLY) return;
@@ -176,7 +178,7 @@ __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restri
             s = fmaf(w.z, v[q4 >> 2][(q4 & 3) * 4 + 2], s);
             s = fmaf(w.w, v[q4 >> 2][(q4 & 3) * 4 + 3], s);
         }
-        s += __shfl_xor(s, 32);
+        s = add_halves(s);
         out[ch] = s + pk[OFF_RB + ch];
     }
 }
@@ -184,6 +186,8 @@ __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restri
 // ---------------------------------------------------------------- point-mode kernel
 template <bool DENSITY_ONLY, bool DBG>
 __global__ __launch_bounds__(256) void nb_points_kernel(MarchArgs a) {
+    __shared__ __attribute__((aligned(16))) char tiles[4 * F32_TILE_BYTES];
+    char *tile = tiles + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * F32_TILE_BYTES;
     const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     long long idx = wave * 32 + j;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(256) void nb_points_kernel(MarchArgs a) {
     }
     float out[4];
     float *dbg = (DBG && a.dbg && valid) ? a.dbg + idx * 992 : nullptr;
-    decode<DENSITY_ONLY, DBG>(a.sc, a.pk, a.lb, px, py, pz, pe, lane, out, dbg);
+    decode<DENSITY_ONLY, DBG>(a.sc, a.pk, a.lb, px, py, pz, pe, lane, tile, out, dbg);
     if (valid && hi == 0) {
         if (DENSITY_ONLY) {
             a.raw_out[idx] = out[3];
@@ -214,6 +218,8 @@ __global__ __launch_bounds__(256) void nb_points_kernel(MarchArgs a) {
 
 // ---------------------------------------------------------------- ray-mode kernel (march + composite)
 __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
+    __shared__ __attribute__((aligned(16))) char tiles[4 * F32_TILE_BYTES];
+    char *tile = tiles + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * F32_TILE_BYTES;
     const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
     const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
     const long long wave = (long long)grp * 4 + (threadIdx.x >> 6);
@@ -254,9 +260,10 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
         // the weight stream is loop-invariant: hide the base pointers from LICM, which would otherwise
         // hoist all ~5000 fragment loads out of the depth loop and spill them
         // (an opaque zero offset keeps the pointers in the global address space)
-        int zero = 0;
-        asm volatile("" : "+s"(zero));
-        decode<false, false>(a.sc, a.pk + zero, a.lb + zero, px, py, pz, pe, lane, out, nullptr);
+        // (same for everything derived from the lane id: recompute inside the body instead of spilling it)
+        int zero = 0, lane_i = lane;
+        asm volatile("" : "+s"(zero), "+v"(lane_i));
+        decode<false, false>(a.sc, a.pk + zero, a.lb + zero, px, py, pz, pe, lane_i, tile + zero, out, nullptr);
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
         const float w = ra.add(out, z_cur, dist);

@@ -333,14 +333,17 @@ __device__ __forceinline__ void gather_level_coop(const SceneDev &sc, const Grid
     }
 }
 
-__device__ __forceinline__ void gather_features(const SceneDev &sc, float px, float py, float pz, int hi,
-                                                float (&F)[176]) {
+// all four levels through the cooperative gather (tile = wave-private LDS of TILE bytes)
+template <int TILE>
+__device__ __forceinline__ void gather_features(const SceneDev &sc, float px, float py, float pz, int hi, int lane,
+                                                char *tile, float (&F)[176]) {
     const GridCoord g = grid_coords(sc, px, py, pz);
+    const WaveBox wb = wave_box(g);
     float f0[16], f1[32], f2[64], f3[64];
-    gather_level<0>(sc, g, hi, f0);
-    gather_level<1>(sc, g, hi, f1);
-    gather_level<2>(sc, g, hi, f2);
-    gather_level<3>(sc, g, hi, f3);
+    gather_level_coop<0, TILE>(sc, g, wb, hi, lane, tile, f0);
+    gather_level_coop<1, TILE>(sc, g, wb, hi, lane, tile, f1);
+    gather_level_coop<2, TILE>(sc, g, wb, hi, lane, tile, f2);
+    gather_level_coop<3, TILE>(sc, g, wb, hi, lane, tile, f3);
 #pragma unroll
     for (int i = 0; i < 16; ++i) F[i] = f0[i];
 #pragma unroll

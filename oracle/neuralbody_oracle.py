@@ -6,7 +6,7 @@ only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
 
 Pinning:
   * rows a1-a5, a7-a14 are pinned against the UNMODIFIED reference executed on CPU
-    (oracle/ref_harness.py) — tests/test_oracle_vs_reference.py when /root/reference
+    (oracle/ref_harness.py) — tests/test_reference_interop.py when /root/reference
     exists, and the committed fixtures tests/golden/*.npz (made by
     tests/golden/make_golden.py from the reference itself) everywhere.
   * row a6 (the spconv encoder): **parity unpinned** against spconv v1.2.1 @ abf0acf

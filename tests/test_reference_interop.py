@@ -1,0 +1,69 @@
+"""Interop with the reference's own code (CPU; needs /root/reference, skipped on the GPU box):
+  * a checkpoint written by the reference's save_model from the reference Network loads into our Network
+    through the reference's load_network (lib/utils/net_utils.py:326-380), key for key, value for value;
+  * the plugin files resolve through the reference's make_network / make_renderer factories
+    (lib/networks/make_network.py:5-9, lib/networks/renderer/make_renderer.py:5-9) and build our classes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_harness as rh
+
+pytestmark = pytest.mark.skipif(not rh.available(), reason="reference tree not present")
+
+PLUGINS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neuralbody_amd", "plugins")
+
+
+def test_reference_checkpoint_round_trip(tmp_path):
+    from neuralbody_amd import synthetic as syn
+    from neuralbody_amd.network import Network
+
+    ns = rh.load()
+    import lib.utils.net_utils as nu  # the reference's module (importable once rh.load() ran)
+
+    sd = syn.make_weights(3, num_train_frame=9)
+    ref_net = rh.make_reference_network(sd)
+
+    class _Dummy:  # optimizer / scheduler / recorder stand-ins with the state_dict surface save_model uses
+        def state_dict(self):
+            return {}
+
+    nu.save_model(ref_net, _Dummy(), _Dummy(), _Dummy(), str(tmp_path), epoch=7, last=True)
+    ours = Network(num_train_frame=9)
+    next_epoch = nu.load_network(ours, str(tmp_path), strict=True)
+    assert next_epoch == 8
+    got = ours.state_dict()
+    assert list(got) == list(ref_net.state_dict()), "state_dict key ORDER differs from the reference"
+    for k, v in ref_net.state_dict().items():
+        assert torch.equal(got[k], v), k
+    # and back: our weights load into the reference module
+    ref_net.load_state_dict(ours.state_dict(), strict=True)
+
+
+def test_plugins_resolve_through_reference_factories():
+    ns = rh.load()
+    cfg = ns.cfg
+    saved = (cfg.network_module, cfg.network_path, cfg.renderer_module, cfg.renderer_path)
+    cwd = os.getcwd()
+    os.chdir(ns.root)
+    try:
+        cfg.network_module, cfg.network_path = "lib.networks.latent_xyzc_hip", os.path.join(PLUGINS, "latent_xyzc.py")
+        cfg.renderer_module = "lib.networks.renderer.if_clight_renderer_hip"
+        cfg.renderer_path = os.path.join(PLUGINS, "if_clight_renderer.py")
+        net = ns.make_network(cfg)
+        ren = ns.make_renderer(cfg, net)
+    finally:
+        cfg.network_module, cfg.network_path, cfg.renderer_module, cfg.renderer_path = saved
+        os.chdir(cwd)
+    from neuralbody_amd.network import Network
+    from neuralbody_amd.renderer import Renderer
+
+    assert isinstance(net, Network) and isinstance(ren, Renderer)
+    assert net.latent.weight.shape[0] == cfg.num_train_frame
+    assert ren.cfg.N_samples == cfg.N_samples and ren.cfg.H == int(cfg.H * cfg.ratio)
+    for name in ("encode_sparse_voxels", "calculate_density", "calculate_density_color", "forward"):
+        assert callable(getattr(net, name))
+    for name in ("get_sampling_points", "prepare_sp_input", "get_density_color", "get_pixel_value", "render"):
+        assert callable(getattr(ren, name))
