@@ -94,7 +94,7 @@ __device__ __forceinline__ void relu_tiles(f32x16 (&h)[NT]) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h[t][r] = fmaxf(h[t][r], 0.f);
+        for (int r = 0; r < 16; ++r) h[t][r] = relu1(h[t][r]);
 }
 
 // out[f] for the feature held in (tile t, register r) of this lane

@@ -180,20 +180,36 @@ struct Frag4 {
     bf16x8 ah0, al0, ah1, al1;
 };
 
+// hipcc waits lgkmcnt(0) before the first use of ANY LDS read once an LDS-DMA has been issued (measured: 348
+// full drains per depth step, i.e. the prefetched fragments of the NEXT record pair were waited for together
+// with the current ones and the LDS latency was exposed in every other iteration).  The fragment reads are
+// therefore issued from inline asm, which the compiler does not count, and waited for by hand with a COUNTED
+// lgkmcnt: LDS operations retire in order, so "at most 4 outstanding" means everything older than the four reads
+// just issued for the next pair — in particular the current pair's fragments — has landed.
 template <int REC0>
-__device__ __forceinline__ Frag4 load_pair(const Ring &rg, int k) {
+__device__ __forceinline__ void load_pair(const Ring &rg, int k, Frag4 &f) {
     const int rec = REC0 + 2 * k;
-    Frag4 f;
     if (rec % PAGE_RECS == 0) turn_page(rg, rec / PAGE_RECS);
 #if defined(NB_DMA_SPREAD) && !defined(NB_ABL_NODMA)
     issue_piece(rg, (rec / PAGE_RECS + AHEAD) % N_PAGES, (rec % PAGE_RECS) / 2);  // after the page's barrier
 #endif
-    f.ah0 = lds_frag(rg, rec, 0);
-    f.al0 = lds_frag(rg, rec, 1);
-    if ((rec + 1) % PAGE_RECS == 0) turn_page(rg, (rec + 1) / PAGE_RECS);
-    f.ah1 = lds_frag(rg, rec + 1, 0);
-    f.al1 = lds_frag(rg, rec + 1, 1);
-    return f;
+    const int page = rec / PAGE_RECS, slot = page % N_SLOTS;
+    const int addr = rg.base[slot] + (rec % PAGE_RECS) * REC_BYTES;  // lane * 16 + slot base + record offset
+    // one statement: four reads of two consecutive records (A_hi, A_lo of tile t0, then of tile t1)
+    asm volatile(
+        "ds_read_b128 %0, %4\n\t"
+        "ds_read_b128 %1, %4 offset:1024\n\t"
+        "ds_read_b128 %2, %4 offset:2048\n\t"
+        "ds_read_b128 %3, %4 offset:3072"
+        : "=&v"(f.ah0), "=&v"(f.al0), "=&v"(f.ah1), "=&v"(f.al1)
+        : "v"(addr)
+        : "memory");
+}
+
+// wait until the fragments in `f` have landed while the NEWER reads (4 of them, or none) may stay in flight
+template <int NEWER>
+__device__ __forceinline__ void wait_pair(Frag4 &f) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.ah0), "+v"(f.al0), "+v"(f.ah1), "+v"(f.al1) : "n"(NEWER));
 }
 
 // INIT: start the NT accumulator tiles from the bias; otherwise continue accumulating into `acc`
@@ -203,37 +219,38 @@ __device__ __forceinline__ void mlp_layer16(const Ring &rg, const float *bp, f32
                                             const bf16x8 (&xh)[NC], const bf16x8 (&xl)[NC]) {
     const int hi = rg.lane >> 5;
     constexpr int NP = NT / 2 * NC;
-    Frag4 cur = load_pair<REC0>(rg, 0);
+    Frag4 buf[2];
+    load_pair<REC0>(rg, 0, buf[0]);
     f32x16 c0, c1;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        const int tp = k / NC, c = k % NC;
-        if (c == 0) {
-            if (INIT) {
-                c0 = bias_tile(bp, 2 * tp, hi);
-                c1 = bias_tile(bp, 2 * tp + 1, hi);
+    for (int tp = 0; tp < NT / 2; ++tp) {
+        if (INIT) {
+            c0 = bias_tile(bp, 2 * tp, hi);
+            c1 = bias_tile(bp, 2 * tp + 1, hi);
+        } else {
+            c0 = acc[2 * tp];
+            c1 = acc[2 * tp + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = tp * NC + c;
+            Frag4 &cur = buf[k & 1];
+            if (k + 1 < NP) {
+                load_pair<REC0>(rg, k + 1, buf[(k + 1) & 1]);
+                wait_pair<4>(cur);
             } else {
-                c0 = acc[2 * tp];
-                c1 = acc[2 * tp + 1];
+                wait_pair<0>(cur);
             }
+            c0 = NB_MFMA16(cur.ah0, xh[c], c0);
+            c1 = NB_MFMA16(cur.ah1, xh[c], c1);
+            c0 = NB_MFMA16(cur.ah0, xl[c], c0);
+            c1 = NB_MFMA16(cur.ah1, xl[c], c1);
+            c0 = NB_MFMA16(cur.al0, xh[c], c0);
+            c1 = NB_MFMA16(cur.al1, xh[c], c1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        Frag4 nxt = cur;
-        if (k + 1 < NP) nxt = load_pair<REC0>(rg, k + 1);
-        c0 = NB_MFMA16(cur.ah0, xh[c], c0);
-        c1 = NB_MFMA16(cur.ah1, xh[c], c1);
-        c0 = NB_MFMA16(cur.ah0, xl[c], c0);
-        c1 = NB_MFMA16(cur.ah1, xl[c], c1);
-        c0 = NB_MFMA16(cur.al0, xh[c], c0);
-        c1 = NB_MFMA16(cur.al1, xh[c], c1);
-        // issue the next pair's four fragment reads first, so six MFMAs (192 cycles) cover the LDS latency
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (c == NC - 1) {
-            acc[2 * tp] = c0;
-            acc[2 * tp + 1] = c1;
-        }
-        cur = nxt;
+        acc[2 * tp] = c0;
+        acc[2 * tp + 1] = c1;
     }
 }
 
@@ -246,7 +263,7 @@ __device__ __forceinline__ void tiles_to_operands(const f32x16 (&acc)[8], bf16x8
         for (int h = 0; h < 2; ++h) {
             float v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = RELU ? fmaxf(acc[t][8 * h + r], 0.f) : acc[t][8 * h + r];
+            for (int r = 0; r < 8; ++r) v[r] = RELU ? relu1(acc[t][8 * h + r]) : acc[t][8 * h + r];
             split8(v, xh[2 * t + h], xl[2 * t + h]);
         }
 }
@@ -336,10 +353,10 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
 #pragma unroll
         for (int q4 = 0; q4 < 32; ++q4) {
             const f32x4 w = aw[q4];
-            s = fmaf(w.x, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 0], 0.f), s);
-            s = fmaf(w.y, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 1], 0.f), s);
-            s = fmaf(w.z, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 2], 0.f), s);
-            s = fmaf(w.w, fmaxf(acc[q4 >> 2][(q4 & 3) * 4 + 3], 0.f), s);
+            s = fmaf(w.x, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 0]), s);
+            s = fmaf(w.y, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 1]), s);
+            s = fmaf(w.z, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 2]), s);
+            s = fmaf(w.w, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 3]), s);
         }
         s = add_halves(s);
         out[3] = s + prm[P_AB];
@@ -384,10 +401,10 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
 #pragma unroll
         for (int q4 = 0; q4 < 16; ++q4) {
             const f32x4 w = rw[q4];
-            s = fmaf(w.x, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 0], 0.f), s);
-            s = fmaf(w.y, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 1], 0.f), s);
-            s = fmaf(w.z, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 2], 0.f), s);
-            s = fmaf(w.w, fmaxf(v[q4 >> 2][(q4 & 3) * 4 + 3], 0.f), s);
+            s = fmaf(w.x, relu1(v[q4 >> 2][(q4 & 3) * 4 + 0]), s);
+            s = fmaf(w.y, relu1(v[q4 >> 2][(q4 & 3) * 4 + 1]), s);
+            s = fmaf(w.z, relu1(v[q4 >> 2][(q4 & 3) * 4 + 2]), s);
+            s = fmaf(w.w, relu1(v[q4 >> 2][(q4 & 3) * 4 + 3]), s);
         }
         s = add_halves(s);
         out[ch] = s + prm[P_RB + ch];

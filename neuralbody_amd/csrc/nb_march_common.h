@@ -11,6 +11,9 @@ namespace nbm {
 
 constexpr int N_PE = 45;
 
+// relu as one v_med3_f32: fmaxf on an MFMA result makes hipcc insert a canonicalising v_max_f32 x, x, x first
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+
 // feature row (within a 32-row tile) held by accumulator register r of a lane with half index hi
 __host__ __device__ constexpr int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
