@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 4
+#define NB_ABI_VERSION 5
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -41,6 +41,7 @@ extern "C" {
 #define NB_HID 256
 #define NB_VIEW_HID 128
 #define NB_N_LEVELS 4
+#define NB_TAP_WIDTH 1600
 
 const char *nb_last_error(void);
 int nb_abi_version(void);
@@ -101,8 +102,9 @@ int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *o
  * Network.calculate_density (:74-89).
  *   wpts    dev [n,3] world-space points; viewdir dev [n,3] (ignored when density_only)
  *   raw_out dev [n,4] (rgb logits, sigma)   or [n,1] sigma when density_only
- *   dbg     dev or NULL: when non-NULL receives, per point, [352 features | 256 h3 |
- *           256 merged-latent layer output | 128 view hidden] = 992 floats (tests only)
+ *   dbg     dev or NULL: activation tap, NB_TAP_WIDTH floats per point:
+ *           [F 352 | h1 256 | h2 256 | h3 256 | G 256 (latent_fc output) | V 128 | PE 90 | pad]
+ *           (post-ReLU where the layer has one) — what the backward pass consumes; also used by tests
  * ------------------------------------------------------------------------------- */
 int nb_decode_points(const nb_scene *scene, const float *packed, const float *latent_bias,
                      const float *wpts, const float *viewdir, int64_t n, int density_only,
@@ -137,6 +139,34 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
 int nb_composite(const float *raw, const float *z_vals, const float *ray_d, int64_t n_rays,
                  int32_t n_samples, int white_bkgd, float *rgb_map, float *disp_map,
                  float *acc_map, float *weights, float *depth_map, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * Backward pass (training step: lib/train/trainers/if_nerf_clight.py:18-36 runs Renderer.render
+ * under autograd; the reference's backward is PyTorch autograd through the same modules).
+ * ------------------------------------------------------------------------------- */
+
+/* d raw [n_rays,n_samples,4] from d rgb_map [n_rays,3] (and optionally d acc_map / d depth_map
+ * [n_rays], may be NULL): backward of raw2outputs (nerf_net_utils.py:19-49, raw_noise_std 0). */
+int nb_composite_bwd(const float *raw, const float *z_vals, const float *ray_d, int64_t n_rays,
+                     int32_t n_samples, int white_bkgd, const float *d_rgb_map, const float *d_acc_map,
+                     const float *d_depth_map, float *d_raw, void *stream);
+
+/* Row-major fp32 GEMM C[m,n] = alpha * op(A) op(B) + beta * C on rocBLAS (the MLP backward's plain
+ * library GEMMs: backward of the Conv1d(k=1) layers, latent_xyzc.py:99-121).  lda/ldb/ldc are row
+ * strides.  The library keeps one lazily created rocBLAS handle. */
+int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
+             const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream);
+
+/* dy[i] = y[i] > 0 ? dy[i] : 0 (ReLU backward on the post-activation value), in place. */
+int nb_relu_bwd(float *dy, const float *y, int64_t n, void *stream);
+/* out[c] += sum_r x[r*ld + c]  (bias gradients); out must be initialised by the caller. */
+int nb_colsum(const float *x, int64_t n_rows, int32_t n_cols, int32_t ld, float *out, void *stream);
+
+/* Backward of the 4-level trilinear lookup (F.grid_sample, latent_xyzc.py:62-72) restricted to the
+ * ACTIVE voxels: d_feat dev [n,352] -> drows[l] dev [n_rows_l, C_l] (+=, atomics; zero them first),
+ * grids[l] dev = index grid of level l (row id or -1).  scene->vol[] is not read. */
+int nb_trilinear_bwd(const nb_scene *scene, const int32_t *const grids[4], float *const drows[4],
+                     const float *wpts, const float *d_feat, int64_t n, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Structured-latent-code encoder — replaces Network.encode_sparse_voxels

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
@@ -51,6 +51,11 @@ SIGNATURES = {
     "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.c_int, _P, _P, _P, _P,
                            _P, _P, C.c_int, _P]),
     "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "nb_composite_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P]),
+    "nb_sgemm": (C.c_int, [C.c_int, C.c_int, _I32, _I32, _I32, C.c_float, _P, _I32, _P, _I32, C.c_float, _P, _I32, _P]),
+    "nb_relu_bwd": (C.c_int, [_P, _P, _I64, _P]),
+    "nb_colsum": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
+    "nb_trilinear_bwd": (C.c_int, [C.POINTER(NbScene), C.c_void_p * 4, C.c_void_p * 4, _P, _P, _I64, _P]),
     "nb_scan_scratch_size": (_I64, [_I64]),
     "nb_enc_voxelize": (C.c_int, [_P, _I32, _I32x3, _P, _P, _P, _P, _P, _P]),
     "nb_enc_downsample_index": (C.c_int, [_P, _P, _I32, _I32x3, _I32x3, _P, _P, _P, _I32, _P, _P]),

@@ -1,0 +1,222 @@
+// nb_backward.hip — backward pass of the decoder side of the hot path (training step, SURVEY.md §8 row a15:
+// lib/train/trainers/if_nerf_clight.py:18-36 calls Renderer.render under autograd; the reference's backward is
+// PyTorch autograd through raw2outputs, the Conv1d stack, F.grid_sample and spconv).
+//
+//   nb_composite_bwd   d(rgb_map, acc_map, depth_map) -> d raw            (raw2outputs, nerf_net_utils.py:19-49)
+//   nb_sgemm           plain row-major fp32 GEMMs of the MLP backward on rocBLAS (library GEMMs: dX = dY.W,
+//                      dW = dY^T.X over the N = rays x samples rows)
+//   nb_relu_bwd / nb_colsum   elementwise mask and bias-gradient reductions
+//   nb_trilinear_bwd   dF [N,352] -> gradients of the ACTIVE voxel rows of the four feature volumes
+//                      (grid_sample backward restricted to active voxels: inactive sites are constants)
+#include <rocblas/rocblas.h>
+
+#include "nb_march_common.h"
+
+using namespace nbm;
+
+namespace {
+
+// ------------------------------------------------------------------ compositing backward
+// One thread per ray, two sweeps.  Forward sweep recomputes alpha_i, T_i and stashes T_i in d_raw[...,3];
+// backward sweep carries B_i = sum_{k>i} w_k dw_k:
+//   dw_i     = g . c_i (+ d_acc + d_depth z_i - [white_bkgd] sum(g))
+//   dc_i     = w_i g                         -> d raw_rgb = dc (.) c (1 - c)
+//   dalpha_i = T_i dw_i - B_i / (1 - alpha_i + 1e-10)
+//   dsigma_i = dalpha_i dist_i (1 - alpha_i) [sigma_i > 0]
+__global__ void composite_bwd_kernel(const float *__restrict__ raw, const float *__restrict__ z,
+                                     const float *__restrict__ ray_d, long long n_rays, int S, int white_bkgd,
+                                     const float *__restrict__ d_rgb, const float *__restrict__ d_acc,
+                                     const float *__restrict__ d_depth, float *__restrict__ d_raw) {
+    const long long ray = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (ray >= n_rays) return;
+    const float dx = ray_d[ray * 3], dy = ray_d[ray * 3 + 1], dz = ray_d[ray * 3 + 2];
+    const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float g0 = d_rgb[ray * 3], g1 = d_rgb[ray * 3 + 1], g2 = d_rgb[ray * 3 + 2];
+    const float ga = d_acc ? d_acc[ray] : 0.f, gd = d_depth ? d_depth[ray] : 0.f;
+    const float gw = white_bkgd ? -(g0 + g1 + g2) : 0.f;
+    const float *r = raw + ray * S * 4;
+    const float *zz = z + ray * S;
+    float *o = d_raw + ray * S * 4;
+    auto dist_of = [&](int s) { return __fmul_rn((s + 1 < S) ? __fsub_rn(zz[s + 1], zz[s]) : 1e10f, dn); };
+    float T = 1.f;
+    for (int s = 0; s < S; ++s) {
+        const float alpha = 1.f - expf(-fmaxf(r[s * 4 + 3], 0.f) * dist_of(s));
+        o[s * 4 + 3] = T;
+        T = T * (__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
+    }
+    float B = 0.f;
+    for (int s = S - 1; s >= 0; --s) {
+        const float sig = r[s * 4 + 3], dist = dist_of(s);
+        const float e = expf(-fmaxf(sig, 0.f) * dist);  // 1 - alpha
+        const float alpha = 1.f - e;
+        const float Ts = o[s * 4 + 3];
+        const float w = alpha * Ts;
+        const float c0 = 1.f / (1.f + expf(-r[s * 4])), c1 = 1.f / (1.f + expf(-r[s * 4 + 1])),
+                    c2 = 1.f / (1.f + expf(-r[s * 4 + 2]));
+        const float dw = g0 * c0 + g1 * c1 + g2 * c2 + ga + gd * zz[s] + gw;
+        o[s * 4 + 0] = w * g0 * c0 * (1.f - c0);
+        o[s * 4 + 1] = w * g1 * c1 * (1.f - c1);
+        o[s * 4 + 2] = w * g2 * c2 * (1.f - c2);
+        const float dalpha = Ts * dw - B / (__fadd_rn(e, 1e-10f));
+        o[s * 4 + 3] = sig > 0.f ? dalpha * dist * e : 0.f;
+        B += w * dw;
+    }
+}
+
+__global__ void relu_bwd_kernel(float *__restrict__ dy, const float *__restrict__ y, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        f32x4 d = *reinterpret_cast<f32x4 *>(dy + i);
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(y + i);
+        d.x = v.x > 0.f ? d.x : 0.f;
+        d.y = v.y > 0.f ? d.y : 0.f;
+        d.z = v.z > 0.f ? d.z : 0.f;
+        d.w = v.w > 0.f ? d.w : 0.f;
+        *reinterpret_cast<f32x4 *>(dy + i) = d;
+    } else {
+        for (long long k = i; k < n; ++k) dy[k] = y[k] > 0.f ? dy[k] : 0.f;
+    }
+}
+
+// out[c] (+)= sum_r x[r * ld + c]   — one block per 64 columns x a slab of rows, fp64 partials, float atomics
+__global__ void colsum_kernel(const float *__restrict__ x, long long n_rows, int n_cols, int ld, float *__restrict__ out) {
+    __shared__ double part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const long long rows_per_block = (n_rows + gridDim.y - 1) / gridDim.y;
+    const long long r0 = (long long)blockIdx.y * rows_per_block, r1 = min(n_rows, r0 + rows_per_block);
+    double s = 0.0;
+    if (c < n_cols)
+        for (long long r = r0 + w; r < r1; r += 4) s += (double)x[r * ld + c];
+    part[w][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (w == 0 && c < n_cols) atomicAdd(&out[c], (float)(part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// ------------------------------------------------------------------ trilinear (grid_sample) backward
+struct TriArgs {
+    SceneDev sc;              // vol[] unused
+    const int *grid[4];       // index grid of each dense level (row id or -1)
+    float *drows[4];          // gradient of the active rows [n_rows_l, C_l], accumulated with atomics
+    const float *wpts;        // [n,3]
+    const float *dF;          // [n,352]
+    long long n;
+};
+
+__global__ void trilinear_bwd_kernel(TriArgs a) {
+    // one thread per (point, 4-channel group): 88 groups = 8 + 16 + 32 + 32
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pt = t / 88;
+    if (pt >= a.n) return;
+    const int g = (int)(t % 88);
+    const int L = g < 8 ? 0 : (g < 24 ? 1 : (g < 56 ? 2 : 3));
+    const int q = g - (L == 0 ? 0 : (L == 1 ? 8 : (L == 2 ? 24 : 56)));
+    const int C = lvl_c(L);
+    const GridCoord gc = grid_coords(a.sc, a.wpts[pt * 3], a.wpts[pt * 3 + 1], a.wpts[pt * 3 + 2]);
+    const int D = a.sc.dhw[L][0], H = a.sc.dhw[L][1], W = a.sc.dhw[L][2];
+    const float ix = unnorm_clamped(gc.gw, W), iy = unnorm_clamped(gc.gh, H), iz = unnorm_clamped(gc.gd, D);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
+    const f32x4 d = *reinterpret_cast<const f32x4 *>(a.dF + pt * 352 + lvl_chan_base(L) + q * 4);
+    if (d.x == 0.f && d.y == 0.f && d.z == 0.f && d.w == 0.f) return;
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+        if ((unsigned)xx >= (unsigned)W || (unsigned)yy >= (unsigned)H || (unsigned)zz >= (unsigned)D) continue;
+        const int row = a.grid[L][((long long)zz * H + yy) * W + xx];
+        if (row < 0) continue;  // inactive voxel: a constant zero of .dense(), no parameter behind it
+        const float w = (wx[dx] * wy[dy]) * wz[dz];
+        float *dst = a.drows[L] + (size_t)row * C + q * 4;
+        atomicAdd(dst + 0, w * d.x);
+        atomicAdd(dst + 1, w * d.y);
+        atomicAdd(dst + 2, w * d.z);
+        atomicAdd(dst + 3, w * d.w);
+    }
+}
+
+rocblas_handle g_handle = nullptr;
+
+}  // namespace
+
+extern "C" {
+
+int nb_composite_bwd(const float *raw, const float *z_vals, const float *ray_d, int64_t n_rays, int32_t n_samples,
+                     int white_bkgd, const float *d_rgb_map, const float *d_acc_map, const float *d_depth_map,
+                     float *d_raw, void *stream) {
+    NB_REQUIRE(n_rays >= 0 && n_samples >= 1, "nb_composite_bwd: bad sizes");
+    if (n_rays == 0) return NB_OK;
+    NB_REQUIRE(raw && z_vals && ray_d && d_rgb_map && d_raw, "nb_composite_bwd: NULL pointer");
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(nb_ceil_div(n_rays, 64)), dim3(64), 0, (hipStream_t)stream, raw, z_vals,
+                       ray_d, (long long)n_rays, n_samples, white_bkgd, d_rgb_map, d_acc_map, d_depth_map, d_raw);
+    NB_CHECK_LAUNCH("composite_bwd_kernel");
+    return NB_OK;
+}
+
+int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
+             const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream) {
+    NB_REQUIRE(a && b && c && m >= 0 && n >= 0 && k >= 0, "nb_sgemm: bad argument");
+    if (m == 0 || n == 0) return NB_OK;
+    if (!g_handle) {
+        if (rocblas_create_handle(&g_handle) != rocblas_status_success) {
+            nb_set_error("nb_sgemm: rocblas_create_handle failed");
+            return NB_ELAUNCH;
+        }
+    }
+    rocblas_set_stream(g_handle, (hipStream_t)stream);
+    rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
+    // row-major C[m,n] = op(A) op(B)  ==  column-major C^T[n,m] = op(B)^T op(A)^T
+    const rocblas_status st = rocblas_sgemm(g_handle, trans_b ? rocblas_operation_transpose : rocblas_operation_none,
+                                            trans_a ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha,
+                                            b, ldb, a, lda, &beta, c, ldc);
+    if (st != rocblas_status_success) {
+        nb_set_error("nb_sgemm: rocblas_sgemm status %d", (int)st);
+        return NB_ELAUNCH;
+    }
+    return NB_OK;
+}
+
+int nb_relu_bwd(float *dy, const float *y, int64_t n, void *stream) {
+    NB_REQUIRE(n >= 0, "nb_relu_bwd: n < 0");
+    if (n == 0) return NB_OK;
+    NB_REQUIRE(dy && y, "nb_relu_bwd: NULL pointer");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(nb_ceil_div(nb_ceil_div(n, 4), 256)), dim3(256), 0, (hipStream_t)stream, dy, y,
+                       (long long)n);
+    NB_CHECK_LAUNCH("relu_bwd_kernel");
+    return NB_OK;
+}
+
+int nb_colsum(const float *x, int64_t n_rows, int32_t n_cols, int32_t ld, float *out, void *stream) {
+    NB_REQUIRE(n_rows >= 0 && n_cols >= 0 && ld >= n_cols, "nb_colsum: bad sizes");
+    if (n_rows == 0 || n_cols == 0) return NB_OK;
+    NB_REQUIRE(x && out, "nb_colsum: NULL pointer");
+    const int slabs = (int)(n_rows < 4096 ? 1 : (n_rows / 1024 < 256 ? n_rows / 1024 : 256));
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb_ceil_div(n_cols, 64), slabs), dim3(256), 0, (hipStream_t)stream, x,
+                       (long long)n_rows, n_cols, ld, out);
+    NB_CHECK_LAUNCH("colsum_kernel");
+    return NB_OK;
+}
+
+int nb_trilinear_bwd(const nb_scene *scene, const int32_t *const grids[4], float *const drows[4], const float *wpts,
+                     const float *d_feat, int64_t n, void *stream) {
+    NB_REQUIRE(scene && grids && drows && n >= 0, "nb_trilinear_bwd: bad argument");
+    if (n == 0) return NB_OK;
+    NB_REQUIRE(wpts && d_feat, "nb_trilinear_bwd: NULL pointer");
+    TriArgs a = {};
+    nb_scene tmp = *scene;
+    for (int l = 0; l < 4; ++l) {
+        NB_REQUIRE(grids[l] && drows[l], "nb_trilinear_bwd: NULL grid / gradient buffer at level %d", l);
+        a.grid[l] = grids[l];
+        a.drows[l] = drows[l];
+        if (!tmp.vol[l]) tmp.vol[l] = wpts;  // the forward volumes are not read here; any non-NULL pointer passes the check
+    }
+    if (int rc = fill_scene(&tmp, &a.sc)) return rc;
+    a.wpts = wpts;
+    a.dF = d_feat;
+    a.n = n;
+    hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(nb_ceil_div(n * 88, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    NB_CHECK_LAUNCH("trilinear_bwd_kernel");
+    return NB_OK;
+}
+
+}  // extern "C"

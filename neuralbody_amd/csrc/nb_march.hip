@@ -122,22 +122,24 @@ __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restri
         gather_features<F32_TILE_BYTES>(sc, px, py, pz, hi, lane, tile, F);
         if (DBG && dbg) {
 #pragma unroll
-            for (int q = 0; q < 176; ++q) dbg[col_feat(q, hi)] = F[q];
+            for (int q = 0; q < 176; ++q) dbg[TAP_F + col_feat(q, hi)] = F[q];
         }
         mlp_layer<8, G0, NB_PF>(pk + OFF_L0, pk + OFF_B0, acc, [&](int q) { return F[q]; }, lane);
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = acc[t];
     relu_tiles(h);
+    if (DBG && dbg) dump_tiles(h, dbg + TAP_H1, hi);
     mlp_layer<8, GH, NB_PF>(pk + OFF_L1, pk + OFF_B1, acc, [&](int q) { return h[q >> 4][q & 15]; }, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = acc[t];
     relu_tiles(h);
+    if (DBG && dbg) dump_tiles(h, dbg + TAP_H2, hi);
     mlp_layer<8, GH, NB_PF>(pk + OFF_L2, pk + OFF_B2, acc, [&](int q) { return h[q >> 4][q & 15]; }, lane);
 #pragma unroll
     for (int t = 0; t < 8; ++t) h[t] = acc[t];
     relu_tiles(h);
-    if (DBG && dbg) dump_tiles(h, dbg + 352, hi);
+    if (DBG && dbg) dump_tiles(h, dbg + TAP_H3, hi);
     // alpha_fc on the VALU: each half-wave holds 128 of the 256 features of its sample
     {
         const f32x4 *aw = reinterpret_cast<const f32x4 *>(pk + OFF_AW + hi * 128);
@@ -156,7 +158,7 @@ __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restri
     if (DENSITY_ONLY) return;
     // feature_fc and latent_fc[:, :256] merged; per-frame latent folded into the bias `lb`
     mlp_layer<8, GH, NB_PF>(pk + OFF_L4, lb, acc, [&](int q) { return h[q >> 4][q & 15]; }, lane);
-    if (DBG && dbg) dump_tiles(acc, dbg + 352 + 256, hi);
+    if (DBG && dbg) dump_tiles(acc, dbg + TAP_G, hi);
     // view_fc on [latent_fc out (256) | PE(viewdir) | PE(xyz)]
     f32x16 v[4];
     mlp_layer<4, GV, NB_PF>(
@@ -164,7 +166,10 @@ __device__ __forceinline__ void decode(const SceneDev &sc, const float *__restri
         [&](int q) { return q < 128 ? acc[q >> 4][q & 15] : (q - 128 < N_PE ? pe[q - 128 < N_PE ? q - 128 : 0] : 0.f); },
         lane);
     relu_tiles(v);
-    if (DBG && dbg) dump_tiles(v, dbg + 352 + 512, hi);
+    if (DBG && dbg) {
+        dump_tiles(v, dbg + TAP_V, hi);
+        dump_pe(pe, dbg + TAP_PE, hi);
+    }
     // rgb_fc on the VALU
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void nb_points_kernel(MarchArgs a) {
         for (int c = 0; c < N_PE; ++c) pe[c] = 0.f;
     }
     float out[4];
-    float *dbg = (DBG && a.dbg && valid) ? a.dbg + idx * 992 : nullptr;
+    float *dbg = (DBG && a.dbg && valid) ? a.dbg + idx * TAP_WIDTH : nullptr;
     decode<DENSITY_ONLY, DBG>(a.sc, a.pk, a.lb, px, py, pz, pe, lane, tile, out, dbg);
     if (valid && hi == 0) {
         if (DENSITY_ONLY) {

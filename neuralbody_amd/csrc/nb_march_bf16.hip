@@ -287,7 +287,7 @@ __device__ __forceinline__ void feats_to_operands(const float (&f)[8 * NCL], bf1
         split8(v, fh[c], fl[c]);
         if (dbg) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) dbg[col_feat(dbg_base + 8 * c + r, hi)] = v[r];
+            for (int r = 0; r < 8; ++r) dbg[TAP_F + col_feat(dbg_base + 8 * c + r, hi)] = v[r];
         }
     }
 }
@@ -341,11 +341,13 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
 #undef gather_level_coop
 #endif
     }
+    if (DBG && dbg) dump_tiles(acc, dbg + TAP_H1, hi, true);
     tiles_to_operands<true>(acc, xh, xl);
     mlp_layer16<REC_L1, 8, NCH>(rg, prm + P_B1, acc, xh, xl);
+    if (DBG && dbg) dump_tiles(acc, dbg + TAP_H2, hi, true);
     tiles_to_operands<true>(acc, xh, xl);
     mlp_layer16<REC_L2, 8, NCH>(rg, prm + P_B2, acc, xh, xl);
-    if (DBG && dbg) dump_tiles(acc, dbg + 352, hi, true);
+    if (DBG && dbg) dump_tiles(acc, dbg + TAP_H3, hi, true);
     // alpha_fc in fp32 on the VALU from the un-split fc_2 output
     {
         const f32x4 *aw = reinterpret_cast<const f32x4 *>(prm + P_AW + hi * 128);
@@ -365,7 +367,7 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
     // the ring protocol needs every wave to walk the whole stream, so DENSITY_ONLY still runs the
     // colour head (its result is simply not stored)
     mlp_layer16<REC_L4, 8, NCH>(rg, prm + P_LB, acc, xh, xl);
-    if (DBG && dbg) dump_tiles(acc, dbg + 352 + 256, hi, false);
+    if (DBG && dbg) dump_tiles(acc, dbg + TAP_G, hi, false);
     // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings
     f32x16 v[4];
     tiles_to_operands<false>(acc, xh, xl);
@@ -393,7 +395,10 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
     // the two padding records form the 325th record pair of the step: issue the DMA piece that rides on it
     issue_piece(rg, (N_RECS / PAGE_RECS + AHEAD) % N_PAGES, (N_RECS % PAGE_RECS) / 2);
 #endif
-    if (DBG && dbg) dump_tiles(v, dbg + 352 + 512, hi, true);
+    if (DBG && dbg) {
+        dump_tiles(v, dbg + TAP_V, hi, true);
+        dump_pe(pe, dbg + TAP_PE, hi);
+    }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const f32x4 *rw = reinterpret_cast<const f32x4 *>(prm + P_RW + (ch * 2 + hi) * 64);
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256) void nb_points16_kernel(MarchArgs a) {
         v3[2] = vz;
     }
     float out[4];
-    float *dbg = (DBG && a.dbg && valid) ? a.dbg + idx * 992 : nullptr;
+    float *dbg = (DBG && a.dbg && valid) ? a.dbg + idx * TAP_WIDTH : nullptr;
     decode16<DENSITY_ONLY, DBG>(a.sc, rg, px, py, pz, v3[0], v3[1], v3[2], pe, out, dbg);
     if (valid && hi == 0) {
         if (DENSITY_ONLY) {

@@ -11,6 +11,10 @@ namespace nbm {
 
 constexpr int N_PE = 45;
 
+// activation tap of nb_decode_points (floats per point): what the backward pass needs
+//   [ F 352 | h1 256 | h2 256 | h3 256 | G 256 (latent_fc output) | V 128 (view_fc, post relu) | PE 90 | pad ]
+constexpr int TAP_F = 0, TAP_H1 = 352, TAP_H2 = 608, TAP_H3 = 864, TAP_G = 1120, TAP_V = 1376, TAP_PE = 1504, TAP_WIDTH = 1600;
+
 // relu as one v_med3_f32: fmaxf on an MFMA result makes hipcc insert a canonicalising v_max_f32 x, x, x first
 __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
 
@@ -110,6 +114,12 @@ __device__ __forceinline__ void pe_xyz(float (&pe)[N_PE], float px, float py, fl
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) pe[42 + a] = hi ? p[a] : v[a];
+}
+
+// tap: positional encodings in view_fc input order (column 256 + e -> tap[e], e in [0, 90))
+__device__ __forceinline__ void dump_pe(const float (&pe)[N_PE], float *dst, int hi) {
+#pragma unroll
+    for (int c = 0; c < N_PE; ++c) dst[col_pe(c, hi) - 256] = pe[c];
 }
 
 // ---------------------------------------------------------------- trilinear gather (K3 + K4)

@@ -9,7 +9,10 @@ from . import _lib
 from ._lib import NbError, NbMlpParams, NbScene, check, ptr
 
 LEVEL_CHANNELS = (32, 64, 128, 128)
-DBG_WIDTH = 992
+DBG_WIDTH = 1600
+# activation tap layout of nb_decode_points(debug=True): F | h1 | h2 | h3 | G | V | PE (csrc/nb_march_common.h TAP_*)
+TAP = {"F": (0, 352), "h1": (352, 608), "h2": (608, 864), "h3": (864, 1120), "G": (1120, 1376), "V": (1376, 1504),
+       "PE": (1504, 1594)}
 # bench.py sets this to a list to collect (start, end) HIP events bracketing every nb_march launch on
 # the stream it is enqueued on
 MARCH_EVENTS = None
@@ -319,3 +322,82 @@ def tile_order(pix, width, tile_w=8, tile_h=4):
     key = ((torch.div(py, tile_h, rounding_mode="floor") * n_tx + torch.div(px, tile_w, rounding_mode="floor"))
            * (tile_w * tile_h) + (py % tile_h) * tile_w + (px % tile_w))
     return torch.argsort(key).to(torch.int32)
+
+
+# --------------------------------------------------------------------------------- backward pass
+def composite_bwd(raw, z_vals, ray_d, d_rgb_map, white_bkgd=False, d_acc_map=None, d_depth_map=None):
+    """nb_composite_bwd: d raw [n,S,4] from d rgb_map [n,3] (+ optional d acc_map / d depth_map [n])."""
+    _req(raw, torch.float32, (None, None, 4), "raw")
+    n, S = raw.shape[:2]
+    _req(z_vals, torch.float32, (n, S), "z_vals")
+    _req(ray_d, torch.float32, (n, 3), "ray_d")
+    _req(d_rgb_map, torch.float32, (n, 3), "d_rgb_map")
+    for t, nm in ((d_acc_map, "d_acc_map"), (d_depth_map, "d_depth_map")):
+        if t is not None:
+            _req(t, torch.float32, (n,), nm)
+    d_raw = torch.empty_like(raw)
+    check(_lib.lib().nb_composite_bwd(ptr(raw), ptr(z_vals), ptr(ray_d), n, S, 1 if white_bkgd else 0, ptr(d_rgb_map),
+                                      ptr(d_acc_map), ptr(d_depth_map), ptr(d_raw), _stream()), "nb_composite_bwd")
+    return d_raw
+
+
+def _mat(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or \
+            (t.shape[1] > 1 and t.stride(1) != 1) or t.stride(0) < t.shape[1]:
+        raise ValueError("%s must be a 2-D fp32 HIP tensor with unit column stride" % name)
+    return t
+
+
+def sgemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0):
+    """nb_sgemm (rocBLAS): out[m,n] = alpha * op(a) @ op(b) + beta * out, row-major; a / b / out may be column
+    slices of wider matrices (row stride = leading dimension)."""
+    _mat(a, "a")
+    _mat(b, "b")
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    k2, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if k != k2:
+        raise ValueError("sgemm: inner dimensions %d vs %d" % (k, k2))
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+        beta = 0.0
+    _mat(out, "out")
+    if tuple(out.shape) != (m, n):
+        raise ValueError("sgemm: out is %s, expected %s" % (tuple(out.shape), (m, n)))
+    check(_lib.lib().nb_sgemm(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, float(alpha), ptr(a), a.stride(0), ptr(b),
+                              b.stride(0), float(beta), ptr(out), out.stride(0), _stream()), "nb_sgemm")
+    return out
+
+
+def relu_bwd_(dy, y):
+    """nb_relu_bwd in place: dy *= (y > 0); y is the post-activation value."""
+    _req(dy, torch.float32, None, "dy")
+    _req(y, torch.float32, tuple(dy.shape), "y")
+    check(_lib.lib().nb_relu_bwd(ptr(dy), ptr(y), dy.numel(), _stream()), "nb_relu_bwd")
+    return dy
+
+
+def colsum(x, out=None):
+    """nb_colsum: out[c] += sum_r x[r, c] (x may be a column slice)."""
+    _mat(x, "x")
+    if out is None:
+        out = torch.zeros(x.shape[1], dtype=torch.float32, device=x.device)
+    _req(out, torch.float32, (x.shape[1],), "out")
+    check(_lib.lib().nb_colsum(ptr(x), x.shape[0], x.shape[1], x.stride(0), ptr(out), _stream()), "nb_colsum")
+    return out
+
+
+def trilinear_bwd(scene, grids, drows, wpts, d_feat):
+    """nb_trilinear_bwd: d_feat [n,352] -> drows[l] += gradient of the active rows of level l."""
+    sc, _keep = scene
+    _req(wpts, torch.float32, (None, 3), "wpts")
+    n = wpts.shape[0]
+    _req(d_feat, torch.float32, (n, 352), "d_feat")
+    g4 = (C.c_void_p * 4)()
+    d4 = (C.c_void_p * 4)()
+    for l in range(4):
+        _req(grids[l], torch.int32, tuple(int(v) for v in sc.vol_dhw[l]), "grid[%d]" % l)
+        _req(drows[l], torch.float32, (None, LEVEL_CHANNELS[l]), "drows[%d]" % l)
+        g4[l] = grids[l].data_ptr()
+        d4[l] = drows[l].data_ptr()
+    check(_lib.lib().nb_trilinear_bwd(C.byref(sc), g4, d4, ptr(wpts), ptr(d_feat), n, _stream()), "nb_trilinear_bwd")
+    return drows

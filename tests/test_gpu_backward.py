@@ -1,0 +1,138 @@
+"""GPU tests of the backward pass (training step, §8 row a15) against PyTorch autograd run through the CPU oracle
+(the reference's own backward IS autograd through the same operations).  Gradients are compared relative to the
+largest reference entry of each tensor: fp32 GEMMs with different summation orders over N = rays x samples rows."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as H
+from tests.golden import scenes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rel(a, b, tol, name):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b).max() / scale
+    assert err <= tol, "%s: max |diff| / max |ref| = %.3e > %.1e (ref max %.3e)" % (name, err, tol, scale)
+    return err
+
+
+def test_composite_bwd_matches_autograd():
+    from neuralbody_amd import ops
+    from oracle import neuralbody_oracle as orc
+
+    rs = np.random.RandomState(11)
+    for n, S, white in ((37, 64, False), (9, 128, True), (5, 20, False)):
+        raw = torch.from_numpy((rs.standard_normal((n, S, 4)) * 2).astype(np.float32)).requires_grad_(True)
+        z = torch.from_numpy(np.sort(rs.uniform(1, 3, (n, S)).astype(np.float32), axis=1))
+        d = torch.from_numpy(rs.standard_normal((n, 3)).astype(np.float32))
+        g_rgb = torch.from_numpy(rs.standard_normal((n, 3)).astype(np.float32))
+        g_acc = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+        g_dep = torch.from_numpy(rs.standard_normal(n).astype(np.float32))
+        rgb, disp, acc, w, depth = orc.raw2outputs(raw, z, d, white)
+        ((rgb * g_rgb).sum() + (acc * g_acc).sum() + (depth * g_dep).sum()).backward()
+        got = ops.composite_bwd(raw.detach().to(DEV), z.to(DEV), d.to(DEV), g_rgb.to(DEV), white, g_acc.to(DEV), g_dep.to(DEV))
+        _rel(got.cpu().numpy(), raw.grad.numpy(), 2e-5, "d raw n=%d S=%d" % (n, S))
+        # rgb-only cotangent (the reference loss, if_nerf_clight.py:25)
+        raw.grad = None
+        rgb, disp, acc, w, depth = orc.raw2outputs(raw, z, d, white)
+        (rgb * g_rgb).sum().backward()
+        got = ops.composite_bwd(raw.detach().to(DEV), z.to(DEV), d.to(DEV), g_rgb.to(DEV), white)
+        _rel(got.cpu().numpy(), raw.grad.numpy(), 2e-5, "d raw (rgb only)")
+
+
+def test_sgemm_relu_colsum():
+    from neuralbody_amd import ops
+
+    rs = np.random.RandomState(3)
+    a = torch.from_numpy(rs.standard_normal((257, 40)).astype(np.float32)).to(DEV)
+    b = torch.from_numpy(rs.standard_normal((40, 33)).astype(np.float32)).to(DEV)
+    wide = torch.from_numpy(rs.standard_normal((257, 100)).astype(np.float32)).to(DEV)
+    np.testing.assert_allclose(ops.sgemm(a, b).cpu().numpy(), (a @ b).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ops.sgemm(a, a, trans_a=True).cpu().numpy(), (a.T @ a).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(ops.sgemm(b, b, trans_b=True).cpu().numpy(), (b @ b.T).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    # column slices as operands and as the (accumulating) destination
+    out = torch.ones((257, 50), device=DEV)
+    ref = out.clone()
+    ref[:, 10:43] += 2.0 * (wide[:, 5:45] @ b)
+    ops.sgemm(wide[:, 5:45], b, out=out[:, 10:43], alpha=2.0, beta=1.0)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ops.colsum(wide[:, 7:90]).cpu().numpy(), wide[:, 7:90].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    y = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
+    dy = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
+    ref = torch.where(y > 0, dy, torch.zeros_like(dy))
+    assert torch.equal(ops.relu_bwd_(dy.clone(), y), ref)
+
+
+def test_decoder_backward_matches_autograd():
+    """nb_decode_points(tap) -> nb_composite -> [nb_composite_bwd -> MLP backward -> nb_trilinear_bwd] against autograd
+    through the oracle: gradients of every MLP parameter, of the frame's latent code and of the feature volumes."""
+    from neuralbody_amd import ops, training
+    from oracle import neuralbody_oracle as orc
+
+    name = "small_dense"
+    r, sd, body, batch, cam, _ = scenes.build(name)
+    sdt, vols, out_sh = H.oracle_volumes(sd, batch, True)
+    net = H.make_network(sd, DEV, True, "f32")
+    bd = H.device_batch(batch, DEV)
+    sp = H.sp_input_of(bd, out_sh)
+    S = 64
+    sel = slice(0, 300, 2)  # 150 rays
+    ro, rd = torch.from_numpy(batch["ray_o"][:, sel]), torch.from_numpy(batch["ray_d"][:, sel])
+    ne, fa = torch.from_numpy(batch["near"][:, sel]), torch.from_numpy(batch["far"][:, sel])
+    wpts, z = orc.get_sampling_points(ro, rd, ne, fa, S)
+    vd = rd / torch.norm(rd, dim=2, keepdim=True)
+    w = wpts.reshape(1, -1, 3)
+    v = vd[:, :, None].repeat(1, 1, S, 1).reshape(1, -1, 3)
+    n_rays = ro.shape[1]
+    g_rgb = torch.from_numpy(np.random.RandomState(5).standard_normal((n_rays, 3)).astype(np.float32))
+
+    # ---- reference gradients: autograd through the oracle
+    mlp_keys = [k for k in sdt if k.split(".")[0] in ("fc_0", "fc_1", "fc_2", "alpha_fc", "feature_fc", "latent_fc", "view_fc", "rgb_fc")]
+    sdg = dict(sdt)
+    for k in mlp_keys + ["latent.weight"]:
+        sdg[k] = sdt[k].clone().requires_grad_(True)
+    vols_g = [x.clone().requires_grad_(True) for x in vols]
+    sp_cpu = {"R": torch.from_numpy(batch["R"]), "Th": torch.from_numpy(batch["Th"]), "bounds": torch.from_numpy(batch["bounds"]),
+              "latent_index": torch.from_numpy(batch["latent_index"]), "out_sh": out_sh}
+    raw_ref = orc.calculate_density_color(sdg, w, v, vols_g, sp_cpu)
+    rgb_ref = orc.raw2outputs(raw_ref.reshape(-1, S, 4), z.view(-1, S), rd.reshape(-1, 3), True)[0]
+    (rgb_ref * g_rgb).sum().backward()
+
+    # ---- HIP path
+    scene = net.make_scene([x.to(DEV) for x in vols], sp)
+    lb = net.latent_bias(bd["latent_index"])
+    wd, vdd = w[0].to(DEV).contiguous(), v[0].to(DEV).contiguous()
+    raw, tap = ops.decode_points(scene, net.packed_weights(), lb, wd, vdd, debug=True, precision="f32")
+    zd, rdd = z.view(-1, S).to(DEV).contiguous(), rd.reshape(-1, 3).to(DEV).contiguous()
+    rgb = ops.composite(raw.view(-1, S, 4), zd, rdd, True)[0]
+    _rel(rgb.cpu().numpy(), rgb_ref.detach().numpy(), 1e-4, "forward rgb")
+    d_raw = ops.composite_bwd(raw.view(-1, S, 4), zd, rdd, g_rgb.to(DEV), True)
+    grads, dF = training.decoder_backward(net, tap, d_raw.view(-1, 4), bd["latent_index"])
+    for k in mlp_keys:
+        ref = sdg[k].grad.numpy()
+        got = grads[k].cpu().numpy().reshape(ref.shape)
+        e = _rel(got, ref, 2e-4, "grad " + k)
+    li = int(batch["latent_index"][0])
+    _rel(grads["latent.row"].cpu().numpy(), sdg["latent.weight"].grad[li].numpy(), 2e-4, "grad latent row")
+    assert float(sdg["latent.weight"].grad.abs().sum() - sdg["latent.weight"].grad[li].abs().sum()) == 0.0
+    # ---- trilinear backward: index grids from the volumes' active sets, gradients of the active rows
+    grids, drows, acts = [], [], []
+    for x in vols:
+        act = (x[0].abs().sum(0) > 0)  # [D,H,W]
+        idx = torch.cumsum(act.reshape(-1).long(), 0) - 1
+        grid = torch.where(act.reshape(-1), idx, torch.full_like(idx, -1)).to(torch.int32).view(act.shape)
+        grids.append(grid.to(DEV).contiguous())
+        drows.append(torch.zeros((int(act.sum()), x.shape[1]), dtype=torch.float32, device=DEV))
+        acts.append(act)
+    ops.trilinear_bwd(scene, grids, drows, wd, dF)
+    torch.cuda.synchronize()
+    for l, (x, act) in enumerate(zip(vols_g, acts)):
+        ref = x.grad[0].permute(1, 2, 3, 0)[act].numpy()  # [n_active, C], linear voxel order == row order
+        _rel(drows[l].cpu().numpy(), ref, 3e-4, "grad of active voxels, level %d" % l)
+        assert np.abs(ref).max() > 0
