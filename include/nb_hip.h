@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 5
+#define NB_ABI_VERSION 6
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -214,11 +214,38 @@ int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_d
  * (unbiased variance, latent_xyzc.py:215 momentum 0.01);
  * training == 0: use running_mean / running_var.
  * dense (dev or NULL): channels-last [D,H,W,C] volume receiving the rows (.dense(),
- * latent_xyzc.py:189-201); it must have been zero-filled by the caller. */
+ * latent_xyzc.py:189-201); it must have been zero-filled by the caller.
+ * rows_out (dev or NULL): when given, the activated rows go there and `rows` keeps the raw
+ * convolution output (needed by nb_enc_bn_relu_bwd). */
 int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c,
                    const double *stats, const float *gamma, const float *beta,
                    float *running_mean, float *running_var, int training, float eps, float momentum,
-                   float *batch_stats, const int32_t *rows_lin, float *dense, void *stream);
+                   float *batch_stats, const int32_t *rows_lin, float *dense, float *rows_out, void *stream);
+
+/* ---- encoder backward (training).  Shapes as in the forward calls above. ---- */
+
+/* BatchNorm1d (batch statistics) + ReLU backward.  dy, y (activated rows), x (raw conv output) dev
+ * [n_rows, c]; batch_stats dev [2c+1] as written by nb_enc_bn_relu; sums dev [2c] fp64 scratch.
+ * Outputs: dx dev [n_rows, c] (may alias dy), dgamma / dbeta dev [c]. */
+int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const int32_t *n_rows,
+                       int32_t n_rows_max, int32_t c, const float *batch_stats, float eps, const float *gamma,
+                       double *sums, float *dx, float *dgamma, float *dbeta, void *stream);
+
+/* Gradient of the conv INPUT rows: din[q] = sum_o dx[r(q,o)] @ W[o]^T, where r(q,o) is the output row that
+ * read input voxel q under kernel offset o.  out_grid = index grid of the OUTPUT tensor, in_lin = linear voxel
+ * index of each INPUT row. */
+int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_t out_dhw[3], const int32_t *in_lin,
+                          const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3], int32_t stride,
+                          const float *weight, int32_t cin, int32_t cout, float *din, void *stream);
+
+/* Gradient of the conv weight [3,3,3,Cin,Cout] (zeroed by the call): dW[o] = sum_r in[nbr(r,o)]^T (x) dx[r]. */
+int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3],
+                           const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3],
+                           int32_t stride, const float *dx, int32_t cin, int32_t cout, float *dweight, void *stream);
+
+/* Embedding-lookup backward: dcodes[rows_vert[r], :] = drows[r, :] (dcodes zeroed by the caller). */
+int nb_enc_scatter_codes_bwd(const float *drows, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,
+                             int32_t c, float *dcodes, void *stream);
 
 /* Embedding lookup of the per-vertex codes (latent_xyzc.py:33-34): rows[r,:] = c[rows_vert[r],:] */
 int nb_enc_gather_codes(const float *codes, const int32_t *rows_vert, const int32_t *n_rows,

@@ -193,7 +193,7 @@ __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__
                                const float *__restrict__ beta, float *__restrict__ rmean,
                                float *__restrict__ rvar, int training, float eps, float momentum,
                                float *__restrict__ batch_stats, const int *__restrict__ rows_lin,
-                               float *__restrict__ dense) {
+                               float *__restrict__ dense, float *__restrict__ rows_out) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = *n_rows;
     if (batch_stats && idx <= C) {
@@ -229,7 +229,7 @@ __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__
     const float a = (float)(invstd * (double)gamma[c]);
     const float b = (float)((double)beta[c] - mean * invstd * (double)gamma[c]);
     const float y = fmaxf(fmaf(rows[idx], a, b), 0.f);
-    rows[idx] = y;
+    (rows_out ? rows_out : rows)[idx] = y;  // training keeps the raw conv output for the backward pass
     if (dense) dense[(size_t)rows_lin[r] * C + c] = y;
 }
 
@@ -335,7 +335,8 @@ int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_d
 
 int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c, const double *stats,
                    const float *gamma, const float *beta, float *running_mean, float *running_var, int training,
-                   float eps, float momentum, float *batch_stats, const int32_t *rows_lin, float *dense, void *stream) {
+                   float eps, float momentum, float *batch_stats, const int32_t *rows_lin, float *dense, float *rows_out,
+                   void *stream) {
     NB_REQUIRE(rows && n_rows && gamma && beta, "nb_enc_bn_relu: NULL pointer");
     NB_REQUIRE(training ? stats != nullptr : (running_mean && running_var), "nb_enc_bn_relu: statistics missing");
     NB_REQUIRE(!(training && momentum >= 0.f) || (running_mean && running_var && batch_stats),
@@ -345,7 +346,7 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
     const long long total = (long long)n_rows_max * c;
     const long long threads = total > c + 1 ? total : c + 1;
     hipLaunchKernelGGL(bn_relu_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_rows,
-                       c, stats, gamma, beta, running_mean, running_var, training, eps, momentum, batch_stats, rows_lin, dense);
+                       c, stats, gamma, beta, running_mean, running_var, training, eps, momentum, batch_stats, rows_lin, dense, rows_out);
     NB_CHECK_LAUNCH("nb_enc_bn_relu");
     return NB_OK;
 }

@@ -1,0 +1,288 @@
+// nb_encoder_bwd.hip — backward of the structured-latent-code encoder (training step, §8 row a15): the autograd of
+// SparseConvNet (lib/networks/latent_xyzc.py:166-274) as explicit kernels on the index-grid sparse tensors of
+// nb_encoder.hip.
+//
+//   y = relu(gamma * xhat + beta),  xhat = (x - mean) * invstd,  x[r] = sum_o in[nbr(r, o)] @ W[o]
+//
+//   nb_enc_bn_relu_bwd   g = dy (.) [y > 0];  dgamma = sum g xhat;  dbeta = sum g;
+//                        dx = invstd gamma (g - mean(g) - xhat mean(g xhat))          (batch statistics, train())
+//   nb_enc_conv_bwd_input   d in[q] = sum_o dx[r(q, o)] @ W[o]^T     (gather form: r(q,o) is the output row whose
+//                        receptive field holds q under offset o; stride 1: u = p + 1 - k, stride 2: u = (p + 1 - k) / 2)
+//   nb_enc_conv_bwd_weight  dW[o] = sum_r in[nbr(r, o)]^T (x) dx[r]   (MFMA over row chunks, fp32 atomics into dW)
+//   nb_enc_scatter_codes_bwd  d c.weight[vertex of row r] = d rows[r]  (Embedding lookup backward, :33-34)
+#include "nb_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define NB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+struct Dims {
+    int d, h, w;
+};
+
+__host__ __device__ constexpr int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// ------------------------------------------------------------------ BatchNorm + ReLU backward
+__global__ void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+                                     const int *__restrict__ n_rows, int C, const float *__restrict__ batch_stats,
+                                     float eps, double *__restrict__ sums) {
+    // block = 256 threads = 4 row lanes x 64 channels; grid.x over channel groups, grid.y over row slabs
+    __shared__ double pa[4][64], pb[4][64];
+    const int n = *n_rows;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    const long long per = ((long long)n + gridDim.y - 1) / gridDim.y;
+    const long long r0 = (long long)blockIdx.y * per, r1 = min((long long)n, r0 + per);
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        const double mean = batch_stats[c], invstd = 1.0 / sqrt((double)batch_stats[C + c] + (double)eps);
+        for (long long r = r0 + w; r < r1; r += 4) {
+            const float g = y[r * C + c] > 0.f ? dy[r * C + c] : 0.f;
+            a += (double)g;
+            b += (double)g * (((double)x[r * C + c] - mean) * invstd);
+        }
+    }
+    pa[w][threadIdx.x & 63] = a;
+    pb[w][threadIdx.x & 63] = b;
+    __syncthreads();
+    if (w == 0 && c < C) {
+        const int t = threadIdx.x;
+        atomicAdd(&sums[c], pa[0][t] + pa[1][t] + pa[2][t] + pa[3][t]);
+        atomicAdd(&sums[C + c], pb[0][t] + pb[1][t] + pb[2][t] + pb[3][t]);
+    }
+}
+
+__global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
+                                    const int *__restrict__ n_rows, int C, const float *__restrict__ batch_stats, float eps,
+                                    const float *__restrict__ gamma, const double *__restrict__ sums,
+                                    float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *n_rows;
+    if (idx < C) {
+        dgamma[idx] = (float)sums[C + idx];
+        dbeta[idx] = (float)sums[idx];
+    }
+    if (idx >= (long long)n * C) return;
+    const int c = (int)(idx % C);
+    const double mean = batch_stats[c], invstd = 1.0 / sqrt((double)batch_stats[C + c] + (double)eps);
+    const double xhat = ((double)x[idx] - mean) * invstd;
+    const double g = y[idx] > 0.f ? (double)dy[idx] : 0.0;
+    dx[idx] = (float)(invstd * (double)gamma[c] * (g - sums[c] / n - xhat * sums[C + c] / n));
+}
+
+// ------------------------------------------------------------------ conv backward w.r.t. the input rows
+// one wave = 32 INPUT rows x 32 input channels (blockIdx.y); K runs over the Cout channels of dx
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_bwd_in_kernel(const float *__restrict__ dx, const int *__restrict__ out_grid,
+                                                          Dims go, const int *__restrict__ in_lin,
+                                                          const int *__restrict__ n_in, Dims gi, int stride,
+                                                          const float *__restrict__ weight, float *__restrict__ din) {
+    constexpr int HALF = COUT / 2;
+    const int ct = blockIdx.y;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = *n_in;
+    const int row0 = wave * 32;
+    if (row0 >= n) return;
+    const int row = row0 + i;
+    const bool valid = row < n;
+    const int lin = valid ? in_lin[row] : 0;
+    const int x = lin % gi.w, y = (lin / gi.w) % gi.h, z = lin / (gi.w * gi.h);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int o = 0; o < 27; ++o) {
+        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+        // output voxel u with u * stride - 1 + k == p
+        const int nz = z + 1 - kd, ny = y + 1 - kh, nx = x + 1 - kw;
+        int nbr = -1;
+        bool ok = valid && nz >= 0 && ny >= 0 && nx >= 0;
+        int uz = nz, uy = ny, ux = nx;
+        if (stride == 2) {
+            ok = ok && !(nz & 1) && !(ny & 1) && !(nx & 1);
+            uz = nz >> 1;
+            uy = ny >> 1;
+            ux = nx >> 1;
+        }
+        if (ok && uz < go.d && uy < go.h && ux < go.w) nbr = out_grid[((long long)uz * go.h + uy) * go.w + ux];
+        if (!__any(nbr >= 0)) continue;
+        float A[HALF];
+        if (nbr >= 0) {
+            const f32x4 *p = reinterpret_cast<const f32x4 *>(dx + (size_t)nbr * COUT + hi * HALF);
+#pragma unroll
+            for (int q = 0; q < HALF / 4; ++q) {
+                const f32x4 v = p[q];
+                A[4 * q] = v.x;
+                A[4 * q + 1] = v.y;
+                A[4 * q + 2] = v.z;
+                A[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < HALF; ++c) A[c] = 0.f;
+        }
+        // B[k = co][j = ci] = W[o][ci][co]  (transposed read of the spconv-layout slab)
+        const int ci = ct * 32 + i;
+        const bool ciok = (CIN % 32 == 0) || ci < CIN;
+        const float *wo = weight + ((size_t)o * CIN + (ciok ? ci : 0)) * COUT + hi * HALF;
+#pragma unroll
+        for (int c = 0; c < HALF; ++c) {
+            const float b = ciok ? wo[c] : 0.f;
+            acc = NB_MFMA(A[c], b, acc);
+        }
+    }
+    const int ci = ct * 32 + i;
+    if ((CIN % 32 == 0) || ci < CIN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = row0 + tile_row(r, hi);
+            if (orow < n) din[(size_t)orow * CIN + ci] = acc[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ conv backward w.r.t. the weights
+// one wave = (offset o, ci tile, co tile, chunk of ROWS_PER_WAVE output rows); D[ci][co] += sum_rows in^T dx
+constexpr int ROWS_PER_WAVE = 256;
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float *__restrict__ in_rows, const int *__restrict__ in_grid,
+                                                         Dims gi, const int *__restrict__ out_lin,
+                                                         const int *__restrict__ n_out, Dims go, int stride,
+                                                         const float *__restrict__ dx, float *__restrict__ dw) {
+    constexpr int TI = (CIN + 31) / 32, TO = (COUT + 31) / 32;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);  // row chunk
+    const int o = blockIdx.y;                               // kernel offset 0..26
+    const int ti = blockIdx.z / TO, to = blockIdx.z % TO;
+    const int n = *n_out;
+    const int row0 = wave * ROWS_PER_WAVE;
+    if (row0 >= n) return;
+    const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+    const int ci = ti * 32 + i, co = to * 32 + i;
+    const bool ciok = (CIN % 32 == 0) || ci < CIN, cook = (COUT % 32 == 0) || co < COUT;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    bool any = false;
+    for (int m = 0; m < ROWS_PER_WAVE / 2; ++m) {
+        const int row = row0 + 2 * m + hi;  // this half-wave's row of the K=2 chunk
+        float a = 0.f, b = 0.f;
+        if (row < n) {
+            const int lin = out_lin[row];
+            const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
+            const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
+            if ((unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w) {
+                const int nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+                if (nbr >= 0) {
+                    if (ciok) a = in_rows[(size_t)nbr * CIN + ci];
+                    if (cook) b = dx[(size_t)row * COUT + co];
+                    any = true;
+                }
+            }
+        }
+        acc = NB_MFMA(a, b, acc);  // D[i = ci][j = co] += A[ci][k = row] B[k = row][co]
+    }
+    if (!__any(any)) return;
+    // D fragment: lane (j = co column, hi) holds rows ci_local = tile_row(r, hi)
+    if (cook) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cir = ti * 32 + tile_row(r, hi);
+            if ((CIN % 32 == 0) || cir < CIN) atomicAdd(&dw[((size_t)o * CIN + cir) * COUT + co], acc[r]);
+        }
+    }
+}
+
+__global__ void scatter_codes_bwd_kernel(const float *__restrict__ drows, const int *__restrict__ rows_vert,
+                                         const int *__restrict__ n_rows, int C, float *__restrict__ dcodes) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)(*n_rows) * C) return;
+    const int c = (int)(idx % C);
+    const long long r = idx / C;
+    dcodes[(size_t)rows_vert[r] * C + c] = drows[idx];  // one row per vertex at most: plain store into a zeroed buffer
+}
+
+}  // namespace
+
+extern "C" {
+
+int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const int32_t *n_rows, int32_t n_rows_max,
+                       int32_t c, const float *batch_stats, float eps, const float *gamma, double *sums, float *dx,
+                       float *dgamma, float *dbeta, void *stream) {
+    NB_REQUIRE(dy && y && x && n_rows && batch_stats && gamma && sums && dx && dgamma && dbeta,
+               "nb_enc_bn_relu_bwd: NULL pointer");
+    NB_REQUIRE(c > 0 && n_rows_max >= 0, "nb_enc_bn_relu_bwd: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    NB_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), st));
+    const int slabs = n_rows_max < 2048 ? 1 : (n_rows_max / 512 < 128 ? n_rows_max / 512 : 128);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb_ceil_div(c, 64), slabs), dim3(256), 0, st, dy, y, x, n_rows, c,
+                       batch_stats, eps, sums);
+    const long long total = (long long)n_rows_max * c;
+    const long long threads = total > c ? total : c;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, st, dy, y, x, n_rows, c,
+                       batch_stats, eps, gamma, sums, dx, dgamma, dbeta);
+    NB_CHECK_LAUNCH("nb_enc_bn_relu_bwd");
+    return NB_OK;
+}
+
+#define NB_FOR_CONV_SHAPES(X) X(16, 16) X(16, 32) X(32, 32) X(32, 64) X(64, 64) X(64, 128) X(128, 128)
+
+int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_t out_dhw[3], const int32_t *in_lin,
+                          const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3], int32_t stride,
+                          const float *weight, int32_t cin, int32_t cout, float *din, void *stream) {
+    NB_REQUIRE(dx && out_grid && out_dhw && in_lin && n_in && in_dhw && weight && din, "nb_enc_conv_bwd_input: NULL pointer");
+    NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv_bwd_input: stride %d", stride);
+    if (n_in_max <= 0) return NB_OK;
+    const Dims go = {out_dhw[0], out_dhw[1], out_dhw[2]}, gi = {in_dhw[0], in_dhw[1], in_dhw[2]};
+    hipStream_t st = (hipStream_t)stream;
+#define X(CI, CO)                                                                                                     \
+    if (cin == CI && cout == CO) {                                                                                    \
+        hipLaunchKernelGGL((conv_bwd_in_kernel<CI, CO>), dim3(nb_ceil_div(n_in_max, 128), (CI + 31) / 32), dim3(256), 0, \
+                           st, dx, out_grid, go, in_lin, n_in, gi, stride, weight, din);                              \
+        NB_CHECK_LAUNCH("nb_enc_conv_bwd_input");                                                                     \
+        return NB_OK;                                                                                                 \
+    }
+    NB_FOR_CONV_SHAPES(X)
+#undef X
+    nb_set_error("nb_enc_conv_bwd_input: unsupported channel pair %d -> %d", cin, cout);
+    return NB_EINVAL;
+}
+
+int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3], const int32_t *out_lin,
+                           const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride,
+                           const float *dx, int32_t cin, int32_t cout, float *dweight, void *stream) {
+    NB_REQUIRE(in_rows && in_grid && in_dhw && out_lin && n_out && out_dhw && dx && dweight,
+               "nb_enc_conv_bwd_weight: NULL pointer");
+    NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv_bwd_weight: stride %d", stride);
+    hipStream_t st = (hipStream_t)stream;
+    NB_HIP(hipMemsetAsync(dweight, 0, (size_t)27 * cin * cout * sizeof(float), st));
+    if (n_out_max <= 0) return NB_OK;
+    const Dims go = {out_dhw[0], out_dhw[1], out_dhw[2]}, gi = {in_dhw[0], in_dhw[1], in_dhw[2]};
+#define X(CI, CO)                                                                                                     \
+    if (cin == CI && cout == CO) {                                                                                    \
+        hipLaunchKernelGGL((conv_bwd_w_kernel<CI, CO>),                                                               \
+                           dim3(nb_ceil_div(n_out_max, 4 * ROWS_PER_WAVE), 27, ((CI + 31) / 32) * ((CO + 31) / 32)),  \
+                           dim3(256), 0, st, in_rows, in_grid, gi, out_lin, n_out, go, stride, dx, dweight);          \
+        NB_CHECK_LAUNCH("nb_enc_conv_bwd_weight");                                                                    \
+        return NB_OK;                                                                                                 \
+    }
+    NB_FOR_CONV_SHAPES(X)
+#undef X
+    nb_set_error("nb_enc_conv_bwd_weight: unsupported channel pair %d -> %d", cin, cout);
+    return NB_EINVAL;
+}
+
+int nb_enc_scatter_codes_bwd(const float *drows, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,
+                             int32_t c, float *dcodes, void *stream) {
+    NB_REQUIRE(drows && rows_vert && n_rows && dcodes, "nb_enc_scatter_codes_bwd: NULL pointer");
+    if (n_rows_max <= 0) return NB_OK;
+    hipLaunchKernelGGL(scatter_codes_bwd_kernel, dim3(nb_ceil_div((long long)n_rows_max * c, 256)), dim3(256), 0,
+                       (hipStream_t)stream, drows, rows_vert, n_rows, c, dcodes);
+    NB_CHECK_LAUNCH("nb_enc_scatter_codes_bwd");
+    return NB_OK;
+}
+
+}  // extern "C"

@@ -64,13 +64,17 @@ class SparseConvNet(nn.Module):
         for name, cin, cout, n, stride in ENCODER_BLOCKS:
             setattr(self, name, _block(cin, cout, n, stride))
 
-    def forward(self, codes, coord, out_sh, training):
-        """codes [6890,16] fp32, coord [6890,3] int32 (d,h,w) -> 4 channels-last volumes [D,H,W,C]."""
+    def forward(self, codes, coord, out_sh, training, save=None):
+        """codes [6890,16] fp32, coord [6890,3] int32 (d,h,w) -> 4 channels-last volumes [D,H,W,C].
+        save: optional list that receives one record per conv+BN+ReLU layer (index structures, raw and activated
+        rows, batch statistics) — everything neuralbody_amd.training.encoder_backward needs."""
         dev = codes.device
         dhw = [int(s) for s in out_sh]
         grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw)
         n_max = coord.shape[0]
         rows = ops.enc_gather_codes(codes, rows_vert, n_rows, n_max)
+        if save is not None:
+            save.append({"rows_vert": rows_vert, "n_rows": n_rows, "n_max": n_max})
         volumes = []
         bn_updates = []
         for name, cin, cout, n, stride in ENCODER_BLOCKS:
@@ -87,9 +91,17 @@ class SparseConvNet(nn.Module):
                 if name in DENSE_AFTER and j == n - 1:
                     dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
                     volumes.append(dense)
-                ops.enc_bn_relu(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
-                                bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
-                                momentum=bn.momentum if training else -1.0)  # running stats updated in-kernel
+                act = torch.empty_like(new_rows) if save is not None else None  # keep the raw conv output when saving
+                bstats = ops.enc_bn_relu(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
+                                         bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
+                                         momentum=bn.momentum if training else -1.0,  # running stats updated in-kernel
+                                         rows_out=act)
+                if save is not None:
+                    save.append({"conv": conv, "bn": bn, "stride": stride, "in_rows": rows, "in_grid": grid, "in_dhw": dhw,
+                                 "in_lin": rows_lin, "n_in": n_rows, "n_in_max": n_max, "out_grid": out_grid,
+                                 "out_lin": out_lin, "n_out": n_out, "n_out_max": n_out_max, "out_dhw": out_dhw,
+                                 "x": new_rows, "y": act, "bstats": bstats, "level": len(volumes) - 1 if dense is not None else None})
+                    new_rows = act
                 if training:
                     bn_updates.append(bn.num_batches_tracked)
                 rows, grid, rows_lin, n_rows, n_max, dhw = new_rows, out_grid, out_lin, n_out, n_out_max, out_dhw
@@ -182,7 +194,7 @@ class Network(nn.Module):
         return ops.make_scene(vols, R[0], Th, bmin, self.voxel_size, out_sh)
 
     # ------------------------------------------------------------------ reference API
-    def encode_sparse_voxels(self, sp_input):
+    def encode_sparse_voxels(self, sp_input, save=None):
         coord = sp_input["coord"]
         if int(sp_input.get("batch_size", 1)) != 1:
             raise NotImplementedError("batch size 1 only")
@@ -190,7 +202,7 @@ class Network(nn.Module):
             coord = coord[:, 1:]
         coord = coord.reshape(-1, 3).to(torch.int32).contiguous()
         codes = self.c.weight.detach()
-        vols = self.xyzc_net(codes, coord, sp_input["out_sh"], self.training)
+        vols = self.xyzc_net(codes, coord, sp_input["out_sh"], self.training, save)
         # logical layout [1,C,D,H,W] like spconv's .dense(); storage stays channels-last
         return [v.permute(3, 0, 1, 2)[None] for v in vols]
 

@@ -257,7 +257,7 @@ def enc_conv(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, strid
 
 
 def enc_bn_relu(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, running_var, training, eps,
-                rows_lin=None, dense=None, momentum=-1.0):
+                rows_lin=None, dense=None, momentum=-1.0, rows_out=None):
     """nb_enc_bn_relu (in place on rows) -> batch_stats [2C+1] = mean | biased var | n_rows.
     momentum >= 0 (training only): running_mean / running_var are updated in place by the kernel."""
     c = int(rows.shape[1])
@@ -269,11 +269,13 @@ def enc_bn_relu(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, runn
     if dense is not None:
         _req(dense, torch.float32, (None, None, None, c), "dense")
         _req(rows_lin, torch.int32, (None,), "rows_lin")
+    if rows_out is not None:
+        _req(rows_out, torch.float32, tuple(rows.shape), "rows_out")
     batch_stats = torch.empty(2 * c + 1, dtype=torch.float32, device=rows.device)
     check(_lib.lib().nb_enc_bn_relu(ptr(rows), ptr(n_rows), int(n_rows_max), c, ptr(stats), ptr(gamma), ptr(beta),
                                     ptr(running_mean), ptr(running_var), 1 if training else 0, float(eps),
-                                    float(momentum), ptr(batch_stats), ptr(rows_lin), ptr(dense), _stream()),
-          "nb_enc_bn_relu")
+                                    float(momentum), ptr(batch_stats), ptr(rows_lin), ptr(dense), ptr(rows_out),
+                                    _stream()), "nb_enc_bn_relu")
     return batch_stats
 
 
@@ -401,3 +403,51 @@ def trilinear_bwd(scene, grids, drows, wpts, d_feat):
         d4[l] = drows[l].data_ptr()
     check(_lib.lib().nb_trilinear_bwd(C.byref(sc), g4, d4, ptr(wpts), ptr(d_feat), n, _stream()), "nb_trilinear_bwd")
     return drows
+
+
+def enc_bn_relu_bwd(dy, y, x, n_rows, n_rows_max, batch_stats, eps, gamma):
+    """nb_enc_bn_relu_bwd -> (dx, dgamma, dbeta)."""
+    c = int(x.shape[1])
+    for t, nm in ((dy, "dy"), (y, "y"), (x, "x")):
+        _req(t, torch.float32, (None, c), nm)
+    _req(batch_stats, torch.float32, (2 * c + 1,), "batch_stats")
+    _req(gamma, torch.float32, (c,), "gamma")
+    dev = x.device
+    sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    check(_lib.lib().nb_enc_bn_relu_bwd(ptr(dy), ptr(y), ptr(x), ptr(n_rows), int(n_rows_max), c, ptr(batch_stats),
+                                        float(eps), ptr(gamma), ptr(sums), ptr(dx), ptr(dgamma), ptr(dbeta), _stream()),
+          "nb_enc_bn_relu_bwd")
+    return dx, dgamma, dbeta
+
+
+def enc_conv_bwd_input(dx, out_grid, out_dhw, in_lin, n_in, n_in_max, in_dhw, stride, weight):
+    cin, cout = int(weight.shape[3]), int(weight.shape[4])
+    _req(dx, torch.float32, (None, cout), "dx")
+    _req(out_grid, torch.int32, tuple(int(s) for s in out_dhw), "out_grid")
+    _req(in_lin, torch.int32, (None,), "in_lin")
+    din = torch.zeros((max(int(n_in_max), 1), cin), dtype=torch.float32, device=dx.device)
+    check(_lib.lib().nb_enc_conv_bwd_input(ptr(dx), ptr(out_grid), _i3(out_dhw), ptr(in_lin), ptr(n_in), int(n_in_max),
+                                           _i3(in_dhw), int(stride), ptr(weight), cin, cout, ptr(din), _stream()),
+          "nb_enc_conv_bwd_input")
+    return din
+
+
+def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, dx, cin, cout):
+    _req(in_rows, torch.float32, (None, cin), "in_rows")
+    _req(dx, torch.float32, (None, cout), "dx")
+    dw = torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=dx.device)
+    check(_lib.lib().nb_enc_conv_bwd_weight(ptr(in_rows), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out),
+                                            int(n_out_max), _i3(out_dhw), int(stride), ptr(dx), cin, cout, ptr(dw),
+                                            _stream()), "nb_enc_conv_bwd_weight")
+    return dw
+
+
+def enc_scatter_codes_bwd(drows, rows_vert, n_rows, n_rows_max, n_codes):
+    c = int(drows.shape[1])
+    dcodes = torch.zeros((n_codes, c), dtype=torch.float32, device=drows.device)
+    check(_lib.lib().nb_enc_scatter_codes_bwd(ptr(drows), ptr(rows_vert), ptr(n_rows), int(n_rows_max), c, ptr(dcodes),
+                                              _stream()), "nb_enc_scatter_codes_bwd")
+    return dcodes

@@ -1,7 +1,8 @@
 """trainer_path plugin: `NetworkWrapper(net)` with the reference's forward contract
 (lib/train/trainers/if_nerf_clight.py:8-37): returns (ret, loss, scalar_stats, image_stats) with the
-masked MSE of rgb_map against batch['rgb'].  The forward pass is the fused HIP march; a HIP
-backward is not part of this build yet, so the loss carries no grad (evaluation / validation use)."""
+masked MSE of rgb_map against batch['rgb'].  Under torch.enable_grad() with trainable parameters
+Renderer.render takes the differentiable HIP path (neuralbody_amd/training.py), so loss.backward() fills the
+gradients of every parameter; under no_grad it is the fused inference march."""
 import os
 import sys
 

@@ -97,6 +97,13 @@ class Renderer:
         n_batch, n_pixel = ray_o.shape[:2]
         if n_batch != 1:
             raise NotImplementedError("batch size 1 only (every shipped config renders/trains with batch 1)")
+        if torch.is_grad_enabled() and ray_range is None and any(p.requires_grad for p in self.net.parameters()):
+            # training step (lib/train/trainers/if_nerf_clight.py:18-36): differentiable HIP path
+            from . import training
+
+            if self.cfg.perturb > 0.0 and self.net.training and t_rand is None:
+                t_rand = torch.rand((n_batch, n_pixel, self.cfg.N_samples), device=ray_o.device)
+            return training.render_train(self, batch, t_rand)
         sp_input = self.prepare_sp_input(batch)
         feature_volume = self.net.encode_sparse_voxels(sp_input)
         b, e = (0, n_pixel) if ray_range is None else ray_range

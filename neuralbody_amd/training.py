@@ -70,3 +70,111 @@ def decoder_backward(net, tap, d_raw, latent_index):
         g[name + ".bias"] = ops.colsum(dh)
         dh = ops.sgemm(dh, W)
     return g, dh  # dh is now dF [N,352]
+
+
+def encoder_backward(xyzc_net, ctx, drows_dense):
+    """Backward of SparseConvNet.forward(save=ctx).  drows_dense[l] [n_rows_l, C_l]: gradient w.r.t. the active rows of
+    dense level l (from nb_trilinear_bwd).  Returns (grads, dcodes): grads maps `xyzc_net.<block>.<k>.weight|bias` to
+    gradient tensors, dcodes is the gradient of the 6890 x 16 vertex codes."""
+    head, layers = ctx[0], ctx[1:]
+    names = {}
+    for bname, cin, cout, n, stride in _blocks():
+        block = getattr(xyzc_net, bname)
+        for j in range(n):
+            names[id(block[3 * j])] = "xyzc_net.%s.%d" % (bname, 3 * j)
+            names[id(block[3 * j + 1])] = "xyzc_net.%s.%d" % (bname, 3 * j + 1)
+    g = {}
+    dy = None
+    for rec in reversed(layers):
+        y, x = rec["y"], rec["x"]
+        if rec["level"] is not None:
+            d = drows_dense[rec["level"]]
+            dy = d if dy is None else dy.add_(d)
+        if dy is None:
+            raise RuntimeError("no gradient reaches the last encoder layer")
+        conv, bn = rec["conv"], rec["bn"]
+        dx, dgamma, dbeta = ops.enc_bn_relu_bwd(dy, y, x, rec["n_out"], rec["n_out_max"], rec["bstats"], bn.eps,
+                                                bn.weight.detach())
+        g[names[id(bn)] + ".weight"] = dgamma
+        g[names[id(bn)] + ".bias"] = dbeta
+        w = conv.weight.detach()
+        cin, cout = int(w.shape[3]), int(w.shape[4])
+        g[names[id(conv)] + ".weight"] = ops.enc_conv_bwd_weight(rec["in_rows"], rec["in_grid"], rec["in_dhw"], rec["out_lin"],
+                                                               rec["n_out"], rec["n_out_max"], rec["out_dhw"], rec["stride"],
+                                                               dx, cin, cout)
+        dy = ops.enc_conv_bwd_input(dx, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
+                                    rec["in_dhw"], rec["stride"], w)
+    dcodes = ops.enc_scatter_codes_bwd(dy, head["rows_vert"], head["n_rows"], head["n_max"], 6890)
+    return g, dcodes
+
+
+def _blocks():
+    from .network import ENCODER_BLOCKS
+
+    return ENCODER_BLOCKS
+
+
+class RenderFunction(torch.autograd.Function):
+    """Differentiable Renderer.render for the training step (lib/train/trainers/if_nerf_clight.py:18-36): forward and
+    backward are both the HIP path; autograd only carries d rgb_map in and the parameter gradients out."""
+
+    @staticmethod
+    def forward(ctx, renderer, batch, t_rand, *params):
+        net, cfg = renderer.net, renderer.cfg
+        sp_input = renderer.prepare_sp_input(batch)
+        enc_ctx = []
+        with torch.no_grad():
+            vols = net.encode_sparse_voxels(sp_input, save=enc_ctx)
+            ray_o, ray_d, near, far = batch["ray_o"], batch["ray_d"], batch["near"], batch["far"]
+            wpts, z_vals = renderer.get_sampling_points(ray_o, ray_d, near, far, t_rand)
+            n_batch, n_pixel, S = wpts.shape[:3]
+            viewdir = ray_d / torch.norm(ray_d, dim=2, keepdim=True)
+            w = wpts.reshape(-1, 3).float().contiguous()
+            v = viewdir[:, :, None].expand(n_batch, n_pixel, S, 3).reshape(-1, 3).float().contiguous()
+            scene = net.make_scene(vols, sp_input)
+            lb = net.latent_bias(sp_input["latent_index"])
+            raw, tap = ops.decode_points(scene, net.packed_weights(), lb, w, v, debug=True, precision="f32")
+            z = z_vals.reshape(-1, S).float().contiguous()
+            rd = ray_d.reshape(-1, 3).float().contiguous()
+            rgb, disp, acc, weights, depth = ops.composite(raw.view(-1, S, 4), z, rd, cfg.white_bkgd)
+        ctx.renderer, ctx.sp_input, ctx.enc_ctx, ctx.scene = renderer, sp_input, enc_ctx, scene
+        ctx.saved = (raw, tap, z, rd, w)
+        ctx.n_params = len(params)
+        ctx.mark_non_differentiable(disp, acc, weights, depth)
+        return (rgb.view(n_batch, n_pixel, 3), disp.view(n_batch, n_pixel), acc.view(n_batch, n_pixel),
+                weights.view(n_batch, n_pixel, S), depth.view(n_batch, n_pixel))
+
+    @staticmethod
+    def backward(ctx, d_rgb, *_unused):
+        renderer = ctx.renderer
+        net, cfg = renderer.net, renderer.cfg
+        raw, tap, z, rd, w = ctx.saved
+        S = z.shape[1]
+        d_raw = ops.composite_bwd(raw.view(-1, S, 4), z, rd, d_rgb.reshape(-1, 3).float().contiguous(), cfg.white_bkgd)
+        li = ctx.sp_input["latent_index"]
+        g, dF = decoder_backward(net, tap, d_raw.view(-1, 4), li)
+        layers = ctx.enc_ctx[1:]
+        dense = [rec for rec in layers if rec["level"] is not None]
+        grids = [rec["out_grid"] for rec in dense]
+        drows = [torch.zeros((rec["n_out_max"] if rec["n_out_max"] > 0 else 1, rec["y"].shape[1]), dtype=torch.float32,
+                             device=w.device) for rec in dense]
+        ops.trilinear_bwd(ctx.scene, grids, drows, w, dF)
+        ge, dcodes = encoder_backward(net.xyzc_net, ctx.enc_ctx, drows)
+        g.update(ge)
+        g["c.weight"] = dcodes
+        glat = torch.zeros_like(net.latent.weight)
+        glat.index_copy_(0, li.reshape(-1)[:1].long(), g.pop("latent.row")[None])
+        g["latent.weight"] = glat
+        out = []
+        for name, p in net.named_parameters():
+            gr = g.get(name)
+            out.append(None if gr is None else gr.reshape(p.shape))
+        assert len(out) == ctx.n_params
+        return (None, None, None) + tuple(out)
+
+
+def render_train(renderer, batch, t_rand=None):
+    """Renderer.render with gradients: same output dict, rgb_map carries the autograd graph."""
+    params = [p for _, p in renderer.net.named_parameters()]
+    rgb, disp, acc, weights, depth = RenderFunction.apply(renderer, batch, t_rand, *params)
+    return {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": weights, "depth_map": depth}
