@@ -236,3 +236,61 @@ def test_full_training_step_gradients_match_autograd():
         e = _rel(p.grad.cpu().numpy(), ref.numpy().reshape(p.shape), tol, "grad " + name)
         worst[group] = max(worst.get(group, 0.0), e)
     print("worst relative gradient error per group:", {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_network_wrapper_training_steps_reduce_loss():
+    """The trainer-facing contract (lib/train/trainers/if_nerf_clight.py:18-36 + lib/train/trainers/trainer.py:46-53):
+    NetworkWrapper(batch) -> (ret, loss, scalar_stats, image_stats); loss.backward(); clip_grad_value_(40); Adam step.
+    A few steps on one synthetic batch must reduce the loss, every parameter must receive a finite gradient, and BN
+    running statistics must advance once per forward."""
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    from neuralbody_amd import synthetic as syn
+
+    # the plugin imports the reference's `lib.config.cfg`; stand in for it (the GPU box has no reference tree)
+    cfgmod = types.ModuleType("lib.config")
+    cfgmod.cfg = types.SimpleNamespace(N_samples=64, perturb=1.0, raw_noise_std=0.0, white_bkgd=False, H=512, W=512, ratio=1.0)
+    saved = {k: sys.modules.get(k) for k in ("lib", "lib.config")}
+    sys.modules["lib"] = types.ModuleType("lib")
+    sys.modules["lib.config"] = cfgmod
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("nb_plugin_trainer", os.path.join(root, "neuralbody_amd", "plugins", "if_nerf_clight.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+    sd = syn.make_weights(0, num_train_frame=5)
+    body = syn.make_body(seed=0, box=(0.3, 0.5, 0.2))
+    K, R, T = syn.make_camera(body, 64, 64, focal_factor=2.5, distance=1.5)
+    ro, rd, near, far, mask = syn.host_image_rays(64, 64, K, R, T, body["can_bounds"])
+    rs = np.random.RandomState(0)
+    pick = rs.choice(ro.shape[0], 1024, replace=False)  # N_rand = 1024 random rays (latent_xyzc_313.yaml:66)
+    batch = syn.make_batch(body, ro[pick], rd[pick], near[pick], far[pick], np.ones(1024, bool), latent_index=2)
+    batch["rgb"] = rs.uniform(0, 1, (1, 1024, 3)).astype(np.float32)
+    bd = H.device_batch(batch, DEV)
+    net = H.make_network(sd, DEV, True, "f32")
+    wrapper = mod.NetworkWrapper(net)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    losses = []
+    for it in range(6):
+        ret, loss, stats, image_stats = wrapper(bd)
+        assert set(stats) == {"img_loss", "loss"} and ret["rgb_map"].shape == (1, 1024, 3)
+        opt.zero_grad()
+        loss.mean().backward()
+        for name, p in net.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        torch.nn.utils.clip_grad_value_(net.parameters(), 40)
+        opt.step()
+        losses.append(float(loss))
+    print("training losses:", ["%.5f" % l for l in losses])
+    assert losses[-1] < losses[0], losses
+    assert int(net.xyzc_net.conv0[1].num_batches_tracked) == 6
