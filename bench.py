@@ -112,6 +112,47 @@ def cpu_baseline(sd, bd, vols, n_samples, budget_s=12.0, max_rays=8192):
                       % (done, n_samples, t_total, torch.__version__, best)}
 
 
+def train_bench(args, dev):
+    """Config 4 of BASELINE.json in synthetic form: one training step = NetworkWrapper-style forward (1024 random rays x
+    64 jittered samples of the 6890-vertex scene) + MSE loss + backward through decoder and encoder + clip + Adam.
+    Informational (the headline metric is the render throughput): prints its own JSON line."""
+    from neuralbody_amd import synthetic as syn
+
+    sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, "f32")
+    rend.cfg.perturb = 1.0
+    g = torch.Generator(device="cpu").manual_seed(0)
+    pick = torch.randperm(n_rays, generator=g)[:1024].to(dev)
+    tb = dict(bd)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        tb[k] = bd[k][:, pick].contiguous()
+    tb["mask_at_box"] = torch.ones((1, 1024), dtype=torch.bool, device=dev)
+    target = torch.rand((1, 1024, 3), generator=g).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+
+    def step():
+        out = rend.render(tb)
+        loss = torch.mean((out["rgb_map"] - target) ** 2)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_value_(net.parameters(), 40)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"metric": "train_step_ms", "value": dt * 1e3, "unit": "ms", "higher_is_better": False, "n_gpus": 1,
+                      "steps": args.steps, "warmup": args.warmup, "rays_per_step": 1024, "samples_per_ray": args.samples,
+                      "ray_samples_per_sec": 1024 * args.samples / dt, "final_loss": float(loss.detach()),
+                      "config": {"workload": "synthetic training step: 1024 random rays, forward + backward (decoder via rocBLAS "
+                                             "GEMMs + HIP kernels, encoder HIP kernels) + clip_grad_value_(40) + Adam"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,6 +162,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
+    ap.add_argument("--mode", default="render", choices=["render", "train"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +184,11 @@ def main():
     from neuralbody_amd import ops
     from neuralbody_amd.parallel import all_gather_tiles
 
+    if args.mode == "train":
+        if world != 1:
+            raise SystemExit("--mode train is a single-GPU informational run")
+        train_bench(args, dev)
+        return
     H = W = args.size
     sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
     S = args.samples

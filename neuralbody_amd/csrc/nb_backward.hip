@@ -135,6 +135,49 @@ __global__ void trilinear_bwd_kernel(TriArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ C[m,n] += A^T B over many rows (weight gradients)
+// dW = dY^T X has M, N <= 384 but K = rays x samples (65 536 per training step): rocBLAS picks a single-pass macro
+// tile for it (1.8 ms per GEMM measured).  Split the row range instead: every wave owns (a 256-row chunk, a 32x32 tile
+// of C), accumulates it with v_mfma_f32_32x32x2_f32 (one row pair per MFMA) and adds it to C with fp32 atomics.
+constexpr int TN_ROWS = 256;
+typedef float f32x16_ __attribute__((ext_vector_type(16)));
+__host__ __device__ constexpr int tn_tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                      int ldb, long long R, int M, int N, float alpha,
+                                                      float *__restrict__ C, int ldc) {
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * TN_ROWS;
+    if (row0 >= R) return;
+    const int am = blockIdx.y * 32 + i, bn = blockIdx.z * 32 + i;
+    const bool aok = am < M, bok = bn < N;
+    f32x16_ acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int m = 0; m < TN_ROWS / 2; ++m) {
+        const long long row = row0 + 2 * m + hi;
+        const bool rok = row < R;
+        const float a = (rok && aok) ? A[row * lda + am] : 0.f;
+        const float b = (rok && bok) ? B[row * ldb + bn] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    if (bok) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cm = blockIdx.y * 32 + tn_tile_row(r, hi);
+            if (cm < M) atomicAdd(&C[(size_t)cm * ldc + bn], alpha * acc[r]);
+        }
+    }
+}
+
+__global__ void scale_matrix_kernel(float *__restrict__ C, int m, int n, int ldc, float beta) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)m * n) return;
+    float *p = C + (idx / n) * ldc + idx % n;
+    *p = beta == 0.f ? 0.f : *p * beta;
+}
+
 rocblas_handle g_handle = nullptr;
 
 }  // namespace
@@ -157,6 +200,16 @@ int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float al
              const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream) {
     NB_REQUIRE(a && b && c && m >= 0 && n >= 0 && k >= 0, "nb_sgemm: bad argument");
     if (m == 0 || n == 0) return NB_OK;
+    if (trans_a && !trans_b && k >= 4096 && m <= 512 && n <= 512) {
+        // weight-gradient shape: split the long K (row) dimension across waves (gemm_tn_kernel)
+        hipStream_t st = (hipStream_t)stream;
+        if (beta != 1.f)
+            hipLaunchKernelGGL(scale_matrix_kernel, dim3(nb_ceil_div((long long)m * n, 256)), dim3(256), 0, st, c, m, n, ldc, beta);
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(nb_ceil_div(k, 4 * TN_ROWS), nb_ceil_div(m, 32), nb_ceil_div(n, 32)), dim3(256),
+                           0, st, a, lda, b, ldb, (long long)k, m, n, alpha, c, ldc);
+        NB_CHECK_LAUNCH("gemm_tn_kernel");
+        return NB_OK;
+    }
     if (!g_handle) {
         if (rocblas_create_handle(&g_handle) != rocblas_status_success) {
             nb_set_error("nb_sgemm: rocblas_create_handle failed");

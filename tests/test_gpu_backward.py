@@ -63,6 +63,15 @@ def test_sgemm_relu_colsum():
     ops.sgemm(wide[:, 5:45], b, out=out[:, 10:43], alpha=2.0, beta=1.0)
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(ops.colsum(wide[:, 7:90]).cpu().numpy(), wide[:, 7:90].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-3)
+    # long-K transposed products take the split-K MFMA path (weight-gradient shape), incl. slices and accumulation
+    big_a = torch.from_numpy(rs.standard_normal((9000, 70)).astype(np.float32)).to(DEV)
+    big_b = torch.from_numpy(rs.standard_normal((9000, 45)).astype(np.float32)).to(DEV)
+    ref = (big_a[:, 3:68].double().T @ big_b[:, 2:43].double()).float()
+    np.testing.assert_allclose(ops.sgemm(big_a[:, 3:68], big_b[:, 2:43], trans_a=True).cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-3)
+    acc = torch.full((65, 50), 0.5, device=DEV)
+    ops.sgemm(big_a[:, 3:68], big_b[:, 2:43], trans_a=True, out=acc[:, 4:45], alpha=2.0, beta=1.0)
+    np.testing.assert_allclose(acc[:, 4:45].cpu().numpy(), (0.5 + 2.0 * ref).cpu().numpy(), rtol=2e-4, atol=4e-3)
+    assert float(acc[:, :4].min()) == 0.5 and float(acc[:, 45:].max()) == 0.5
     y = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
     dy = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
     ref = torch.where(y > 0, dy, torch.zeros_like(dy))
