@@ -120,8 +120,43 @@ def run_raygen():
     print("raygen ->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_train_step():
+    """One training step of the UNMODIFIED reference (NetworkWrapper, lib/train/trainers/if_nerf_clight.py:18-36) on CPU:
+    loss and, for every parameter, the gradient's L2 norm, sum and a few probe entries."""
+    ns = rh.load()
+    r, sd, batch, t_rand = scenes.build_train()
+    cfg = ns.cfg
+    cfg.N_samples, cfg.white_bkgd, cfg.perturb, cfg.raw_noise_std = r["n_samples"], False, 1.0, 0.0
+    net = rh.make_reference_network(sd, train_mode=True)
+    wrapper = ns.NetworkWrapper(net)
+    tb = rh.torch_batch(batch)
+    real_rand = torch.rand
+    tr = torch.from_numpy(t_rand)
+    torch.rand = lambda *a, **k: tr  # if_clight_renderer.py:22
+    try:
+        ret, loss, stats, _ = wrapper(tb)
+        loss.backward()
+    finally:
+        torch.rand = real_rand
+    g = {"loss": np.array(float(loss)), "rgb_map": ret["rgb_map"].detach().numpy()}
+    for name, p in net.named_parameters():
+        gr = p.grad.detach().numpy().astype(np.float64)
+        g["norm/" + name] = np.array(np.sqrt((gr ** 2).sum()))
+        g["sum/" + name] = np.array(gr.sum())
+        g["probe/" + name] = gr.reshape(-1)[scenes.grad_probe_indices(gr.shape)]
+        g["max/" + name] = np.array(np.abs(gr).max())
+    path = os.path.join(OUT, "train_step.npz")
+    np.savez_compressed(path, **g)
+    print("train step: loss %.6f ->" % float(loss), path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen"]
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train"]
     for n in names:
-        run_raygen() if n == "raygen" else run_scene(n)
+        if n == "raygen":
+            run_raygen()
+        elif n == "train":
+            run_train_step()
+        else:
+            run_scene(n)

@@ -57,3 +57,31 @@ def probe_indices(mask_flat, n=N_PROBES, seed=123):
     a = act[rs.choice(len(act), n_act, replace=False)] if n_act else np.zeros(0, np.int64)
     b = rs.randint(0, mask_flat.size, n - n_act)
     return np.concatenate([a, b]).astype(np.int64)
+
+
+# training-step recipe: N_rand random rays of one frame, stratified jitter, MSE against `rgb`
+TRAIN = dict(weights_seed=4, num_train_frame=6, body=_SMALL_BODY, cam=dict(H=48, W=48, focal_factor=2.5, distance=1.5),
+             n_samples=64, n_rand=256, latent_index=4, weights_kw=dict(alpha_bias=0.0, alpha_scale=12.0))
+GRAD_PROBES = 6
+
+
+def build_train():
+    """-> (recipe, state_dict_np, batch_np incl. 'rgb' target and 'mask_at_box' over the sampled rays, t_rand)"""
+    r = TRAIN
+    sd = syn.make_weights(r["weights_seed"], num_train_frame=r["num_train_frame"], **r["weights_kw"])
+    body = syn.make_body(**r["body"])
+    c = r["cam"]
+    K, R, T = syn.make_camera(body, c["H"], c["W"], focal_factor=c["focal_factor"], distance=c["distance"])
+    ray_o, ray_d, near, far, mask = syn.host_image_rays(c["H"], c["W"], K, R, T, body["can_bounds"])
+    rs = np.random.RandomState(31)
+    pick = np.sort(rs.choice(ray_o.shape[0], r["n_rand"], replace=False))
+    batch = syn.make_batch(body, ray_o[pick], ray_d[pick], near[pick], far[pick], np.ones(r["n_rand"], bool),
+                           latent_index=r["latent_index"])
+    batch["rgb"] = rs.uniform(0, 1, (1, r["n_rand"], 3)).astype(np.float32)
+    t_rand = np.minimum(rs.uniform(0, 1, (1, r["n_rand"], r["n_samples"])).astype(np.float32), np.float32(1.0 - 2 ** -24))
+    return r, sd, batch, t_rand
+
+
+def grad_probe_indices(shape, n=GRAD_PROBES, seed=5):
+    size = int(np.prod(shape)) if len(shape) else 1
+    return np.random.RandomState(seed + size % 1000).randint(0, size, n)

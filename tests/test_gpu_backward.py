@@ -303,3 +303,31 @@ def test_network_wrapper_training_steps_reduce_loss():
     print("training losses:", ["%.5f" % l for l in losses])
     assert losses[-1] < losses[0], losses
     assert int(net.xyzc_net.conv0[1].num_batches_tracked) == 6
+
+
+def test_training_step_matches_reference_fixture():
+    """One training step (forward with the fixture's jitter, MSE loss, backward) against the gradients of the UNMODIFIED
+    reference (tests/golden/train_step.npz): loss to 1e-5, per-parameter gradient norms and probe entries to 2e-2 of
+    the tensor's largest gradient entry (fp32 ReLU-mask flips, see the tests above)."""
+    g = np.load(H.GOLDEN + "/train_step.npz")
+    r, sd, batch, t_rand = scenes.build_train()
+    net = H.make_network(sd, DEV, True, "f32")
+    rend = H.make_renderer(net, dict(n_samples=r["n_samples"], perturb=True, white_bkgd=False))
+    bd = H.device_batch(batch, DEV)
+    out = rend.render(bd, t_rand=torch.from_numpy(t_rand).to(DEV))
+    mask = bd["mask_at_box"]
+    loss = torch.mean((out["rgb_map"][mask] - bd["rgb"][mask]) ** 2)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5, (float(loss.detach()), float(g["loss"]))
+    H.assert_close(out["rgb_map"].detach().cpu().numpy(), g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    worst = 0.0
+    for name, p in net.named_parameters():
+        gr = p.grad.cpu().numpy().astype(np.float64)
+        scale = max(float(g["max/" + name]), 1e-30)
+        e1 = abs(np.sqrt((gr ** 2).sum()) - float(g["norm/" + name])) / max(float(g["norm/" + name]), 1e-30)
+        idx = scenes.grad_probe_indices(gr.shape)
+        e2 = np.abs(gr.reshape(-1)[idx] - g["probe/" + name]).max() / scale
+        worst = max(worst, e1, e2)
+        assert e1 <= 2e-2 and e2 <= 2e-2, (name, e1, e2)
+    print("training step vs reference fixture: worst relative deviation %.2e over %d tensors" % (worst, len(list(net.parameters()))))

@@ -84,3 +84,27 @@ def test_oracle_raygen_matches_reference_golden(golden_dir):
         np.testing.assert_array_equal(near, g[tag + "_img_near"])
         np.testing.assert_array_equal(far, g[tag + "_img_far"])
         np.testing.assert_array_equal(ro[0], g[tag + "_ray_o"])
+
+
+def test_oracle_autograd_matches_reference_training_step(golden_dir):
+    """The oracle under autograd against the gradients the UNMODIFIED reference produced for one training step
+    (tests/golden/train_step.npz, made by make_golden.py: NetworkWrapper on CPU): loss, and per parameter the
+    gradient norm, sum and probe entries."""
+    g = np.load(os.path.join(golden_dir, "train_step.npz"))
+    r, sd, batch, t_rand = scenes.build_train()
+    sdg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+           for k, v in orc.tensor_state_dict(sd).items()}
+    out = orc.render(sdg, batch, n_samples=r["n_samples"], training=True, t_rand=torch.from_numpy(t_rand))
+    mask = torch.from_numpy(batch["mask_at_box"])
+    loss = torch.mean((out["rgb_map"][mask] - torch.from_numpy(batch["rgb"])[mask]) ** 2)  # if_nerf_clight.py:25
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-6
+    _close(out["rgb_map"].detach().numpy(), g["rgb_map"], name="rgb_map")
+    names = [k[5:] for k in g.files if k.startswith("norm/")]
+    assert len(names) == 69  # 17 conv + 34 BN affine + 16 MLP + c + latent: every trainable tensor
+    for name in names:
+        gr = sdg[name].grad.numpy().astype(np.float64)
+        scale = max(float(g["max/" + name]), 1e-30)
+        assert abs(np.sqrt((gr ** 2).sum()) - float(g["norm/" + name])) <= 2e-3 * max(float(g["norm/" + name]), 1e-30), name
+        idx = scenes.grad_probe_indices(gr.shape)
+        assert np.abs(gr.reshape(-1)[idx] - g["probe/" + name]).max() <= 2e-3 * scale, name
