@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 6
+#define NB_ABI_VERSION 7
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -111,6 +111,25 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
                      float *raw_out, float *dbg, int precision, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * Optional sample culling of nb_march — replaces prepare_inside_pts of the mask-culled renderers
+ * (lib/networks/renderer/if_clight_renderer_mmsk.py:12-45, if_clight_renderer_msk.py:12-49): a sample
+ * is decoded only if it projects inside every one of n_views silhouettes; culled samples get raw = 0
+ * (if_clight_renderer_mmsk.py:54-59).  pre_affine != 0 (the _msk variant) first maps the point
+ * world -> SMPL space of the rendered pose (scene R, Th) -> world of the snapshot frame (R0, Th0).
+ * ------------------------------------------------------------------------------- */
+#define NB_MAX_CULL_VIEWS 4
+typedef struct nb_cull {
+    int32_t n_views;                       /* 1..NB_MAX_CULL_VIEWS */
+    int32_t H, W;                          /* mask size = int(cfg.H * cfg.ratio), int(cfg.W * cfg.ratio) */
+    int32_t pre_affine;
+    const uint8_t *msk[NB_MAX_CULL_VIEWS]; /* dev [H,W] uint8, non-zero = inside */
+    float RT[NB_MAX_CULL_VIEWS][12];       /* row-major 3x4 [R|T] (batch['RT']) */
+    float K[NB_MAX_CULL_VIEWS][9];         /* batch['Ks'] / batch['K'] */
+    float R0[9];                           /* batch['R0_snap'] */
+    float Th0[3];                          /* batch['Th0_snap'] */
+} nb_cull;
+
+/* ---------------------------------------------------------------------------------
  * nb_march — the fused per-ray path: replaces Renderer.get_pixel_value
  * (lib/networks/renderer/if_clight_renderer.py:62-92), i.e. get_sampling_points (:11-27),
  * get_density_color (:54-60), Network.calculate_density_color and raw2outputs
@@ -122,13 +141,14 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
  *   ray_order dev [n_rays] int32 permutation or NULL: lane slot i marches ray ray_order[i].  Results are
  *           written at the ray's own index, so this only changes WHICH rays share a wavefront (e.g. 8x4
  *           pixel tiles instead of row segments, for gather locality); outputs are bit-identical.
+ *   cull    HOST pointer to an nb_cull or NULL (no culling)
  *   outputs dev: rgb_map [n_rays,3], disp_map/acc_map/depth_map [n_rays],
  *           weights [n_rays,n_samples]; raw (optional, may be NULL) [n_rays,n_samples,4]
  * ------------------------------------------------------------------------------- */
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias,
              const float *ray_o, const float *ray_d, const float *near, const float *far,
              int64_t n_rays, int32_t n_samples, const float *t_vals, const float *t_rand,
-             const int32_t *ray_order, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
+             const int32_t *ray_order, const nb_cull *cull, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
              float *depth_map, float *raw, int precision, void *stream);
 
 /* ---------------------------------------------------------------------------------

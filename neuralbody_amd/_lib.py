@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
@@ -22,6 +22,17 @@ class NbScene(C.Structure):
         ("bounds_min", C.c_float * 3),
         ("voxel_size", C.c_float * 3),
         ("out_sh", C.c_int32 * 3),
+    ]
+
+
+class NbCull(C.Structure):
+    _fields_ = [
+        ("n_views", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("pre_affine", C.c_int32),
+        ("msk", C.c_void_p * 4),
+        ("RT", (C.c_float * 12) * 4),
+        ("K", (C.c_float * 9) * 4),
+        ("R0", C.c_float * 9),
+        ("Th0", C.c_float * 3),
     ]
 
 
@@ -48,8 +59,8 @@ SIGNATURES = {
     "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
     "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),
     "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
-    "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.c_int, _P, _P, _P, _P,
-                           _P, _P, C.c_int, _P]),
+    "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.POINTER(NbCull), C.c_int,
+                           _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
     "nb_composite_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P]),
     "nb_sgemm": (C.c_int, [C.c_int, C.c_int, _I32, _I32, _I32, C.c_float, _P, _I32, _P, _I32, C.c_float, _P, _I32, _P]),

@@ -268,7 +268,11 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
         // (same for everything derived from the lane id: recompute inside the body instead of spilling it)
         int zero = 0, lane_i = lane;
         asm volatile("" : "+s"(zero), "+v"(lane_i));
-        decode<false, false>(a.sc, a.pk + zero, a.lb + zero, px, py, pz, pe, lane_i, tile + zero, out, nullptr);
+        const bool ins = a.cull.n_views == 0 || cull_inside(a.cull, a.sc, px, py, pz);
+        if (__any(ins)) {
+            decode<false, false>(a.sc, a.pk + zero, a.lb + zero, px, py, pz, pe, lane_i, tile + zero, out, nullptr);
+        }
+        if (!ins) out[0] = out[1] = out[2] = out[3] = 0.f;  // culled sample: raw = 0 (if_clight_renderer_mmsk.py:54-59)
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
         const float w = ra.add(out, z_cur, dist);
@@ -471,8 +475,8 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
 
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias, const float *ray_o,
              const float *ray_d, const float *near, const float *far, int64_t n_rays, int32_t n_samples,
-             const float *t_vals, const float *t_rand, const int32_t *ray_order, int white_bkgd, float *rgb_map,
-             float *disp_map,
+             const float *t_vals, const float *t_rand, const int32_t *ray_order, const nb_cull *cull, int white_bkgd,
+             float *rgb_map, float *disp_map,
              float *acc_map, float *weights, float *depth_map, float *raw, int precision, void *stream) {
     NB_REQUIRE(scene && packed && latent_bias, "nb_march: NULL scene / weights");
     NB_REQUIRE(n_rays >= 0 && n_samples >= 1, "nb_march: n_rays = %lld, n_samples = %d", (long long)n_rays, n_samples);
@@ -481,6 +485,7 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     NB_REQUIRE(rgb_map && disp_map && acc_map && weights && depth_map, "nb_march: NULL output");
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
+    if (int rc = fill_cull(cull, &a.cull)) return rc;
     fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, ray_order,
                     white_bkgd,
                     rgb_map, disp_map, acc_map, weights, depth_map, raw);

@@ -80,7 +80,7 @@ constexpr int PARAM_BYTES = 8192;
 constexpr int TILE_BYTES = 8192;  // per-wave voxel tile of the cooperative gather
 constexpr int LDS_BYTES = RING_BYTES + PARAM_BYTES + 4 * TILE_BYTES;
 static_assert(LDS_BYTES <= 163840, "LDS budget (160 KiB per workgroup)");
-static_assert(P_SIZE * 4 <= 8192, "parameter region overflow");
+static_assert((P_SIZE + 4) * 4 <= 8192, "parameter region overflow (4 ints of cull flags follow the parameters)");
 
 typedef const void __attribute__((address_space(1))) *gptr_t;
 typedef void __attribute__((address_space(3))) *lptr_t;
@@ -551,7 +551,20 @@ __global__ __launch_bounds__(256) void nb_march16_kernel(MarchArgs a) {
             r2.base[sl] = lane_i * 16 + sl * PAGE_BYTES;
             asm volatile("" : "+v"(r2.base[sl]));  // keep base + immediate addressing (do not fold into per-read adds)
         }
-        decode16<false, false>(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, nullptr);
+        // Sample culling (nb_cull).  The four waves walk the weight ring in lock step, so skipping a depth step is a
+        // WORKGROUP decision: decode only if any sample of the 128 rays survives (two extra barriers per step, paid
+        // only when culling is on); culled samples of a decoded step get raw = 0.
+        bool ins = true, run = true;
+        if (a.cull.n_views) {
+            ins = cull_inside(a.cull, a.sc, px, py, pz);
+            int *flags = reinterpret_cast<int *>(rg.lds + RING_BYTES) + P_SIZE;
+            if (lane_i == 0) flags[rg.wave_off / (DMA_PER_WAVE * 1024)] = __any(ins) ? 1 : 0;
+            __syncthreads();
+            run = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+            __syncthreads();
+        }
+        if (run) decode16<false, false>(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, nullptr);
+        if (!ins || !run) out[0] = out[1] = out[2] = out[3] = 0.f;
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
         const float w = ra.add(out, z_cur, dist);

@@ -60,8 +60,57 @@ struct SceneDev {
     float osh[3];
 };
 
+// sample culling against training-view silhouettes (nb_cull): the reference's fp32 operation order
+struct CullDev {
+    int n_views, H, W, pre;
+    const unsigned char *msk[4];
+    float RT[4][12];
+    float K[4][9];
+    float R0[9];
+    float Th0[3];
+};
+
+__device__ __forceinline__ int cull_pixel(float f, int size) {
+    // torch: .round() (half to even) -> .long() -> clamp(0, size-1); non-finite / out-of-int64-range converts to
+    // INT64_MIN on the CPU and therefore clamps to 0
+    const float r = rintf(f);
+    if (!(fabsf(r) < 9.0e18f)) return 0;
+    return (int)fminf(fmaxf(r, 0.f), (float)(size - 1));
+}
+
+__device__ __forceinline__ bool cull_inside(const CullDev &c, const SceneDev &sc, float px, float py, float pz) {
+    float p[3] = {px, py, pz};
+    if (c.pre) {  // if_clight_renderer_msk.py:18-32
+        const float q[3] = {__fsub_rn(px, sc.Th[0]), __fsub_rn(py, sc.Th[1]), __fsub_rn(pz, sc.Th[2])};
+        float can[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            can[j] = __fadd_rn(__fadd_rn(__fmul_rn(q[0], sc.R[j]), __fmul_rn(q[1], sc.R[3 + j])), __fmul_rn(q[2], sc.R[6 + j]));
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            p[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(can[0], c.R0[i * 3]), __fmul_rn(can[1], c.R0[i * 3 + 1])),
+                                       __fmul_rn(can[2], c.R0[i * 3 + 2])), c.Th0[i]);
+    }
+    bool inside = true;
+    for (int v = 0; v < c.n_views; ++v) {  // if_clight_renderer_mmsk.py:21-38
+        float t[3], q[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            t[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p[0], c.RT[v][i * 4]), __fmul_rn(p[1], c.RT[v][i * 4 + 1])),
+                                       __fmul_rn(p[2], c.RT[v][i * 4 + 2])), c.RT[v][i * 4 + 3]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            q[i] = __fadd_rn(__fadd_rn(__fmul_rn(t[0], c.K[v][i * 3]), __fmul_rn(t[1], c.K[v][i * 3 + 1])),
+                             __fmul_rn(t[2], c.K[v][i * 3 + 2]));
+        const int x = cull_pixel(__fdiv_rn(q[0], q[2]), c.W), y = cull_pixel(__fdiv_rn(q[1], q[2]), c.H);
+        inside = inside && c.msk[v][(size_t)y * c.W + x] != 0;
+    }
+    return inside;
+}
+
 struct MarchArgs {
     SceneDev sc;
+    CullDev cull;
     const float *pk;  // packed decoder weights (format depends on the kernel family)
     const float *lb;
     // ray mode
@@ -452,6 +501,26 @@ inline int fill_scene(const nb_scene *s, SceneDev *d) {
     return NB_OK;
 }
 
+
+inline int fill_cull(const nb_cull *c, CullDev *d) {
+    d->n_views = 0;
+    if (!c) return NB_OK;
+    NB_REQUIRE(c->n_views >= 1 && c->n_views <= NB_MAX_CULL_VIEWS && c->H > 0 && c->W > 0, "nb_cull: n_views %d, H %d, W %d",
+               c->n_views, c->H, c->W);
+    d->n_views = c->n_views;
+    d->H = c->H;
+    d->W = c->W;
+    d->pre = c->pre_affine;
+    for (int v = 0; v < c->n_views; ++v) {
+        NB_REQUIRE(c->msk[v] != nullptr, "nb_cull: msk[%d] is NULL", v);
+        d->msk[v] = c->msk[v];
+        for (int k = 0; k < 12; ++k) d->RT[v][k] = c->RT[v][k];
+        for (int k = 0; k < 9; ++k) d->K[v][k] = c->K[v][k];
+    }
+    for (int k = 0; k < 9; ++k) d->R0[k] = c->R0[k];
+    for (int k = 0; k < 3; ++k) d->Th0[k] = c->Th0[k];
+    return NB_OK;
+}
 
 inline void fill_march_args(MarchArgs &a, const float *packed, const float *latent_bias, const float *ray_o,
                             const float *ray_d, const float *near, const float *far, long long n_rays, int n_samples,

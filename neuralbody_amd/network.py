@@ -236,7 +236,7 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ fused march
     def render_rays(self, ray_o, ray_d, near, far, feature_volume, sp_input, n_samples, t_rand=None,
-                    white_bkgd=False, want_raw=False, ray_order=None):
+                    white_bkgd=False, want_raw=False, ray_order=None, cull=None):
         """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
         scene = self.make_scene(feature_volume, sp_input)
         lb = self.latent_bias(sp_input["latent_index"])
@@ -246,4 +246,5 @@ class Network(nn.Module):
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._host_cache[key] = t_vals
         return ops.march(scene, self.packed_weights(), lb, ray_o, ray_d, near, far, t_vals, t_rand,
-                         white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision, ray_order=ray_order)
+                         white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision, ray_order=ray_order,
+                         cull=cull)

@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import NbError, NbMlpParams, NbScene, check, ptr
+from ._lib import NbCull, NbError, NbMlpParams, NbScene, check, ptr
 
 LEVEL_CHANNELS = (32, 64, 128, 128)
 DBG_WIDTH = 1600
@@ -133,7 +133,7 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
 
 
 def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=None, white_bkgd=False,
-          want_raw=False, precision="f32", ray_order=None):
+          want_raw=False, precision="f32", ray_order=None, cull=None):
     """nb_march: all rays of one batch element -> dict of per-ray outputs."""
     sc, _keep = scene
     _req(packed, torch.float32, (mlp_pack_size(),), "packed")
@@ -161,7 +161,8 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     check(_lib.lib().nb_march(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(ray_o), ptr(ray_d), ptr(near), ptr(far),
-                              n, S, ptr(t_vals), ptr(t_rand), ptr(ray_order), 1 if white_bkgd else 0, ptr(rgb), ptr(disp),
+                              n, S, ptr(t_vals), ptr(t_rand), ptr(ray_order),
+                              C.byref(cull[0]) if cull is not None else None, 1 if white_bkgd else 0, ptr(rgb), ptr(disp),
                               ptr(acc),
                               ptr(weights), ptr(depth), ptr(raw), _lib.PRECISIONS[precision], _stream()), "nb_march")
     if ev is not None:
@@ -451,3 +452,31 @@ def enc_scatter_codes_bwd(drows, rows_vert, n_rows, n_rows_max, n_codes):
     check(_lib.lib().nb_enc_scatter_codes_bwd(ptr(drows), ptr(rows_vert), ptr(n_rows), int(n_rows_max), c, ptr(dcodes),
                                               _stream()), "nb_enc_scatter_codes_bwd")
     return dcodes
+
+
+def make_cull(masks, RTs, Ks, H, W, R0=None, Th0=None):
+    """nb_cull from device uint8 masks [H,W] (1..4 views) and HOST 3x4 / 3x3 matrices.  R0 / Th0 (host) select the
+    _msk variant (snapshot-frame placement).  Returns (NbCull, keepalive)."""
+    if not 1 <= len(masks) <= 4:
+        raise ValueError("1..4 mask views supported")
+    c = NbCull()
+    c.n_views, c.H, c.W = len(masks), int(H), int(W)
+    c.pre_affine = 0 if R0 is None else 1
+    keep = []
+    for v, m in enumerate(masks):
+        _req(m, torch.uint8, (int(H), int(W)), "mask[%d]" % v)
+        c.msk[v] = m.data_ptr()
+        keep.append(m)
+        rt = [float(x) for row in RTs[v] for x in row]
+        k = [float(x) for row in Ks[v] for x in row]
+        for i in range(12):
+            c.RT[v][i] = rt[i]
+        for i in range(9):
+            c.K[v][i] = k[i]
+    if R0 is not None:
+        r0 = [float(x) for row in R0 for x in row]
+        for i in range(9):
+            c.R0[i] = r0[i]
+        for i in range(3):
+            c.Th0[i] = float(Th0[i])
+    return c, keep

@@ -1,0 +1,17 @@
+"""renderer_path plugin for the mask-culled renderer (lib/networks/renderer/if_clight_renderer_msk.py): `Renderer(net)`
+bound to the reference's global cfg; selected by the novel-view / novel-pose overlays of the shipped configs
+(e.g. configs/zju_mocap_exp/latent_xyzc_313.yaml:95,125, configs/snapshot_exp/snapshot_f3c.yaml:88,105)."""
+import os
+import sys
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from neuralbody_amd.plugins.if_clight_renderer import _LiveCfg  # noqa: E402
+from neuralbody_amd.renderer import RendererMsk as _Renderer  # noqa: E402
+
+
+class Renderer(_Renderer):
+    def __init__(self, net):
+        super().__init__(net, _LiveCfg())

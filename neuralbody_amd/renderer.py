@@ -114,10 +114,15 @@ class Renderer:
         else:
             tr = None
         ray_order = self._tile_order(batch, n_pixel, b, e)
+        cull = self.make_cull(batch)
         ret = self.net.render_rays(ray_o[0, b:e].contiguous(), ray_d[0, b:e].contiguous(), near[0, b:e].contiguous(),
                                    far[0, b:e].contiguous(), feature_volume, sp_input, self.cfg.N_samples, t_rand=tr,
-                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw, ray_order=ray_order)
+                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw, ray_order=ray_order, cull=cull)
         return {k: v[None] for k, v in ret.items()}
+
+    def make_cull(self, batch):
+        """Sample-culling description for nb_march (None: the base renderer decodes every sample)."""
+        return None
 
     def _tile_order(self, batch, n_pixel, b, e):
         """slot -> ray permutation grouping the rays [b, e) into 8x4 pixel tiles (None when the image geometry
@@ -136,3 +141,34 @@ class Renderer:
         order = ops.tile_order(pix[b:e], int(W))
         self._order_cache = (key, order)
         return order
+
+
+def _host(t):
+    return t.detach().float().cpu().numpy()
+
+
+class RendererMmsk(Renderer):
+    """lib/networks/renderer/if_clight_renderer_mmsk.py::Renderer — novel views of multi-view (ZJU) subjects: samples
+    that project outside any of the dilated training-view masks are culled (batch keys msks [B,nv,H,W], Ks [B,nv,3,3],
+    RT [B,nv,3,4], multi_view_demo_dataset.py:176).  The culling runs inside nb_march (nb_cull)."""
+
+    def make_cull(self, batch):
+        if "Ks" not in batch:
+            raise KeyError("the _mmsk renderer needs batch['msks'], batch['Ks'], batch['RT']")
+        msks = batch["msks"][0]
+        nv, H, W = msks.shape
+        masks = [msks[v].to(torch.uint8).contiguous() for v in range(nv)]
+        return ops.make_cull(masks, _host(batch["RT"][0]), _host(batch["Ks"][0]), H, W)
+
+
+class RendererMsk(Renderer):
+    """lib/networks/renderer/if_clight_renderer_msk.py::Renderer — novel views of monocular (People-Snapshot) subjects:
+    the sample is carried into the snapshot frame's pose (R0_snap, Th0_snap) and tested against that frame's mask."""
+
+    def make_cull(self, batch):
+        if "R0_snap" not in batch:
+            raise KeyError("the _msk renderer needs batch['msk'], batch['K'], batch['RT'], batch['R0_snap'], batch['Th0_snap']")
+        msk = batch["msk"][0]
+        H, W = msk.shape
+        return ops.make_cull([msk.to(torch.uint8).contiguous()], [_host(batch["RT"][0])], [_host(batch["K"][0])], H, W,
+                             R0=_host(batch["R0_snap"][0]), Th0=_host(batch["Th0_snap"][0]).reshape(-1))

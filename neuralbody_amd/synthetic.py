@@ -242,3 +242,28 @@ def full_coverage_camera(body, H, W, distance=2.5, yaw=0.35, pitch=0.1):
         if mask.all():
             return K, R, T
     raise RuntimeError("no full-coverage camera found")
+
+
+def make_view_masks(body, H, W, n_views=4, focal_factor=1.6, distance=2.0, dilate=3):
+    """Synthetic training-view silhouettes for the mask-culled renderers (lib/networks/renderer/
+    if_clight_renderer_mmsk.py:12-45): `n_views` cameras around the body, each mask = the projected vertices dilated by
+    `dilate` pixels (the datasets dilate the CIHP masks by a 5x5 kernel, multi_view_demo_dataset.py:122-125).
+    Returns (msks [nv,H,W] uint8, Ks [nv,3,3] f32, RT [nv,3,4] f32)."""
+    from scipy import ndimage
+
+    msks, Ks, RTs = [], [], []
+    for v in range(n_views):
+        K, R, T = make_camera(body, H, W, focal_factor=focal_factor, distance=distance, yaw=0.4 + 2 * math.pi * v / n_views,
+                              pitch=0.05 * (v % 2))
+        cam = body["world_verts"].astype(np.float64) @ R.T + T.ravel()
+        uv = cam @ K.T
+        uv = uv[:, :2] / uv[:, 2:]
+        px = np.round(uv).astype(np.int64)
+        ok = (px[:, 0] >= 0) & (px[:, 0] < W) & (px[:, 1] >= 0) & (px[:, 1] < H)
+        m = np.zeros((H, W), bool)
+        m[px[ok, 1], px[ok, 0]] = True
+        m = ndimage.binary_dilation(m, structure=np.ones((2 * dilate + 1, 2 * dilate + 1), bool))
+        msks.append(m.astype(np.uint8))
+        Ks.append(K.astype(np.float32))
+        RTs.append(np.concatenate([R, T], 1).astype(np.float32))
+    return np.stack(msks), np.stack(Ks), np.stack(RTs)

@@ -264,3 +264,81 @@ def render(sd, batch, n_samples=64, voxel_size=(0.005, 0.005, 0.005), training=T
         rets.append({"rgb_map": rgb.view(nb, npx, -1), "disp_map": disp.view(nb, npx), "acc_map": acc.view(nb, npx),
                      "weights": wts.view(nb, npx, -1), "depth_map": depth.view(nb, npx), "raw": raw})
     return {k: torch.cat([r[k] for r in rets], dim=1) for k in rets[0]}
+
+
+# ----------------------------------------------------------------------------- _mmsk / _msk renderers (§8(f) rank 2)
+def inside_mmsk(pts, batch, H, W):
+    """lib/networks/renderer/if_clight_renderer_mmsk.py:12-45: a sample survives if it projects inside ALL the
+    (dilated) training-view masks.  pts [B,P,S,3] -> bool [1, P*S]."""
+    sh = pts.shape
+    pts = pts.view(sh[0], -1, sh[3])
+    insides = []
+    for nv in range(batch["Ks"].size(1)):
+        R = batch["RT"][:, nv, :3, :3]
+        T = batch["RT"][:, nv, :3, 3]
+        pts_ = torch.matmul(pts, R.transpose(2, 1)) + T[:, None]
+        pts_ = torch.matmul(pts_, batch["Ks"][:, nv].transpose(2, 1))
+        pts2d = pts_[..., :2] / pts_[..., 2:]
+        pts2d = pts2d.round().long()
+        pts2d[..., 0] = torch.clamp(pts2d[..., 0], 0, W - 1)
+        pts2d[..., 1] = torch.clamp(pts2d[..., 1], 0, H - 1)
+        pts2d = pts2d[0]
+        msk = batch["msks"][0, nv]
+        insides.append(msk[pts2d[:, 1], pts2d[:, 0]][None].bool())
+    inside = insides[0]
+    for i in range(1, len(insides)):
+        inside = inside * insides[i]
+    return inside
+
+
+def inside_msk(wpts, batch, H, W):
+    """lib/networks/renderer/if_clight_renderer_msk.py:12-49: world -> SMPL space of the rendered pose -> world of the
+    snapshot frame -> its camera -> its mask.  wpts [B,P,S,3] -> bool [1, P*S]."""
+    can_pts = wpts - batch["Th"][:, None, None]
+    can_pts = torch.matmul(can_pts, batch["R"])
+    sh = can_pts.shape
+    can_pts = can_pts.view(sh[0], -1, sh[3])
+    pts = torch.matmul(can_pts, batch["R0_snap"].transpose(2, 1)) + batch["Th0_snap"][:, None]
+    R = batch["RT"][..., :3]
+    T = batch["RT"][..., 3]
+    pts = torch.matmul(pts, R.transpose(2, 1)) + T[:, None]
+    pts = torch.matmul(pts, batch["K"].transpose(2, 1))
+    pts2d = pts[..., :2] / pts[..., 2:]
+    pts2d = pts2d.round().long()
+    pts2d[..., 0] = torch.clamp(pts2d[..., 0], 0, W - 1)
+    pts2d[..., 1] = torch.clamp(pts2d[..., 1], 0, H - 1)
+    pts2d = pts2d[0]
+    msk = batch["msk"][0]
+    return msk[pts2d[:, 1], pts2d[:, 0]][None].bool()
+
+
+def render_masked(sd, batch, H, W, kind, n_samples=64, voxel_size=(0.005, 0.005, 0.005), training=True,
+                  white_bkgd=False, chunk=2048, feature_volume=None):
+    """if_clight_renderer_mmsk.py:47-94 (kind='mmsk') / _msk (kind='msk'): culled samples get raw = 0
+    (full_raw = zeros, :55), the rest is the base renderer."""
+    dtype = sd["c.weight"].dtype
+    b = {k: _t(v, dtype) if isinstance(v, (np.ndarray, torch.Tensor)) else v for k, v in batch.items()}
+    out_sh = torch.max(b["out_sh"], dim=0)[0].tolist()
+    sp = {"bounds": b["bounds"], "R": b["R"], "Th": b["Th"].reshape(b["Th"].shape[0], 1, 3),
+          "latent_index": b["latent_index"].long(), "out_sh": out_sh}
+    if feature_volume is None:
+        feature_volume = encode_sparse_voxels(sd, b["coord"], out_sh, training=training)
+    ray_o, ray_d, near, far = b["ray_o"], b["ray_d"], b["near"], b["far"]
+    n_pixel = ray_o.shape[1]
+    rets = []
+    for i in range(0, n_pixel, chunk):
+        ro, rd = ray_o[:, i:i + chunk], ray_d[:, i:i + chunk]
+        wpts, z_vals = get_sampling_points(ro, rd, near[:, i:i + chunk], far[:, i:i + chunk], n_samples)
+        inside = inside_mmsk(wpts, b, H, W) if kind == "mmsk" else inside_msk(wpts, b, H, W)
+        viewdir = rd / torch.norm(rd, dim=2, keepdim=True)
+        nb, npx, ns = wpts.shape[:3]
+        w = wpts.view(nb, npx * ns, -1)
+        v = viewdir[:, :, None].repeat(1, 1, ns, 1).contiguous().view(nb, npx * ns, -1)
+        full_raw = torch.zeros([nb, npx * ns, 4]).to(w)
+        if inside.sum() > 0:
+            raw = calculate_density_color(sd, w[inside][None], v[inside][None], feature_volume, sp, voxel_size)
+            full_raw[inside] = raw[0]
+        rgb, disp, acc, wts, depth = raw2outputs(full_raw.reshape(-1, ns, 4), z_vals.view(-1, ns), rd.reshape(-1, 3), white_bkgd)
+        rets.append({"rgb_map": rgb.view(nb, npx, -1), "disp_map": disp.view(nb, npx), "acc_map": acc.view(nb, npx),
+                     "weights": wts.view(nb, npx, -1), "depth_map": depth.view(nb, npx), "inside": inside.view(nb, npx, ns)})
+    return {k: torch.cat([r[k] for r in rets], dim=1) for k in rets[0]}

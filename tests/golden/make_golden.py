@@ -120,6 +120,32 @@ def run_raygen():
     print("raygen ->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_masked(kind):
+    """The reference's mask-culled renderers (lib/networks/renderer/if_clight_renderer_mmsk.py / _msk.py) on CPU."""
+    import importlib
+
+    ns = rh.load()
+    r, sd, batch, (H, W) = scenes.build_masked(kind)
+    cfg = ns.cfg
+    cfg.N_samples, cfg.white_bkgd, cfg.perturb, cfg.raw_noise_std = r["n_samples"], False, 0.0, 0.0
+    cfg.H, cfg.W, cfg.ratio = H, W, 1.0
+    net = rh.make_reference_network(sd, train_mode=True)
+    mod = importlib.import_module("lib.networks.renderer.if_clight_renderer_" + kind)
+    ren = mod.Renderer(net)
+    tb = rh.torch_batch(batch)
+    with torch.no_grad():
+        out = ren.render(tb)
+        wpts, _ = ren.get_sampling_points(tb["ray_o"], tb["ray_d"], tb["near"], tb["far"])
+        inside = ren.prepare_inside_pts(wpts, tb)
+    g = {k: v.numpy() for k, v in out.items()}
+    g["inside"] = inside.numpy().reshape(1, -1, r["n_samples"])
+    g["input_digest"] = np.array(input_digest(sd, batch))
+    path = os.path.join(OUT, "masked_%s.npz" % kind)
+    np.savez_compressed(path, **g)
+    print(kind, "rays", out["rgb_map"].shape[1], "inside fraction %.3f" % g["inside"].mean(), "rgb max %.3f" % g["rgb_map"].max(),
+          "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 def run_train_step():
     """One training step of the UNMODIFIED reference (NetworkWrapper, lib/train/trainers/if_nerf_clight.py:18-36) on CPU:
     loss and, for every parameter, the gradient's L2 norm, sum and a few probe entries."""
@@ -152,11 +178,13 @@ def run_train_step():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train"]
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk"]
     for n in names:
         if n == "raygen":
             run_raygen()
         elif n == "train":
             run_train_step()
+        elif n in ("mmsk", "msk"):
+            run_masked(n)
         else:
             run_scene(n)

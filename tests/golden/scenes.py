@@ -85,3 +85,33 @@ def build_train():
 def grad_probe_indices(shape, n=GRAD_PROBES, seed=5):
     size = int(np.prod(shape)) if len(shape) else 1
     return np.random.RandomState(seed + size % 1000).randint(0, size, n)
+
+
+# mask-culled renderers (§8(f) rank 2): 'mmsk' = multi-view ZJU novel view, 'msk' = monocular People-Snapshot novel view
+# a capsule "body" (thin limbs inside a mostly empty bounding box) so that the silhouettes really cull samples
+_CAPSULE_BODY = dict(seed=5, box=(0.45, 0.85, 0.18), rh=(0.1, 0.2, -0.1), th=(0.05, -0.1, 0.2), layout="capsules")
+MASKED = {
+    "mmsk": dict(weights_seed=2, num_train_frame=7, body=_CAPSULE_BODY, cam=dict(H=48, W=48, focal_factor=1.8, distance=1.6),
+                 n_samples=64, latent_index=1, n_views=4, weights_kw=dict(alpha_bias=1.0, alpha_scale=12.0)),
+    "msk": dict(weights_seed=2, num_train_frame=7, body=_CAPSULE_BODY, cam=dict(H=48, W=48, focal_factor=1.8, distance=1.6),
+                n_samples=64, latent_index=2, n_views=1, weights_kw=dict(alpha_bias=1.0, alpha_scale=12.0)),
+}
+
+
+def build_masked(kind):
+    """-> (recipe, state_dict_np, batch_np with the extra keys of the _mmsk / _msk datasets, (H, W))"""
+    r = MASKED[kind]
+    sd = syn.make_weights(r["weights_seed"], num_train_frame=r["num_train_frame"], **r["weights_kw"])
+    body = syn.make_body(**r["body"])
+    c = r["cam"]
+    K, R, T = syn.make_camera(body, c["H"], c["W"], focal_factor=c["focal_factor"], distance=c["distance"], yaw=-0.3)
+    ray_o, ray_d, near, far, mask = syn.host_image_rays(c["H"], c["W"], K, R, T, body["can_bounds"])
+    batch = syn.make_batch(body, ray_o, ray_d, near, far, mask, latent_index=r["latent_index"])
+    msks, Ks, RT = syn.make_view_masks(body, c["H"], c["W"], n_views=r["n_views"], focal_factor=1.8, distance=1.6, dilate=1)
+    if kind == "mmsk":  # multi_view_demo_dataset.py:176
+        batch.update(msks=msks[None], Ks=Ks[None], RT=RT[None])
+    else:  # monocular_demo_dataset.py:117-142: Th is [3]; the snapshot frame's own pose places the mask
+        batch["Th"] = batch["Th"].reshape(1, 3)
+        batch.update(msk=(msks[0] * 255)[None].astype(np.uint8), K=Ks[0][None], RT=RT[0][None],
+                     R0_snap=body["R"][None].astype(np.float32), Th0_snap=body["Th"].reshape(1, 3).astype(np.float32))
+    return r, sd, batch, (c["H"], c["W"])

@@ -21,7 +21,7 @@ def test_library_exports_every_header_symbol(lib):
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.nb_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.nb_abi_version() == _lib.ABI_VERSION == 7
 
 
 def test_sizes_and_struct_layout(lib):
@@ -36,8 +36,8 @@ def test_sizes_and_struct_layout(lib):
 
 def test_error_codes_without_touching_a_device(lib):
     # NULL scene -> NB_EINVAL and a message, no crash, no launch
-    rc = lib.nb_march(None, None, None, None, None, None, None, 10, 64, None, None, None, 0, None, None, None, None,
-                      None, None, 0, None)
+    rc = lib.nb_march(None, None, None, None, None, None, None, 10, 64, None, None, None, None, 0, None, None, None,
+                      None, None, None, 0, None)
     assert rc == -1
     assert b"nb_march" in lib.nb_last_error()
     rc = lib.nb_composite(None, None, None, 4, 0, 0, None, None, None, None, None, None)

@@ -5,6 +5,8 @@ the C ABI (neuralbody_amd.ops -> libnb_hip.so).
 
 Tolerances: RGB <= 1e-4 L-inf (BASELINE.json north_star); intermediate quantities are compared
 relative to max(1, |ref|) with the budgets written next to each check."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -301,6 +303,34 @@ def test_render_end_to_end_matches_reference(name, precision):
         if vols is not None:
             pv = rend.get_pixel_value(bd["ray_o"], bd["ray_d"], bd["near"], bd["far"], vols, sp, bd)
             H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 1e-5, "fused vs unfused rgb")
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("kind", ["mmsk", "msk"])
+def test_mask_culled_renderers_match_reference(kind, precision):
+    """RendererMmsk / RendererMsk (sample culling inside nb_march) against the reference's if_clight_renderer_mmsk /
+    if_clight_renderer_msk outputs (tests/golden/masked_*.npz, generated by make_golden.py::run_masked)."""
+    from neuralbody_amd.renderer import RenderConfig, Renderer, RendererMmsk, RendererMsk
+
+    g = np.load(os.path.join(H.GOLDEN, "masked_%s.npz" % kind))
+    r, sd, batch, (Hh, Ww) = scenes.build_masked(kind)
+    net = H.make_network(sd, DEV, True, precision)
+    cfg = RenderConfig(N_samples=r["n_samples"], perturb=0.0, raw_noise_std=0.0, white_bkgd=False)
+    rend = (RendererMmsk if kind == "mmsk" else RendererMsk)(net, cfg)
+    bd = H.device_batch(batch, DEV)
+    with torch.no_grad():
+        out = rend.render(bd)
+        base = Renderer(net, cfg).render(bd)  # the un-culled renderer on the same batch
+    torch.cuda.synchronize()
+    err = H.assert_close(out["rgb_map"].cpu().numpy(), g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    H.assert_close(out["acc_map"].cpu().numpy(), g["acc_map"], 2e-4, "acc_map")
+    H.assert_close(out["weights"].cpu().numpy(), g["weights"], 2e-4, "weights")
+    H.assert_close(out["depth_map"].cpu().numpy(), g["depth_map"], 2e-4, "depth_map")
+    # culled samples carry exactly zero weight; and the culling changes the image (the fixture exercises it)
+    inside = g["inside"].reshape(out["weights"].shape)
+    assert float(out["weights"].cpu().numpy()[~inside].max(initial=0.0)) == 0.0
+    assert float((out["rgb_map"] - base["rgb_map"]).abs().max()) > 1e-2
+    print("%s/%s: rgb L-inf vs reference %.2e, inside fraction %.2f" % (kind, precision, err, inside.mean()))
 
 
 # ------------------------------------------------------------------------------------------- ray generation

@@ -108,3 +108,17 @@ def test_oracle_autograd_matches_reference_training_step(golden_dir):
         assert abs(np.sqrt((gr ** 2).sum()) - float(g["norm/" + name])) <= 2e-3 * max(float(g["norm/" + name]), 1e-30), name
         idx = scenes.grad_probe_indices(gr.shape)
         assert np.abs(gr.reshape(-1)[idx] - g["probe/" + name]).max() <= 2e-3 * scale, name
+
+
+@pytest.mark.parametrize("kind", ["mmsk", "msk"])
+def test_oracle_masked_renderers_match_reference_golden(kind, golden_dir):
+    """oracle.render_masked against the reference's if_clight_renderer_mmsk / _msk (fixtures made by make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "masked_%s.npz" % kind))
+    r, sd, batch, (Hh, Ww) = scenes.build_masked(kind)
+    assert _digest(sd, batch) == str(g["input_digest"]), "seeded inputs drifted from the fixture"
+    with torch.no_grad():
+        out = orc.render_masked(orc.tensor_state_dict(sd), batch, Hh, Ww, kind, n_samples=r["n_samples"], training=True)
+    assert np.array_equal(out["inside"].numpy(), g["inside"])
+    assert 0.2 < g["inside"].mean() < 0.8, "fixture does not exercise the culling"
+    for k in ("rgb_map", "disp_map", "acc_map", "weights", "depth_map"):
+        _close(out[k].numpy(), g[k], tol=2e-5 if k == "disp_map" else TOL, name=k)
