@@ -558,10 +558,16 @@ __global__ __launch_bounds__(256) void nb_march16_kernel(MarchArgs a) {
         if (a.cull.n_views) {
             ins = cull_inside(a.cull, a.sc, px, py, pz);
             int *flags = reinterpret_cast<int *>(rg.lds + RING_BYTES) + P_SIZE;
-            if (lane_i == 0) flags[rg.wave_off / (DMA_PER_WAVE * 1024)] = __any(ins) ? 1 : 0;
+            const int any_wave = __any(ins) ? 1 : 0;  // evaluated by the whole wave, stored by one lane
+            if (lane_i == 0) flags[rg.wave_off / (DMA_PER_WAVE * 1024)] = any_wave;
             __syncthreads();
-            run = (flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+            // readfirstlane: the decision is uniform by construction; say so, so that the ring's barriers and DMA sit
+            // under a scalar branch instead of an exec-masked region
+            run = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
             __syncthreads();
+#ifdef NB_CULL_NOSKIP
+            run = true;
+#endif
         }
         if (run) decode16<false, false>(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, nullptr);
         if (!ins || !run) out[0] = out[1] = out[2] = out[3] = 0.f;
