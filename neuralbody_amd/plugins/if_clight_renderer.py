@@ -22,6 +22,7 @@ class _LiveCfg:
     white_bkgd = property(lambda self: bool(cfg.white_bkgd))
     H = property(lambda self: int(cfg.H * cfg.ratio))  # image_rays geometry, lib/utils/render_utils.py:121-122
     W = property(lambda self: int(cfg.W * cfg.ratio))
+    mesh_th = property(lambda self: float(cfg.mesh_th))
 
 
 class Renderer(_Renderer):

@@ -17,7 +17,7 @@ from . import ops
 class RenderConfig:
     """The cfg keys the hot path reads."""
 
-    def __init__(self, N_samples=64, perturb=0.0, raw_noise_std=0.0, white_bkgd=False, H=None, W=None):
+    def __init__(self, N_samples=64, perturb=0.0, raw_noise_std=0.0, white_bkgd=False, H=None, W=None, mesh_th=50.0):
         # H, W (optional): image size of the view the rays come from (cfg.H * cfg.ratio in the reference); when
         # batch['mask_at_box'] covers H*W pixels, rays are grouped into 8x4 pixel tiles per wavefront
         self.H, self.W = H, W
@@ -25,6 +25,7 @@ class RenderConfig:
         self.perturb = float(perturb)
         self.raw_noise_std = float(raw_noise_std)
         self.white_bkgd = bool(white_bkgd)
+        self.mesh_th = float(mesh_th)  # lib/config/config.py:45; the shipped configs override it to 5
 
 
 class Renderer:
@@ -172,3 +173,34 @@ class RendererMsk(Renderer):
         H, W = msk.shape
         return ops.make_cull([msk.to(torch.uint8).contiguous()], [_host(batch["RT"][0])], [_host(batch["K"][0])], H, W,
                              R0=_host(batch["R0_snap"][0]), Th0=_host(batch["Th0_snap"][0]).reshape(-1))
+
+
+class RendererMesh(Renderer):
+    """lib/networks/renderer/if_mesh_renderer.py::Renderer — density on the lattice of
+    multi_view_mesh_dataset.py:142-158 for mesh extraction.  The hot part (encoder + `calculate_density` of every
+    lattice point flagged `inside`) runs on HIP in ONE nb_decode_points launch (the reference chunks 131 072 points per
+    call, :37); marching cubes is CPU post-processing of the reference's own dependencies (PyMCubes, trimesh)."""
+
+    def batchify_rays(self, wpts, alpha_decoder, chunk=1024 * 32):
+        """if_mesh_renderer.py:15-24; kept for subclasses — chunking is not needed for memory here."""
+        return torch.cat([alpha_decoder(wpts[:, i:i + chunk]) for i in range(0, wpts.shape[1], chunk)], 1)
+
+    def density_cube(self, batch, pad=10):
+        """-> DEVICE float32 tensor [X+2*pad, Y+2*pad, Z+2*pad]: alpha at the inside lattice points, 0 elsewhere."""
+        pts = batch["pts"]
+        inside = batch["inside"][0].bool()
+        wpts = pts[0][inside][None].contiguous()
+        sp_input = self.prepare_sp_input(batch)
+        feature_volume = self.net.encode_sparse_voxels(sp_input)
+        alpha = self.net.calculate_density(wpts, feature_volume, sp_input)
+        cube = torch.zeros(pts.shape[1:-1], dtype=torch.float32, device=pts.device)
+        cube[inside] = alpha[0, :, 0]
+        return torch.nn.functional.pad(cube, (pad,) * 6)
+
+    def render(self, batch):
+        import mcubes  # CPU marching cubes, as in the reference (if_mesh_renderer.py:6,46)
+        import trimesh
+
+        cube = self.density_cube(batch).double().cpu().numpy()
+        vertices, triangles = mcubes.marching_cubes(cube, self.cfg.mesh_th)
+        return {"cube": cube, "mesh": trimesh.Trimesh(vertices, triangles)}

@@ -267,3 +267,23 @@ def make_view_masks(body, H, W, n_views=4, focal_factor=1.6, distance=2.0, dilat
         Ks.append(K.astype(np.float32))
         RTs.append(np.concatenate([R, T], 1).astype(np.float32))
     return np.stack(msks), np.stack(Ks), np.stack(RTs)
+
+
+def make_density_lattice(body, step=0.02, n_views=3, H=64, W=64, dilate=2):
+    """The mesh-extraction query set of lib/datasets/light_stage/multi_view_mesh_dataset.py:142-158: a regular lattice
+    over the world bounding box (np.arange per axis, 'ij' meshgrid) and the `inside` bitmap = lattice points that project
+    inside every synthetic silhouette (the dataset's prepare_inside_pts, :100-140, done here in numpy).
+    Returns (pts [X,Y,Z,3] f32, inside [X,Y,Z] uint8)."""
+    cb = body["can_bounds"].astype(np.float32)
+    axes = [np.arange(cb[0, a], cb[1, a] + step, step) for a in range(3)]
+    pts = np.stack(np.meshgrid(*axes, indexing="ij"), axis=-1).astype(np.float32)
+    msks, Ks, RT = make_view_masks(body, H, W, n_views=n_views, focal_factor=1.8, distance=1.6, dilate=dilate)
+    flat = pts.reshape(-1, 3).astype(np.float64)
+    inside = np.ones(flat.shape[0], bool)
+    for v in range(n_views):
+        cam = flat @ RT[v, :, :3].astype(np.float64).T + RT[v, :, 3].astype(np.float64)
+        uv = cam @ Ks[v].astype(np.float64).T
+        px = np.round(uv[:, :2] / uv[:, 2:]).astype(np.int64)
+        x, y = np.clip(px[:, 0], 0, W - 1), np.clip(px[:, 1], 0, H - 1)
+        inside &= msks[v][y, x] != 0
+    return pts, inside.reshape(pts.shape[:-1]).astype(np.uint8)

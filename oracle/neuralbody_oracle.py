@@ -342,3 +342,19 @@ def render_masked(sd, batch, H, W, kind, n_samples=64, voxel_size=(0.005, 0.005,
         rets.append({"rgb_map": rgb.view(nb, npx, -1), "disp_map": disp.view(nb, npx), "acc_map": acc.view(nb, npx),
                      "weights": wts.view(nb, npx, -1), "depth_map": depth.view(nb, npx), "inside": inside.view(nb, npx, ns)})
     return {k: torch.cat([r[k] for r in rets], dim=1) for k in rets[0]}
+
+
+def density_cube(sd, batch, voxel_size=(0.005, 0.005, 0.005), training=True, pad=10):
+    """lib/networks/renderer/if_mesh_renderer.py:26-45 up to (not including) marching cubes: density of the lattice
+    points flagged `inside`, scattered into a zero cube, zero-padded by 10 on every side.  -> float64 ndarray."""
+    pts = _t(batch["pts"])
+    sh = pts.shape
+    inside = torch.as_tensor(batch["inside"][0]).bool()
+    wpts = pts[0][inside][None]
+    out_sh = np.asarray(batch["out_sh"]).max(0).tolist()
+    vols = encode_sparse_voxels(sd, torch.as_tensor(batch["coord"]), out_sh, training=training)
+    sp = {"R": _t(batch["R"]), "Th": _t(batch["Th"]), "bounds": _t(batch["bounds"]), "out_sh": out_sh}
+    alpha = calculate_density(sd, wpts, vols, sp, voxel_size)[0, :, 0].numpy()
+    cube = np.zeros(tuple(sh[1:-1]))
+    cube[inside.numpy()] = alpha
+    return np.pad(cube, pad, mode="constant")

@@ -146,6 +146,34 @@ def run_masked(kind):
           "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_mesh():
+    """The reference's mesh renderer (lib/networks/renderer/if_mesh_renderer.py) on CPU.  mcubes / trimesh are absent
+    from the image and are CPU post-processing outside the hot path: they are stubbed for the import, the fixture keeps
+    the density cube the marching cubes would consume."""
+    import importlib
+    import types
+
+    ns = rh.load()
+    mc = types.ModuleType("mcubes")
+    mc.marching_cubes = lambda cube, th: (np.zeros((0, 3)), np.zeros((0, 3), np.int64))
+    sys.modules["mcubes"] = mc
+    sys.modules["trimesh"].Trimesh = lambda v, t: ("mesh", len(v), len(t))
+    r, sd, batch = scenes.build_mesh()
+    net = rh.make_reference_network(sd, train_mode=True)
+    mod = importlib.import_module("lib.networks.renderer.if_mesh_renderer")
+    ren = mod.Renderer(net)
+    with torch.no_grad():
+        out = ren.render(rh.torch_batch(batch))
+    cube = out["cube"]
+    inside = batch["inside"][0].astype(bool)
+    g = {"cube": cube.astype(np.float32), "n_inside": np.array(int(inside.sum())), "input_digest": np.array(input_digest(sd, batch))}
+    assert np.array_equal(g["cube"].astype(np.float64), cube), "the cube holds float32 values"
+    path = os.path.join(OUT, "mesh_cube.npz")
+    np.savez_compressed(path, **g)
+    print("mesh cube", cube.shape, "inside %d of %d" % (inside.sum(), inside.size), "alpha range %.2f..%.2f, > mesh_th=5: %d" %
+          (cube.min(), cube.max(), (cube > 5).sum()), "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 def run_train_step():
     """One training step of the UNMODIFIED reference (NetworkWrapper, lib/train/trainers/if_nerf_clight.py:18-36) on CPU:
     loss and, for every parameter, the gradient's L2 norm, sum and a few probe entries."""
@@ -178,12 +206,14 @@ def run_train_step():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk"]
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh"]
     for n in names:
         if n == "raygen":
             run_raygen()
         elif n == "train":
             run_train_step()
+        elif n == "mesh":
+            run_mesh()
         elif n in ("mmsk", "msk"):
             run_masked(n)
         else:

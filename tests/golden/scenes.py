@@ -115,3 +115,25 @@ def build_masked(kind):
         batch.update(msk=(msks[0] * 255)[None].astype(np.uint8), K=Ks[0][None], RT=RT[0][None],
                      R0_snap=body["R"][None].astype(np.float32), Th0_snap=body["Th"].reshape(1, 3).astype(np.float32))
     return r, sd, batch, (c["H"], c["W"])
+
+
+# density lattice for mesh extraction (§8(f) rank 4): if_mesh_renderer.py over a coarse lattice of the capsule body
+MESH = dict(weights_seed=6, num_train_frame=5, body=_CAPSULE_BODY, step=0.025, latent_index=3,
+            weights_kw=dict(alpha_bias=1.0, alpha_scale=12.0))
+
+
+def build_mesh():
+    """-> (recipe, state_dict_np, batch_np with 'pts' [1,X,Y,Z,3] and 'inside' [1,X,Y,Z] — the keys of
+    multi_view_mesh_dataset.py:160-181)"""
+    r = MESH
+    sd = syn.make_weights(r["weights_seed"], num_train_frame=r["num_train_frame"], **r["weights_kw"])
+    body = syn.make_body(**r["body"])
+    pts, inside = syn.make_density_lattice(body, step=r["step"])
+    batch = {
+        "pts": pts[None], "inside": inside[None],
+        "coord": body["coord"][None].astype(np.int32), "out_sh": body["out_sh"][None].astype(np.int32),
+        "bounds": body["bounds"][None].astype(np.float32), "R": body["R"][None].astype(np.float32),
+        "Th": body["Th"][None].astype(np.float32), "latent_index": np.array([r["latent_index"]], np.int64),
+        "wbounds": body["can_bounds"][None].astype(np.float32), "frame_index": np.array([0], np.int64),
+    }
+    return r, sd, batch

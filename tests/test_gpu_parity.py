@@ -333,6 +333,47 @@ def test_mask_culled_renderers_match_reference(kind, precision):
     print("%s/%s: rgb L-inf vs reference %.2e, inside fraction %.2f" % (kind, precision, err, inside.mean()))
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_density_cube_matches_reference(precision, monkeypatch):
+    """RendererMesh (encoder + nb_decode_points(density_only) over the inside lattice points) against the cube the
+    reference's if_mesh_renderer hands to marching cubes (tests/golden/mesh_cube.npz)."""
+    import sys
+    import types
+
+    from neuralbody_amd.renderer import RenderConfig, RendererMesh
+
+    g = np.load(os.path.join(H.GOLDEN, "mesh_cube.npz"))
+    r, sd, batch = scenes.build_mesh()
+    net = H.make_network(sd, DEV, True, precision)
+    rend = RendererMesh(net, RenderConfig(mesh_th=5.0))
+    bd = H.device_batch(batch, DEV)
+    with torch.no_grad():
+        cube = rend.density_cube(bd)
+    torch.cuda.synchronize()
+    assert cube.is_cuda and tuple(cube.shape) == g["cube"].shape
+    err = H.assert_close(cube.cpu().numpy(), g["cube"], 2e-4, "cube")
+    # the iso-surface decision marching cubes makes is the same everywhere except within the tolerance of the threshold
+    ours, ref = cube.cpu().numpy() > 5.0, g["cube"] > 5.0
+    assert np.array_equal(ours[np.abs(g["cube"] - 5.0) > 1e-2], ref[np.abs(g["cube"] - 5.0) > 1e-2])
+    # render(): same dict as the reference (cube float64 ndarray + mesh); PyMCubes/trimesh are CPU post-processing and
+    # absent from the image, so they are stubbed here exactly as in make_golden.py::run_mesh
+    mc, tm = types.ModuleType("mcubes"), types.ModuleType("trimesh")
+    seen = {}
+
+    def marching_cubes(c, th):
+        seen["th"], seen["shape"] = th, c.shape
+        return np.zeros((0, 3)), np.zeros((0, 3), np.int64)
+
+    mc.marching_cubes = marching_cubes
+    tm.Trimesh = lambda v, t: ("mesh", len(v), len(t))
+    monkeypatch.setitem(sys.modules, "mcubes", mc)
+    monkeypatch.setitem(sys.modules, "trimesh", tm)
+    with torch.no_grad():
+        out = rend.render(bd)
+    assert set(out) == {"cube", "mesh"} and out["cube"].dtype == np.float64 and seen == {"th": 5.0, "shape": g["cube"].shape}
+    print("mesh cube/%s: max rel err vs reference %.2e over %d lattice points" % (precision, err, int(g["n_inside"])))
+
+
 # ------------------------------------------------------------------------------------------- ray generation
 def test_raygen_matches_reference_golden():
     from neuralbody_amd import ops

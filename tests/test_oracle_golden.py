@@ -122,3 +122,16 @@ def test_oracle_masked_renderers_match_reference_golden(kind, golden_dir):
     assert 0.2 < g["inside"].mean() < 0.8, "fixture does not exercise the culling"
     for k in ("rgb_map", "disp_map", "acc_map", "weights", "depth_map"):
         _close(out[k].numpy(), g[k], tol=2e-5 if k == "disp_map" else TOL, name=k)
+
+
+def test_oracle_density_cube_matches_reference_golden(golden_dir):
+    """oracle.density_cube against the reference's if_mesh_renderer cube (fixture made by make_golden.py::run_mesh)."""
+    g = np.load(os.path.join(golden_dir, "mesh_cube.npz"))
+    r, sd, batch = scenes.build_mesh()
+    assert _digest(sd, batch) == str(g["input_digest"]), "seeded inputs drifted from the fixture"
+    with torch.no_grad():
+        cube = orc.density_cube(orc.tensor_state_dict(sd), batch, training=True)
+    assert cube.shape == g["cube"].shape and cube.dtype == np.float64
+    assert int((cube != 0).sum()) <= int(g["n_inside"])
+    assert (g["cube"] > 5).sum() > 100 and (g["cube"] < 5).sum() > 100, "fixture does not straddle cfg.mesh_th"
+    _close(cube, g["cube"], tol=5e-5, name="cube")  # alpha_fc is scaled x12 in the recipe: fp32 summation-order noise

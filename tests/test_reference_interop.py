@@ -55,18 +55,20 @@ def test_plugins_resolve_through_reference_factories():
         net = ns.make_network(cfg)
         ren = ns.make_renderer(cfg, net)
         culled = {}
-        for kind in ("mmsk", "msk"):  # the novel-view overlays' renderers (latent_xyzc_313.yaml:95, snapshot_f3c.yaml:88)
-            cfg.renderer_module = "lib.networks.renderer.if_clight_renderer_%s_hip" % kind
-            cfg.renderer_path = os.path.join(PLUGINS, "if_clight_renderer_%s.py" % kind)
+        # the novel-view and mesh overlays' renderers (latent_xyzc_313.yaml:95,140-148, snapshot_f3c.yaml:88)
+        for kind, fname in (("mmsk", "if_clight_renderer_mmsk"), ("msk", "if_clight_renderer_msk"), ("mesh", "if_mesh_renderer")):
+            cfg.renderer_module = "lib.networks.renderer.%s_hip" % fname
+            cfg.renderer_path = os.path.join(PLUGINS, fname + ".py")
             culled[kind] = ns.make_renderer(cfg, net)
     finally:
         cfg.network_module, cfg.network_path, cfg.renderer_module, cfg.renderer_path = saved
         os.chdir(cwd)
     from neuralbody_amd.network import Network
-    from neuralbody_amd.renderer import Renderer, RendererMmsk, RendererMsk
+    from neuralbody_amd.renderer import Renderer, RendererMesh, RendererMmsk, RendererMsk
 
     assert isinstance(net, Network) and isinstance(ren, Renderer)
     assert isinstance(culled["mmsk"], RendererMmsk) and isinstance(culled["msk"], RendererMsk)
+    assert isinstance(culled["mesh"], RendererMesh) and culled["mesh"].cfg.mesh_th == cfg.mesh_th
     assert net.latent.weight.shape[0] == cfg.num_train_frame
     assert ren.cfg.N_samples == cfg.N_samples and ren.cfg.H == int(cfg.H * cfg.ratio)
     for name in ("encode_sparse_voxels", "calculate_density", "calculate_density_color", "forward"):
