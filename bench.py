@@ -153,6 +153,40 @@ def train_bench(args, dev):
                                              "GEMMs + HIP kernels, encoder HIP kernels) + clip_grad_value_(40) + Adam"}}))
 
 
+def turntable_bench(args, dev):
+    """Config 2/5 of BASELINE.json in synthetic form: a spiral camera path (gen_path) around the body, every view done
+    as nb_raygen -> Renderer.render (encoder + march) -> nb_image_assemble, i.e. finished images on the device with one
+    4-byte host sync per view.  Informational: prints its own JSON line."""
+    from neuralbody_amd import novel_view as nv
+    from neuralbody_amd import synthetic as syn
+
+    H = W = args.size
+    sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
+    K, R, T = syn.full_coverage_camera(body, H, W)
+    train = []
+    for yaw in (0.0, 0.8, 1.6, 2.4):
+        _, Rv, Tv = syn.full_coverage_camera(body, H, W, yaw=yaw)
+        train.append(np.concatenate([np.concatenate([Rv, Tv.reshape(3, 1)], 1), [[0, 0, 0, 1.0]]], 0))
+    path = nv.gen_path(train, args.steps + args.warmup, center=body["world_verts"].mean(0).astype(np.float64))
+    frame = {k: v for k, v in bd.items() if k in ("coord", "out_sh", "bounds", "R", "Th", "latent_index")}
+    nvr = nv.NovelViewRenderer(rend, H, W, dev)
+    rays = 0
+    for RT in path[:args.warmup]:
+        nvr.render_view(K, RT, body["can_bounds"], frame)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for RT in path[args.warmup:]:
+        rays += nvr.render_view(K, RT, body["can_bounds"], frame, bgr=True, scale=255.0)["n_rays"]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "turntable_views_per_sec", "value": args.steps / dt, "unit": "views/s", "higher_is_better": True,
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_view": dt / args.steps * 1e3,
+                      "rays_per_sec": rays / dt, "ray_samples_per_sec": rays * args.samples / dt,
+                      "mean_rays_per_view": rays / args.steps,
+                      "config": {"workload": "synthetic spiral path, %dx%d, %d samples/ray: raygen + encoder + march + image "
+                                             "assembly per view, all on device" % (H, W, args.samples)}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -162,7 +196,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
-    ap.add_argument("--mode", default="render", choices=["render", "train"])
+    ap.add_argument("--mode", default="render", choices=["render", "train", "turntable"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -188,6 +222,11 @@ def main():
         if world != 1:
             raise SystemExit("--mode train is a single-GPU informational run")
         train_bench(args, dev)
+        return
+    if args.mode == "turntable":
+        if world != 1:
+            raise SystemExit("--mode turntable is a single-GPU informational run (views shard with render_views_sharded)")
+        turntable_bench(args, dev)
         return
     H = W = args.size
     sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)

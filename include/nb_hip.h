@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 7
+#define NB_ABI_VERSION 8
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -282,6 +282,20 @@ int nb_enc_gather_codes(const float *codes, const int32_t *rows_vert, const int3
 int nb_raygen(int32_t H, int32_t W, const double K[9], const double R[9], const double T[3],
               const float bounds[6], float *ray_o, float *ray_d, float *near, float *far,
               uint8_t *mask_at_box, int32_t *n_rays, void *scratch, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * nb_image_assemble — replaces the image re-assembly of the demo visualizer
+ * (lib/visualizers/if_nerf_demo.py:15-30; same scatter in lib/evaluators/if_nerf.py:59-68):
+ *   img = white_bkgd ? 1 : 0;  img[mask_at_box] = rgb_map;  (optionally) img = img[..., ::-1];  img *= scale
+ *   depth = 0;  depth[mask_at_box] = depth_map
+ * on device, so a view leaves the GPU (or enters the all-gather) as a finished image.
+ *   mask_at_box dev [n_pixels] uint8; rgb_map dev [n_rays,3], depth_map dev [n_rays] or NULL — the
+ *   compacted per-ray outputs in pixel order (what nb_raygen + nb_march produce); img dev [n_pixels,3];
+ *   depth dev [n_pixels] or NULL (iff depth_map is NULL); scratch dev nb_scan_scratch_size(n_pixels) bytes.
+ *   Pixels whose compacted index is >= n_rays keep the background. */
+int nb_image_assemble(const uint8_t *mask_at_box, int64_t n_pixels, const float *rgb_map, const float *depth_map,
+                      int64_t n_rays, int white_bkgd, int bgr, float scale, float *img, float *depth, void *scratch,
+                      void *stream);
 
 #ifdef __cplusplus
 }

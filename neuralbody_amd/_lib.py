@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 7
+ABI_VERSION = 8
 PRECISIONS = {"f32": 0, "bf16x3": 1}
 
 
@@ -79,6 +79,7 @@ SIGNATURES = {
     "nb_enc_gather_codes": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_raygen": (C.c_int, [_I32, _I32, C.c_double * 9, C.c_double * 9, C.c_double * 3, C.c_float * 6, _P, _P, _P,
                             _P, _P, _P, _P, _P]),
+    "nb_image_assemble": (C.c_int, [_P, _I64, _P, _P, _I64, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -85,6 +85,32 @@ __global__ void ray_emit_kernel(RayCam c, int H, int W, const int *__restrict__ 
     far_out[r] = far;
 }
 
+__global__ void mask_flag_kernel(const uint8_t *__restrict__ mask, long long n, int *__restrict__ flags) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) flags[p] = mask[p] != 0;
+}
+
+// img[p] = mask[p] ? rgb_map[pos[p]] * scale : background; optional channel flip (the demo visualizer writes BGR)
+__global__ void image_assemble_kernel(const int *__restrict__ flags, const int *__restrict__ pos, long long n,
+                                      long long n_rays, const float *__restrict__ rgb_map,
+                                      const float *__restrict__ depth_map, float bkgd, int bgr, float scale,
+                                      float *__restrict__ img, float *__restrict__ depth) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float c[3] = {bkgd, bkgd, bkgd}, d = 0.f;
+    const long long r = pos[p];
+    if (flags[p] && r < n_rays) {
+        c[0] = rgb_map[r * 3 + 0];
+        c[1] = rgb_map[r * 3 + 1];
+        c[2] = rgb_map[r * 3 + 2];
+        if (depth_map) d = depth_map[r];
+    }
+    img[p * 3 + 0] = (bgr ? c[2] : c[0]) * scale;
+    img[p * 3 + 1] = c[1] * scale;
+    img[p * 3 + 2] = (bgr ? c[0] : c[2]) * scale;
+    if (depth) depth[p] = d;
+}
+
 bool inv3(const double *m, double *out) {
     const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
     const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
@@ -128,5 +154,26 @@ extern "C" int nb_raygen(int32_t H, int32_t W, const double K[9], const double R
     if (int rc = nb_exclusive_scan(flags, pos, n_rays, n, bs, st)) return rc;
     hipLaunchKernelGGL(ray_emit_kernel, grd, blk, 0, st, c, H, W, flags, pos, ray_o, ray_d, near, far);
     NB_CHECK_LAUNCH("nb_raygen");
+    return NB_OK;
+}
+
+extern "C" int nb_image_assemble(const uint8_t *mask_at_box, int64_t n_pixels, const float *rgb_map, const float *depth_map,
+                                 int64_t n_rays, int white_bkgd, int bgr, float scale, float *img, float *depth,
+                                 void *scratch, void *stream) {
+    NB_REQUIRE(n_pixels >= 0 && n_rays >= 0, "nb_image_assemble: n_pixels = %lld, n_rays = %lld", (long long)n_pixels,
+               (long long)n_rays);
+    if (n_pixels == 0) return NB_OK;
+    NB_REQUIRE(mask_at_box && img && scratch && (rgb_map || n_rays == 0), "nb_image_assemble: NULL pointer");
+    NB_REQUIRE((depth == nullptr) == (depth_map == nullptr) || n_rays == 0, "nb_image_assemble: depth and depth_map go together");
+    hipStream_t st = (hipStream_t)stream;
+    int *flags, *pos, *bs;
+    nb_scan_carve(scratch, n_pixels, &flags, &pos, &bs);
+    const dim3 grd(nb_ceil_div(n_pixels, 256)), blk(256);
+    hipLaunchKernelGGL(mask_flag_kernel, grd, blk, 0, st, mask_at_box, (long long)n_pixels, flags);
+    // the total lands in the block-sum area's spare slot: nobody needs it on the host
+    if (int rc = nb_exclusive_scan(flags, pos, bs + nb_scan_blocks(n_pixels), n_pixels, bs, st)) return rc;
+    hipLaunchKernelGGL(image_assemble_kernel, grd, blk, 0, st, flags, pos, (long long)n_pixels, (long long)n_rays, rgb_map,
+                       depth_map, white_bkgd ? 1.f : 0.f, bgr, scale, img, depth);
+    NB_CHECK_LAUNCH("nb_image_assemble");
     return NB_OK;
 }

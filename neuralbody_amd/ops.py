@@ -316,6 +316,27 @@ def raygen(H, W, K, R, T, bounds, device):
     return ray_o, ray_d, near, far, mask, n_rays
 
 
+def image_assemble(mask_at_box, rgb_map, depth_map=None, white_bkgd=False, bgr=False, scale=1.0):
+    """nb_image_assemble: mask_at_box [H*W] uint8/bool (any shape, flattened), rgb_map [n,3] and optional depth_map [n]
+    in compacted pixel order -> (img [H*W,3], depth [H*W] or None) on device."""
+    mask = mask_at_box.reshape(-1)
+    if mask.dtype == torch.bool:
+        mask = mask.to(torch.uint8)
+    _req(mask, torch.uint8, (None,), "mask_at_box")
+    _req(rgb_map, torch.float32, (None, 3), "rgb_map")
+    n_pix, n = mask.shape[0], rgb_map.shape[0]
+    if depth_map is not None:
+        _req(depth_map, torch.float32, (n,), "depth_map")
+    img = torch.empty((n_pix, 3), dtype=torch.float32, device=mask.device)
+    depth = torch.empty(n_pix, dtype=torch.float32, device=mask.device) if depth_map is not None else None
+    scratch = scan_scratch(n_pix, mask.device)
+    with torch.cuda.device(mask.device):
+        check(_lib.lib().nb_image_assemble(ptr(mask), n_pix, ptr(rgb_map), ptr(depth_map), n, 1 if white_bkgd else 0,
+                                           1 if bgr else 0, float(scale), ptr(img), ptr(depth), ptr(scratch), _stream()),
+              "nb_image_assemble")
+    return img, depth
+
+
 def tile_order(pix, width, tile_w=8, tile_h=4):
     """Permutation (int32) that groups rays into tile_w x tile_h pixel tiles: `pix` are the linear pixel
     ids (row-major, image `width`) of the rays.  32 consecutive slots = one wavefront = one compact tile, so

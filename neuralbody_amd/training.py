@@ -173,8 +173,19 @@ class RenderFunction(torch.autograd.Function):
         return (None, None, None) + tuple(out)
 
 
+MAX_TAP_BYTES = 32 * 2 ** 30  # activation tap kept for the backward pass (ops.DBG_WIDTH floats per sample)
+
+
 def render_train(renderer, batch, t_rand=None):
     """Renderer.render with gradients: same output dict, rgb_map carries the autograd graph."""
+    n_points = batch["ray_o"].shape[1] * renderer.cfg.N_samples
+    tap_bytes = n_points * ops.DBG_WIDTH * 4
+    if tap_bytes > MAX_TAP_BYTES:
+        raise RuntimeError(
+            "differentiable render of %d rays x %d samples would keep %.1f GiB of activations for the backward pass "
+            "(limit %.0f GiB, neuralbody_amd.training.MAX_TAP_BYTES). Training batches are cfg.N_rand = 1024 rays "
+            "(if_nerf_clight.py); full-image inference must run under torch.no_grad() as run.py:66,98 does."
+            % (batch["ray_o"].shape[1], renderer.cfg.N_samples, tap_bytes / 2 ** 30, MAX_TAP_BYTES / 2 ** 30))
     params = [p for _, p in renderer.net.named_parameters()]
     rgb, disp, acc, weights, depth = RenderFunction.apply(renderer, batch, t_rand, *params)
     return {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": weights, "depth_map": depth}

@@ -174,6 +174,66 @@ def run_mesh():
           (cube.min(), cube.max(), (cube > 5).sum()), "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def _cv2_rodrigues(x):
+    """Stand-in for cv2.Rodrigues (cv2 is absent): vector -> matrix or matrix -> vector, returned as cv2 does in a tuple."""
+    from neuralbody_amd.novel_view import rodrigues
+
+    x = np.asarray(x, np.float64)
+    if x.size == 3:
+        return (rodrigues(x.reshape(3)), None)
+    th = np.arccos(np.clip((np.trace(x) - 1) / 2, -1, 1))
+    axis = np.array([x[2, 1] - x[1, 2], x[0, 2] - x[2, 0], x[1, 0] - x[0, 1]]) / (2 * np.sin(th))
+    return ((axis * th).reshape(3, 1), None)
+
+
+def run_novel():
+    """Host camera / pose algebra of the novel-view loop, executed by the UNMODIFIED reference:
+    render_utils.load_cam + gen_path (both `center` variants) and monocular_demo_dataset.Dataset.prepare_input."""
+    import importlib
+    import tempfile
+    import types
+
+    ns = rh.load()
+    cfg = ns.cfg
+    r, body, cams, center = scenes.build_novel()
+    ru = importlib.import_module("lib.utils.render_utils")
+    g = {}
+    saved = (cfg.ratio, cfg.num_render_views, list(cfg.voxel_size))
+    with tempfile.TemporaryDirectory() as tmp:
+        ann = os.path.join(tmp, "annots.npy")
+        np.save(ann, {"cams": cams}, allow_pickle=True)
+        cfg.ratio, cfg.num_render_views = r["ratio"], r["num_render_views"]
+        try:
+            K, RT = ru.load_cam(ann)
+            g["load_cam/K"], g["load_cam/RT"] = np.array(K), np.array(RT)
+            g["gen_path/auto"] = np.array(ru.gen_path([m.copy() for m in RT]))
+            g["gen_path/center"] = np.array(ru.gen_path([m.copy() for m in RT], center.copy()))
+            # rotating-SMPL frames: the dataset class without its file-reading constructor
+            for name in ("imageio", "plyfile"):
+                sys.modules.setdefault(name, types.ModuleType(name))
+            sys.modules["plyfile"].PlyData = object
+            sys.modules["cv2"].Rodrigues = _cv2_rodrigues
+            mod = importlib.import_module("lib.datasets.light_stage.monocular_demo_dataset")
+            ds = object.__new__(mod.Dataset)
+            ds.data_root = tmp
+            ds.ts = np.arange(0, np.pi * 2, np.pi / 72)
+            rvec = _cv2_rodrigues(body["R"])[0].reshape(3)
+            ds.params = {"pose": [np.concatenate([rvec, np.zeros(69)])], "trans": [body["Th"].reshape(3).astype(np.float64)]}
+            os.makedirs(os.path.join(tmp, "vertices"))
+            np.save(os.path.join(tmp, "vertices", "0.npy"), body["world_verts"].astype(np.float32))
+            g["turntable/rvec"] = rvec
+            for step in r["turntable_steps"]:
+                coord, out_sh, can_bounds, bounds, Rh, Th = ds.prepare_input(0, step)
+                R = _cv2_rodrigues(Rh)[0].astype(np.float32)  # monocular_demo_dataset.py:125
+                for k, v in (("coord", coord), ("out_sh", out_sh), ("can_bounds", can_bounds), ("bounds", bounds), ("R", R), ("Th", Th)):
+                    g["turntable/%d/%s" % (step, k)] = v
+        finally:
+            cfg.ratio, cfg.num_render_views, cfg.voxel_size = saved
+    path = os.path.join(OUT, "novel_view.npz")
+    np.savez_compressed(path, **g)
+    print("novel view:", {k: v.shape for k, v in g.items() if "turntable" not in k}, "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 def run_train_step():
     """One training step of the UNMODIFIED reference (NetworkWrapper, lib/train/trainers/if_nerf_clight.py:18-36) on CPU:
     loss and, for every parameter, the gradient's L2 norm, sum and a few probe entries."""
@@ -206,7 +266,7 @@ def run_train_step():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh"]
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh", "novel"]
     for n in names:
         if n == "raygen":
             run_raygen()
@@ -214,6 +274,8 @@ if __name__ == "__main__":
             run_train_step()
         elif n == "mesh":
             run_mesh()
+        elif n == "novel":
+            run_novel()
         elif n in ("mmsk", "msk"):
             run_masked(n)
         else:

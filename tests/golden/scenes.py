@@ -137,3 +137,23 @@ def build_mesh():
         "wbounds": body["can_bounds"][None].astype(np.float32), "frame_index": np.array([0], np.int64),
     }
     return r, sd, batch
+
+
+# novel-view driving (§8(f) rank 3): training cameras for gen_path / load_cam, a posed body for the rotating-SMPL frames
+NOVEL = dict(body=dict(seed=8, box=(0.45, 0.85, 0.18), rh=(0.3, -0.5, 0.2), th=(0.1, 0.05, 1.9), layout="capsules"),
+             n_cams=5, num_render_views=6, ratio=0.5, turntable_steps=(0, 17, 100))
+
+
+def build_novel():
+    """-> (recipe, body, cams dict as stored in the datasets' annots (K, R, T in millimetres), center)"""
+    r = NOVEL
+    body = syn.make_body(**r["body"])
+    cams = {"K": [], "R": [], "T": []}
+    for v in range(r["n_cams"]):
+        K, R, T = syn.make_camera(body, 96, 128, focal_factor=1.4, distance=2.2 + 0.1 * v, yaw=-0.9 + 0.45 * v,
+                                  pitch=0.05 * ((v % 3) - 1))
+        cams["K"].append(K.tolist())
+        cams["R"].append(R.tolist())
+        cams["T"].append((T.reshape(3, 1) * 1000.0).tolist())
+    center = body["world_verts"].mean(0).astype(np.float64)
+    return r, body, cams, center
