@@ -39,6 +39,8 @@ PRECISION_INFO = {
     "f32": ("f32", "nb_march_kernel", 663296.0, 157.3),
     # the same layers as 1944 v_mfma_f32_32x32x16_bf16 per 32 samples (bf16 hi/lo split: 3 products, K padded to 16)
     "bf16x3": ("bf16", "nb_march16_kernel", 1944 * 32768 / 32.0, 2500.0),
+    # M-split organisation of the same arithmetic: 4 waves x 984 MFMAs per 64 samples (encoding K padded to 128)
+    "bf16x3s": ("bf16", "nb_march16s_kernel", 4 * 984 * 32768 / 64.0, 2500.0),
 }
 
 
@@ -195,7 +197,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3"])
+    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3", "bf16x3s"])
     ap.add_argument("--mode", default="render", choices=["render", "train", "turntable"])
     args = ap.parse_args()
 
@@ -282,7 +284,9 @@ def main():
                    "rays_per_view": n_rays, "out_sh": [int(s) for s in body["out_sh"]],
                    "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                   "bf16x3": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
-                                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate"}[net.precision],
+                                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate",
+                                  "bf16x3s": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
+                                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate (M-split workgroups)"}[net.precision],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
@@ -294,7 +298,7 @@ def main():
                              "the kernel issues %.0f MFMA flop/sample (merged feature_fc.latent_fc layer%s), so "
                              "executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~219 MB/launch "
                              "(<0.1%% of the launch time at 8 TB/s)"
-                             % (n_rays * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.precision == "bf16x3" else "")},
+                             % (n_rays * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.precision != "f32" else "")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         with torch.no_grad():

@@ -35,6 +35,8 @@ extern "C" {
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
 #define NB_PREC_BF16X3 1 /* bf16 hi+lo split of both operands, 3 products on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+#define NB_PREC_BF16X3S 2 /* nb_march only: the same arithmetic, workgroup organised by output-feature quarters
+                             (activations in LDS, weights straight from L2, two workgroups per CU) */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */

@@ -195,6 +195,10 @@ __device__ __forceinline__ void load_pair(const Ring &rg, int k, Frag4 &f) {
 #endif
     const int page = rec / PAGE_RECS, slot = page % N_SLOTS;
     const int addr = rg.base[slot] + (rec % PAGE_RECS) * REC_BYTES;  // lane * 16 + slot base + record offset
+#ifdef NB_ABL_NOLDS
+    asm volatile("" : "=v"(f.ah0), "=v"(f.al0), "=v"(f.ah1), "=v"(f.al1) : "v"(addr));
+    return;
+#endif
     // one statement: four reads of two consecutive records (A_hi, A_lo of tile t0, then of tile t1)
     asm volatile(
         "ds_read_b128 %0, %4\n\t"
@@ -209,8 +213,34 @@ __device__ __forceinline__ void load_pair(const Ring &rg, int k, Frag4 &f) {
 // wait until the fragments in `f` have landed while the NEWER reads (4 of them, or none) may stay in flight
 template <int NEWER>
 __device__ __forceinline__ void wait_pair(Frag4 &f) {
+#ifdef NB_ABL_NOLGKM
+    asm volatile("" : "+v"(f.ah0), "+v"(f.al0), "+v"(f.ah1), "+v"(f.al1));
+#else
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(f.ah0), "+v"(f.al0), "+v"(f.ah1), "+v"(f.al1) : "n"(NEWER));
+#endif
 }
+
+#ifdef NB_LDS_SPREAD
+// Spread variant: the four fragment reads of the NEXT record pair are issued one at a time in the shadow of the
+// first four MFMAs of the current pair (consumption order A_hi0, A_hi1, A_lo0, A_lo1) instead of as one burst: the
+// four waves of a workgroup run in lock step, so bursts of 16 x 1 KiB back up the LDS queue and the in-order wave
+// blocks on the read issue with the matrix pipe idle (measured: removing the reads saves 4.2 of 20.7 ms).
+template <int REC0>
+__device__ __forceinline__ int pair_addr(const Ring &rg, int k) {
+    const int rec = REC0 + 2 * k;
+    if (rec % PAGE_RECS == 0) turn_page(rg, rec / PAGE_RECS);
+    const int page = rec / PAGE_RECS, slot = page % N_SLOTS;
+    return rg.base[slot] + (rec % PAGE_RECS) * REC_BYTES;
+}
+template <int OFF>
+__device__ __forceinline__ void read_frag(bf16x8 &dst, int addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=&v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int NEWER>
+__device__ __forceinline__ void wait_frag(bf16x8 &f) {
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(f) : "n"(NEWER));
+}
+#endif
 
 // INIT: start the NT accumulator tiles from the bias; otherwise continue accumulating into `acc`
 // (a layer whose K range is consumed in several phases: fc_0 level by level, view_fc in two parts).
@@ -220,7 +250,17 @@ __device__ __forceinline__ void mlp_layer16(const Ring &rg, const float *bp, f32
     const int hi = rg.lane >> 5;
     constexpr int NP = NT / 2 * NC;
     Frag4 buf[2];
+#ifdef NB_LDS_SPREAD
+    {
+        const int a0 = pair_addr<REC0>(rg, 0);
+        read_frag<0>(buf[0].ah0, a0);
+        read_frag<2048>(buf[0].ah1, a0);
+        read_frag<1024>(buf[0].al0, a0);
+        read_frag<3072>(buf[0].al1, a0);
+    }
+#else
     load_pair<REC0>(rg, 0, buf[0]);
+#endif
     f32x16 c0, c1;
 #pragma unroll
     for (int tp = 0; tp < NT / 2; ++tp) {
@@ -235,6 +275,37 @@ __device__ __forceinline__ void mlp_layer16(const Ring &rg, const float *bp, f32
         for (int c = 0; c < NC; ++c) {
             const int k = tp * NC + c;
             Frag4 &cur = buf[k & 1];
+#ifdef NB_LDS_SPREAD
+            Frag4 &nxt = buf[(k + 1) & 1];
+            constexpr int dummy = 0;
+            (void)dummy;
+            const bool more = k + 1 < NP;
+            int an = 0;
+            if (more) an = pair_addr<REC0>(rg, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // outstanding reads at this point: this pair's four (oldest first: hi0, hi1, lo0, lo1)
+            wait_frag<3>(cur.ah0);
+            c0 = NB_MFMA16(cur.ah0, xh[c], c0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) read_frag<0>(nxt.ah0, an);
+            if (more) wait_frag<3>(cur.ah1); else wait_frag<2>(cur.ah1);
+            c1 = NB_MFMA16(cur.ah1, xh[c], c1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) read_frag<2048>(nxt.ah1, an);
+            c0 = NB_MFMA16(cur.ah0, xl[c], c0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) read_frag<1024>(nxt.al0, an);
+            c1 = NB_MFMA16(cur.ah1, xl[c], c1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) read_frag<3072>(nxt.al1, an);
+            if (more) wait_frag<5>(cur.al0); else wait_frag<1>(cur.al0);
+            c0 = NB_MFMA16(cur.al0, xh[c], c0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) wait_frag<4>(cur.al1); else wait_frag<0>(cur.al1);
+            c1 = NB_MFMA16(cur.al1, xh[c], c1);
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+#endif
             if (k + 1 < NP) {
                 load_pair<REC0>(rg, k + 1, buf[(k + 1) & 1]);
                 wait_pair<4>(cur);

@@ -553,5 +553,9 @@ long long bf16_stream_floats();
 int pack_bf16_stream(const nb_mlp_params *p, float *packed, hipStream_t st);
 int launch_points_bf16(const MarchArgs &a, int density_only, hipStream_t st);
 int launch_march_bf16(const MarchArgs &a, hipStream_t st);
+// M-split split-bf16 march (nb_march_msplit.hip); stream_off = float offset of its weight stream inside the packed blob
+long long msplit_stream_floats();
+int pack_msplit_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
+int launch_march_msplit(MarchArgs a, long long stream_off, hipStream_t st);
 
 }  // namespace nbm

@@ -120,8 +120,8 @@ class Network(nn.Module):
         # decoder GEMM arithmetic: "bf16x3" (split-bf16 MFMA, 3 products, fp32 accumulate) or "f32" (exact
         # fp32 MFMA); both stay inside the 1e-4 RGB parity budget, see DESIGN.md
         self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
-        if self.precision not in ("f32", "bf16x3"):
-            raise ValueError("precision must be 'f32' or 'bf16x3'")
+        if self.precision not in ("f32", "bf16x3", "bf16x3s"):
+            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16x3s'")
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -149,6 +149,10 @@ class Network(nn.Module):
             d[short + "_w"] = m.weight
             d[short + "_b"] = m.bias
         return d
+
+    def _point_precision(self):
+        """nb_decode_points has two kernel families; 'bf16x3s' only changes how nb_march is organised."""
+        return "bf16x3" if self.precision == "bf16x3s" else self.precision
 
     def packed_weights(self):
         """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed."""
@@ -213,7 +217,7 @@ class Network(nn.Module):
             raise NotImplementedError("batch size 1 only")
         p = wpts.reshape(-1, 3).float().contiguous()
         out = ops.decode_points(scene, self.packed_weights(), None, p, None, density_only=True,
-                                precision=self.precision)
+                                precision=self._point_precision())
         return out.view(1, -1, 1)
 
     def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
@@ -223,7 +227,7 @@ class Network(nn.Module):
         p = wpts.reshape(-1, 3).float().contiguous()
         v = viewdir.reshape(-1, 3).float().contiguous()
         lb = self.latent_bias(sp_input["latent_index"])
-        out = ops.decode_points(scene, self.packed_weights(), lb, p, v, precision=self.precision)
+        out = ops.decode_points(scene, self.packed_weights(), lb, p, v, precision=self._point_precision())
         return out.view(1, -1, 4)
 
     def forward(self, sp_input, grid_coords, viewdir, light_pts):

@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 ALL = list(scenes.SCENES)
-PRECISIONS = ["f32", "bf16x3"]
+PRECISIONS = ["f32", "bf16x3", "bf16x3s"]  # nb_march kernel families
+POINT_PRECISIONS = ["f32", "bf16x3"]  # nb_decode_points kernel families ("bf16x3s" only reorganises the march)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -43,7 +44,7 @@ def _scene_with_oracle_volumes(name, precision="f32"):
 
 
 # ------------------------------------------------------------------------------------------- decode
-@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("precision", POINT_PRECISIONS)
 def test_decode_points_stages_against_oracle(precision):
     """nb_decode_points with the debug tap: gathered features (K3/K4), fc_2 output (K5), the merged
     feature/latent layer, view_fc hidden (K6/K7) and raw, each against the oracle."""
@@ -333,7 +334,7 @@ def test_mask_culled_renderers_match_reference(kind, precision):
     print("%s/%s: rgb L-inf vs reference %.2e, inside fraction %.2f" % (kind, precision, err, inside.mean()))
 
 
-@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("precision", POINT_PRECISIONS)
 def test_density_cube_matches_reference(precision, monkeypatch):
     """RendererMesh (encoder + nb_decode_points(density_only) over the inside lattice points) against the cube the
     reference's if_mesh_renderer hands to marching cubes (tests/golden/mesh_cube.npz)."""

@@ -1,6 +1,6 @@
-import sys, time, types
+import os, sys, time, types
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from neuralbody_amd import novel_view as nv, synthetic as syn, ops
 dev = torch.device("cuda:0")
