@@ -45,8 +45,12 @@ __device__ __forceinline__ void split4(const float *v, u32x2 &h, u32x2 &l) {
 }
 
 // one layer for this wave: MT m-tiles x 2 n-tiles, NC chunks; weights = fragments F0.. of the wave's stream
+#ifndef SIDE
+#define SIDE 0
+#endif
 template <int F0, int MT, int NC>
-__device__ __forceinline__ void layer(const char *wl, char *act, int lane, bf16x8 (&ring)[R], f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void layer(const char *wl, char *act, int lane, bf16x8 (&ring)[R], f32x16 (&acc)[2][2],
+                                      float (&side)[8], float sx) {
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -82,12 +86,45 @@ __device__ __forceinline__ void layer(const char *wl, char *act, int lane, bf16x
             ring[f % R] = *reinterpret_cast<const bf16x8 *>(wl + (size_t)((f + R) % F_TOTAL) * 1024);
             ring[(f + 1) % R] = *reinterpret_cast<const bf16x8 *>(wl + (size_t)((f + 1 + R) % F_TOTAL) * 1024);
 #endif
+#ifdef HAND
+#define FILL(k)                                                                                                    \
+    {                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+        _Pragma("unroll") for (int q = 0; q < HAND; ++q)                                                           \
+            asm volatile("v_fma_f32 %0, %0, %1, %2"                                                               \
+                         : "+v"(side[((k) * HAND + q) & 7])                                                        \
+                         : "v"(sx), "v"(side[((k) * HAND + q + 3) & 7]));                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                         \
+    }
+            acc[m][0] = MFMA(ah, bh[cur][0], acc[m][0]);
+            FILL(0)
+            acc[m][1] = MFMA(ah, bh[cur][1], acc[m][1]);
+            FILL(1)
+            acc[m][0] = MFMA(ah, bl[cur][0], acc[m][0]);
+            FILL(2)
+            acc[m][1] = MFMA(ah, bl[cur][1], acc[m][1]);
+            FILL(3)
+            acc[m][0] = MFMA(al, bh[cur][0], acc[m][0]);
+            FILL(4)
+            acc[m][1] = MFMA(al, bh[cur][1], acc[m][1]);
+            FILL(5)
+#else
             acc[m][0] = MFMA(ah, bh[cur][0], acc[m][0]);
             acc[m][1] = MFMA(ah, bh[cur][1], acc[m][1]);
             acc[m][0] = MFMA(ah, bl[cur][0], acc[m][0]);
             acc[m][1] = MFMA(ah, bl[cur][1], acc[m][1]);
             acc[m][0] = MFMA(al, bh[cur][0], acc[m][0]);
             acc[m][1] = MFMA(al, bh[cur][1], acc[m][1]);
+#pragma unroll
+            for (int q = 0; q < SIDE; ++q) side[q & 7] = fmaf(side[q & 7], sx, side[(q + 3) & 7]);
+#ifdef INTERLEAVE
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SIDE / 6, 0);
+            }
+#endif
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -142,6 +179,10 @@ __global__ __launch_bounds__(256, WGPC) void core_kernel(Args a) {
     for (int i = 0; i < R; ++i) ring[i] = *reinterpret_cast<const bf16x8 *>(wl + (size_t)i * 1024);
     f32x16 acc[2][2];
     float sum = 0.f;
+    float side[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) side[q] = 0.001f * (float)(threadIdx.x + q);
+    const float sx = 0.999f + 1e-6f * (float)(threadIdx.x & 3);
 #ifdef STAGGER
     if ((blockIdx.x >> 8) & 1)
         for (int i = 0; i < STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
@@ -151,17 +192,19 @@ __global__ __launch_bounds__(256, WGPC) void core_kernel(Args a) {
         asm volatile("" : "+s"(zero));
         const char *w2 = wl + zero;
         constexpr int FA = 0, FB = FA + 4 * NCH0, FC = FB + 4 * NCH, FD = FC + 4 * NCH, FE = FD + 4 * NCH;
-        layer<FA, 2, NCH0>(w2, act, lane, ring, acc);
+        layer<FA, 2, NCH0>(w2, act, lane, ring, acc, side, sx);
         publish<2>(act, lane, wave, acc);
-        layer<FB, 2, NCH>(w2, act, lane, ring, acc);
+        layer<FB, 2, NCH>(w2, act, lane, ring, acc, side, sx);
         publish<2>(act, lane, wave, acc);
-        layer<FC, 2, NCH>(w2, act, lane, ring, acc);
+        layer<FC, 2, NCH>(w2, act, lane, ring, acc, side, sx);
         publish<2>(act, lane, wave, acc);
-        layer<FD, 2, NCH>(w2, act, lane, ring, acc);
+        layer<FD, 2, NCH>(w2, act, lane, ring, acc, side, sx);
         publish<2>(act, lane, wave, acc);
-        layer<FE, 1, NCHV>(w2, act, lane, ring, acc);
+        layer<FE, 1, NCHV>(w2, act, lane, ring, acc, side, sx);
         publish<1>(act, lane, wave, acc);
         sum += acc[0][0][0] + acc[0][1][5];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) sum += side[q];
     }
     a.out[(size_t)blockIdx.x * 256 + threadIdx.x] = sum;
 }
