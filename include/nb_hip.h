@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 8
+#define NB_ABI_VERSION 9
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -260,10 +260,12 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
                           const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3], int32_t stride,
                           const float *weight, int32_t cin, int32_t cout, float *din, void *stream);
 
-/* Gradient of the conv weight [3,3,3,Cin,Cout] (zeroed by the call): dW[o] = sum_r in[nbr(r,o)]^T (x) dx[r]. */
+/* Gradient of the conv weight [3,3,3,Cin,Cout] (zeroed by the call): dW[o] = sum_r in[nbr(r,o)]^T (x) dx[r].
+ * rulebook: dev int32 scratch [n_out_max * 27] (receives nbr(r,o), -1 = no active input voxel). */
 int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3],
                            const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3],
-                           int32_t stride, const float *dx, int32_t cin, int32_t cout, float *dweight, void *stream);
+                           int32_t stride, const float *dx, int32_t cin, int32_t cout, float *dweight,
+                           int32_t *rulebook, void *stream);
 
 /* Embedding-lookup backward: dcodes[rows_vert[r], :] = drows[r, :] (dcodes zeroed by the caller). */
 int nb_enc_scatter_codes_bwd(const float *drows, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2}
 
 
@@ -74,7 +74,7 @@ SIGNATURES = {
     "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "nb_enc_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
     "nb_enc_conv_bwd_input": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P]),
-    "nb_enc_conv_bwd_weight": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P]),
+    "nb_enc_conv_bwd_weight": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _P]),
     "nb_enc_scatter_codes_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_enc_gather_codes": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_raygen": (C.c_int, [_I32, _I32, C.c_double * 9, C.c_double * 9, C.c_double * 3, C.c_float * 6, _P, _P, _P,

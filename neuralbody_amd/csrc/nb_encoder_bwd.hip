@@ -144,15 +144,33 @@ __global__ __launch_bounds__(256) void conv_bwd_in_kernel(const float *__restric
 }
 
 // ------------------------------------------------------------------ conv backward w.r.t. the weights
+// rule book: nbr[row * 27 + o] = input row read by output row `row` under kernel offset o, or -1.  Built once per layer
+// call; the weight-gradient kernel then spends its issue slots on loads and MFMAs instead of redoing the integer
+// divisions of the voxel index for every (offset, channel tile) pair (measured: 3.9 -> see DESIGN.md §4.4).
+__global__ void conv_rulebook_kernel(const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
+                                     const int *__restrict__ n_out, Dims go, int stride, int *__restrict__ nbr) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *n_out;
+    if (idx >= (long long)n * 27) return;
+    const int row = (int)(idx / 27), o = (int)(idx % 27);
+    const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+    const int lin = out_lin[row];
+    const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
+    const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
+    int v = -1;
+    if ((unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
+        v = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+    nbr[idx] = v;
+}
+
 // one wave = (offset o, ci tile, co tile, chunk of ROWS_PER_WAVE output rows); D[ci][co] += sum_rows in^T dx
 constexpr int ROWS_PER_WAVE = 256;
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float *__restrict__ in_rows, const int *__restrict__ in_grid,
-                                                         Dims gi, const int *__restrict__ out_lin,
-                                                         const int *__restrict__ n_out, Dims go, int stride,
-                                                         const float *__restrict__ dx, float *__restrict__ dw) {
-    constexpr int TI = (CIN + 31) / 32, TO = (COUT + 31) / 32;
+__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float *__restrict__ in_rows, const int *__restrict__ nbr,
+                                                         const int *__restrict__ n_out, const float *__restrict__ dx,
+                                                         float *__restrict__ dw) {
+    constexpr int TO = (COUT + 31) / 32;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);  // row chunk
     const int o = blockIdx.y;                               // kernel offset 0..26
@@ -160,30 +178,30 @@ __global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float *__restrict
     const int n = *n_out;
     const int row0 = wave * ROWS_PER_WAVE;
     if (row0 >= n) return;
-    const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
     const int ci = ti * 32 + i, co = to * 32 + i;
     const bool ciok = (CIN % 32 == 0) || ci < CIN, cook = (COUT % 32 == 0) || co < COUT;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     bool any = false;
-    for (int m = 0; m < ROWS_PER_WAVE / 2; ++m) {
-        const int row = row0 + 2 * m + hi;  // this half-wave's row of the K=2 chunk
-        float a = 0.f, b = 0.f;
-        if (row < n) {
-            const int lin = out_lin[row];
-            const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
-            const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
-            if ((unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w) {
-                const int nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
-                if (nbr >= 0) {
-                    if (ciok) a = in_rows[(size_t)nbr * CIN + ci];
-                    if (cook) b = dx[(size_t)row * COUT + co];
+    for (int m0 = 0; m0 < ROWS_PER_WAVE / 2; m0 += 8) {  // 8 K=2 chunks per round: all loads issued before the MFMAs
+        float a[8], b[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = row0 + 2 * (m0 + q) + hi;  // this half-wave's row of the K=2 chunk
+            a[q] = 0.f;
+            b[q] = 0.f;
+            if (row < n) {
+                const int nb = nbr[(size_t)row * 27 + o];
+                if (nb >= 0) {
+                    if (ciok) a[q] = in_rows[(size_t)nb * CIN + ci];
+                    if (cook) b[q] = dx[(size_t)row * COUT + co];
                     any = true;
                 }
             }
         }
-        acc = NB_MFMA(a, b, acc);  // D[i = ci][j = co] += A[ci][k = row] B[k = row][co]
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = NB_MFMA(a[q], b[q], acc);  // D[i = ci][j = co] += A[ci][k = row] B[k = row][co]
     }
     if (!__any(any)) return;
     // D fragment: lane (j = co column, hi) holds rows ci_local = tile_row(r, hi)
@@ -217,7 +235,9 @@ int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const in
     NB_REQUIRE(c > 0 && n_rows_max >= 0, "nb_enc_bn_relu_bwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     NB_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), st));
-    const int slabs = n_rows_max < 2048 ? 1 : (n_rows_max / 512 < 128 ? n_rows_max / 512 : 128);
+    // 128 rows per block (32 per row lane): the deep levels have ~13 k rows x 128 channels, and a grid of a few dozen
+    // blocks looping over hundreds of rows each ran at 150 us per layer, latency bound
+    const int slabs = n_rows_max <= 128 ? 1 : (int)(nb_ceil_div(n_rows_max, 128) < 2048 ? nb_ceil_div(n_rows_max, 128) : 2048);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb_ceil_div(c, 64), slabs), dim3(256), 0, st, dy, y, x, n_rows, c,
                        batch_stats, eps, sums);
     const long long total = (long long)n_rows_max * c;
@@ -253,19 +273,22 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
 
 int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3], const int32_t *out_lin,
                            const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride,
-                           const float *dx, int32_t cin, int32_t cout, float *dweight, void *stream) {
+                           const float *dx, int32_t cin, int32_t cout, float *dweight, int32_t *rulebook, void *stream) {
     NB_REQUIRE(in_rows && in_grid && in_dhw && out_lin && n_out && out_dhw && dx && dweight,
                "nb_enc_conv_bwd_weight: NULL pointer");
     NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv_bwd_weight: stride %d", stride);
     hipStream_t st = (hipStream_t)stream;
     NB_HIP(hipMemsetAsync(dweight, 0, (size_t)27 * cin * cout * sizeof(float), st));
     if (n_out_max <= 0) return NB_OK;
+    NB_REQUIRE(rulebook != nullptr, "nb_enc_conv_bwd_weight: rulebook scratch is NULL");
     const Dims go = {out_dhw[0], out_dhw[1], out_dhw[2]}, gi = {in_dhw[0], in_dhw[1], in_dhw[2]};
+    hipLaunchKernelGGL(conv_rulebook_kernel, dim3(nb_ceil_div((long long)n_out_max * 27, 256)), dim3(256), 0, st, in_grid, gi,
+                       out_lin, n_out, go, stride, rulebook);
 #define X(CI, CO)                                                                                                     \
     if (cin == CI && cout == CO) {                                                                                    \
         hipLaunchKernelGGL((conv_bwd_w_kernel<CI, CO>),                                                               \
                            dim3(nb_ceil_div(n_out_max, 4 * ROWS_PER_WAVE), 27, ((CI + 31) / 32) * ((CO + 31) / 32)),  \
-                           dim3(256), 0, st, in_rows, in_grid, gi, out_lin, n_out, go, stride, dx, dweight);          \
+                           dim3(256), 0, st, in_rows, rulebook, n_out, dx, dweight);                                   \
         NB_CHECK_LAUNCH("nb_enc_conv_bwd_weight");                                                                    \
         return NB_OK;                                                                                                 \
     }

@@ -325,6 +325,106 @@ __device__ __forceinline__ void mlp_layer16(const Ring &rg, const float *bp, f32
     }
 }
 
+// ---- in-flight operand conversion (NB_CV_INTERLEAVE) -------------------------------------------------------------
+// The relu + hi/lo split of a finished tile pair is cut into two-value slices (~9 VALU) and placed by hand, fenced with
+// sched_barrier, in the MFMA gaps of the NEXT tile pair of the same layer (measured: fillers fenced in place are about
+// two-thirds hidden up to 5 per gap, while anything left to the scheduler clusters and costs its full issue time).
+// Only the last tile pair's conversion stays exposed.  Operands are kept as packed words: word (2t + (r>>3))*4 +
+// ((r&7)>>1) holds the bf16 pair of accumulator registers (r, r+1) of tile t = elements of K chunk 2t + (r>>3).
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2s __attribute__((ext_vector_type(2)));
+struct PackedOps {
+    unsigned h[64], l[64];
+};
+__device__ __forceinline__ bf16x8 ops_hi(const PackedOps &p, int c) {
+    return __builtin_bit_cast(bf16x8, u32x4s{p.h[4 * c], p.h[4 * c + 1], p.h[4 * c + 2], p.h[4 * c + 3]});
+}
+__device__ __forceinline__ bf16x8 ops_lo(const PackedOps &p, int c) {
+    return __builtin_bit_cast(bf16x8, u32x4s{p.l[4 * c], p.l[4 * c + 1], p.l[4 * c + 2], p.l[4 * c + 3]});
+}
+template <bool RELU>
+__device__ __forceinline__ void cv_slice(const f32x16 &src, int t, int j, PackedOps &o) {  // registers (2j, 2j+1) of tile t
+    float x0 = src[2 * j], x1 = src[2 * j + 1];
+    if (RELU) {
+        x0 = relu1(x0);
+        x1 = relu1(x1);
+    }
+#ifdef NB_ABL_NOCONV
+    o.h[(2 * t + (j >> 2)) * 4 + (j & 3)] = __float_as_uint(x0);
+    o.l[(2 * t + (j >> 2)) * 4 + (j & 3)] = __float_as_uint(x1);
+    return;
+#endif
+    const bf16x2s hp = {(__bf16)x0, (__bf16)x1};
+    const unsigned hw = __builtin_bit_cast(unsigned, hp);
+    const float f0 = __uint_as_float(hw << 16), f1 = __uint_as_float(hw & 0xffff0000u);
+    const bf16x2s lp = {(__bf16)(x0 - f0), (__bf16)(x1 - f1)};
+    o.h[(2 * t + (j >> 2)) * 4 + (j & 3)] = hw;
+    o.l[(2 * t + (j >> 2)) * 4 + (j & 3)] = __builtin_bit_cast(unsigned, lp);
+}
+template <bool RELU>
+__device__ __forceinline__ void cv_tiles(const f32x16 (&acc)[8], int t0, int t1, PackedOps &o) {
+#pragma unroll
+    for (int t = t0; t < t1; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cv_slice<RELU>(acc[t], t, j, o);
+}
+
+// 8-tile layer (or last K phase of fc_0) whose output is converted on the fly into `o` (all tiles but the last pair;
+// the caller converts tiles 6 and 7).  XIN = PackedOps or plain fragment arrays via the two accessors.
+template <int REC0, int NC, bool INIT, bool RELU, typename XH, typename XL>
+__device__ __forceinline__ void mlp_layer16_cv(const Ring &rg, const float *bp, f32x16 (&acc)[8], XH xh, XL xl, PackedOps &o) {
+    const int hi = rg.lane >> 5;
+    constexpr int NP = 4 * NC;
+    constexpr int SL = 16 / NC;  // slices per iteration: one tile pair = 16 two-value slices
+    static_assert(NC == 8 || NC == 16, "slice schedule written for 8 or 16 chunks");
+    Frag4 buf[2];
+    load_pair<REC0>(rg, 0, buf[0]);
+    f32x16 c0, c1;
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+        if (INIT) {
+            c0 = bias_tile(bp, 2 * tp, hi);
+            c1 = bias_tile(bp, 2 * tp + 1, hi);
+        } else {
+            c0 = acc[2 * tp];
+            c1 = acc[2 * tp + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = tp * NC + c;
+            Frag4 &cur = buf[k & 1];
+            if (k + 1 < NP) {
+                load_pair<REC0>(rg, k + 1, buf[(k + 1) & 1]);
+                wait_pair<4>(cur);
+            } else {
+                wait_pair<0>(cur);
+            }
+            const bf16x8 bh = xh(c), bl = xl(c);
+            c0 = NB_MFMA16(cur.ah0, bh, c0);
+            c1 = NB_MFMA16(cur.ah1, bh, c1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tp > 0) {
+                const int s0 = SL * c;  // slice index 0..15 inside the previous pair: tile 2(tp-1) + (s>>3), pair s&7
+                cv_slice<RELU>(acc[2 * (tp - 1) + (s0 >> 3)], 2 * (tp - 1) + (s0 >> 3), s0 & 7, o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = NB_MFMA16(cur.ah0, bl, c0);
+            c1 = NB_MFMA16(cur.ah1, bl, c1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tp > 0 && SL == 2) {
+                const int s1 = SL * c + 1;
+                cv_slice<RELU>(acc[2 * (tp - 1) + (s1 >> 3)], 2 * (tp - 1) + (s1 >> 3), s1 & 7, o);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            c0 = NB_MFMA16(cur.al0, bh, c0);
+            c1 = NB_MFMA16(cur.al1, bh, c1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[2 * tp] = c0;
+        acc[2 * tp + 1] = c1;
+    }
+}
+
 // relu + split of a finished layer into the next layer's B operands: chunk 2t+h <- registers 8h..8h+7 of tile t
 template <bool RELU>
 __device__ __forceinline__ void tiles_to_operands(const f32x16 (&acc)[8], bf16x8 (&xh)[16], bf16x8 (&xl)[16]) {
@@ -371,6 +471,9 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
     const float *prm = reinterpret_cast<const float *>(rg.lds + RING_BYTES);
     f32x16 acc[8];
     bf16x8 xh[16], xl[16];
+#ifdef NB_CV_INTERLEAVE
+    PackedOps xa, xb;
+#endif
     {
         // fc_0 level by level: gather one pyramid level (fp32), split it into bf16 B operands and
         // accumulate its K range into all 8 output tiles before touching the next level, so only one
@@ -406,18 +509,37 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
             bf16x8 fh[8], fl[8];
             gather_level_coop<3, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
             feats_to_operands<8>(f, fh, fl, DBG ? dbg : nullptr, 112, hi);
+#ifdef NB_CV_INTERLEAVE
+            mlp_layer16_cv<REC_L0 + 8 * 14, 8, false, true>(
+                rg, prm + P_B0, acc, [&](int c) { return fh[c]; }, [&](int c) { return fl[c]; }, xa);
+#else
             mlp_layer16<REC_L0 + 8 * 14, 8, 8, false>(rg, prm + P_B0, acc, fh, fl);
+#endif
         }
 #ifdef NB_ABL_NOGATHER
 #undef gather_level_coop
 #endif
     }
     if (DBG && dbg) dump_tiles(acc, dbg + TAP_H1, hi, true);
+#ifdef NB_CV_INTERLEAVE
+    cv_tiles<true>(acc, 6, 8, xa);
+    mlp_layer16_cv<REC_L1, NCH, true, true>(
+        rg, prm + P_B1, acc, [&](int c) { return ops_hi(xa, c); }, [&](int c) { return ops_lo(xa, c); }, xb);
+    if (DBG && dbg) dump_tiles(acc, dbg + TAP_H2, hi, true);
+    cv_tiles<true>(acc, 6, 8, xb);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        xh[c] = ops_hi(xb, c);
+        xl[c] = ops_lo(xb, c);
+    }
+    mlp_layer16<REC_L2, 8, NCH>(rg, prm + P_B2, acc, xh, xl);
+#else
     tiles_to_operands<true>(acc, xh, xl);
     mlp_layer16<REC_L1, 8, NCH>(rg, prm + P_B1, acc, xh, xl);
     if (DBG && dbg) dump_tiles(acc, dbg + TAP_H2, hi, true);
     tiles_to_operands<true>(acc, xh, xl);
     mlp_layer16<REC_L2, 8, NCH>(rg, prm + P_B2, acc, xh, xl);
+#endif
     if (DBG && dbg) dump_tiles(acc, dbg + TAP_H3, hi, true);
     // alpha_fc in fp32 on the VALU from the un-split fc_2 output
     {
@@ -434,14 +556,28 @@ __device__ __forceinline__ void decode16(const SceneDev &sc, const Ring &rg, flo
         s = add_halves(s);
         out[3] = s + prm[P_AB];
     }
-    tiles_to_operands<true>(acc, xh, xl);
     // the ring protocol needs every wave to walk the whole stream, so DENSITY_ONLY still runs the
     // colour head (its result is simply not stored)
+#ifdef NB_CV_INTERLEAVE
+    cv_tiles<true>(acc, 0, 8, xa);  // fc_2's output also feeds alpha_fc in fp32 above: converted after the layer
+    mlp_layer16_cv<REC_L4, NCH, true, false>(
+        rg, prm + P_LB, acc, [&](int c) { return ops_hi(xa, c); }, [&](int c) { return ops_lo(xa, c); }, xb);
+    if (DBG && dbg) dump_tiles(acc, dbg + TAP_G, hi, false);
+    cv_tiles<false>(acc, 6, 8, xb);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        xh[c] = ops_hi(xb, c);
+        xl[c] = ops_lo(xb, c);
+    }
+    f32x16 v[4];
+#else
+    tiles_to_operands<true>(acc, xh, xl);
     mlp_layer16<REC_L4, 8, NCH>(rg, prm + P_LB, acc, xh, xl);
     if (DBG && dbg) dump_tiles(acc, dbg + TAP_G, hi, false);
     // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings
     f32x16 v[4];
     tiles_to_operands<false>(acc, xh, xl);
+#endif
     mlp_layer16<REC_LV, 4, 16, true>(rg, prm + P_BV, v, xh, xl);
     {
         // the 30 sin/cos of the world point are only needed here: computing them late keeps registers

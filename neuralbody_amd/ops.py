@@ -461,9 +461,10 @@ def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out
     _req(in_rows, torch.float32, (None, cin), "in_rows")
     _req(dx, torch.float32, (None, cout), "dx")
     dw = torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=dx.device)
+    rulebook = torch.empty(max(int(n_out_max), 1) * 27, dtype=torch.int32, device=dx.device)
     check(_lib.lib().nb_enc_conv_bwd_weight(ptr(in_rows), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out),
                                             int(n_out_max), _i3(out_dhw), int(stride), ptr(dx), cin, cout, ptr(dw),
-                                            _stream()), "nb_enc_conv_bwd_weight")
+                                            ptr(rulebook), _stream()), "nb_enc_conv_bwd_weight")
     return dw
 
 
