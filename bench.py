@@ -171,7 +171,7 @@ def turntable_bench(args, dev):
         train.append(np.concatenate([np.concatenate([Rv, Tv.reshape(3, 1)], 1), [[0, 0, 0, 1.0]]], 0))
     path = nv.gen_path(train, args.steps + args.warmup, center=body["world_verts"].mean(0).astype(np.float64))
     frame = {k: v for k, v in bd.items() if k in ("coord", "out_sh", "bounds", "R", "Th", "latent_index")}
-    nvr = nv.NovelViewRenderer(rend, H, W, dev)
+    nvr = nv.NovelViewRenderer(rend, H, W, dev, reuse_volumes=args.reuse_volumes)
     rays = 0
     for RT in path[:args.warmup]:
         nvr.render_view(K, RT, body["can_bounds"], frame)
@@ -186,7 +186,7 @@ def turntable_bench(args, dev):
                       "rays_per_sec": rays / dt, "ray_samples_per_sec": rays * args.samples / dt,
                       "mean_rays_per_view": rays / args.steps,
                       "config": {"workload": "synthetic spiral path, %dx%d, %d samples/ray: raygen + encoder + march + image "
-                                             "assembly per view, all on device" % (H, W, args.samples)}}))
+                                             "assembly per view, all on device%s" % (H, W, args.samples, "; frame encoded once" if args.reuse_volumes else "")}}))
 
 
 def main():
@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3", "bf16x3s"])
+    ap.add_argument("--reuse-volumes", action="store_true", help="turntable mode: encode the frame once for all views")
     ap.add_argument("--mode", default="render", choices=["render", "train", "turntable"])
     args = ap.parse_args()
 

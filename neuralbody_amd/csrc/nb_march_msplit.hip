@@ -27,7 +27,10 @@ namespace {
 
 // ---------------------------------------------------------------- weight stream (per wave)
 // fragments (1 KiB = 64 lanes x 8 bf16) in consumption order: for every K chunk c, for every M tile m: A_hi, A_lo
-constexpr int S_R = 4;  // register ring depth (fragments)
+#ifndef NB_MS_RING
+#define NB_MS_RING 4
+#endif
+constexpr int S_R = NB_MS_RING;  // register ring depth (fragments): 8 spills more than it prefetches (61 vs 43 spilled registers)
 constexpr int NC_P1 = 8, NC_P2 = 8, NC_P3 = 6, NC_H = 16, NC_V2 = 16, NC_V1 = 8;
 constexpr int F_P1 = 0;                      // fc_0, K phase 1: pyramid level 3 (columns 224..351)
 constexpr int F_P2 = F_P1 + 4 * NC_P1;       // fc_0, K phase 2: level 2 (96..223)

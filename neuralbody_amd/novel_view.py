@@ -126,8 +126,27 @@ class NovelViewRenderer:
     nb_raygen (image_rays) -> renderer.render (any Renderer / RendererMmsk / RendererMsk) -> nb_image_assemble
     (if_nerf_demo.py:15-30).  `H, W` are the reduced image size int(cfg.H * cfg.ratio), int(cfg.W * cfg.ratio)."""
 
-    def __init__(self, renderer, H, W, device="cuda:0"):
+    def __init__(self, renderer, H, W, device="cuda:0", reuse_volumes=False):
+        """reuse_volumes: encode a frame once and reuse its feature volumes for every further view of the same frame
+        (same `coord` tensor, out_sh, latent-independent encoder weights).  The reference re-encodes per view
+        (if_clight_renderer.py:99-100); the volumes are identical (the encoder is deterministic), only the BatchNorm
+        running-statistics side effect of the skipped passes is lost — off by default."""
         self.renderer, self.H, self.W, self.device = renderer, int(H), int(W), torch.device(device)
+        self.reuse_volumes = bool(reuse_volumes)
+        self._vol_key, self._vols = None, None
+
+    def _frame_volumes(self, batch):
+        if not self.reuse_volumes:
+            return None
+        net = self.renderer.net
+        coord = batch["coord"]
+        key = (coord.data_ptr(), coord._version, tuple(coord.shape), tuple(int(v) for v in batch["out_sh"].reshape(-1).tolist()),
+               net.training, tuple((p.data_ptr(), p._version) for p in net.xyzc_net.parameters()),
+               (net.c.weight.data_ptr(), net.c.weight._version))
+        if key != self._vol_key:
+            self._vols = net.encode_sparse_voxels(self.renderer.prepare_sp_input(batch))
+            self._vol_key = key
+        return self._vols
 
     def view_batch(self, K, RT, can_bounds, frame):
         """image_rays on device + the frame's sp_input fields -> the batch dict Renderer.render consumes.
@@ -152,7 +171,7 @@ class NovelViewRenderer:
         if n == 0:
             out = {"rgb_map": torch.zeros((1, 0, 3), device=self.device), "depth_map": torch.zeros((1, 0), device=self.device)}
         else:
-            out = self.renderer.render(batch) if t_rand is None else self.renderer.render(batch, t_rand=t_rand)
+            out = self.renderer.render(batch, t_rand=t_rand, feature_volume=self._frame_volumes(batch))
         img, depth = ops.image_assemble(batch["mask_at_box"][0], out["rgb_map"][0].contiguous(), out["depth_map"][0].contiguous(),
                                         white_bkgd=self.renderer.cfg.white_bkgd, bgr=bgr, scale=scale)
         return {"img": img.view(self.H, self.W, 3), "depth": depth.view(self.H, self.W),

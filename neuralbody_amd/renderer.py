@@ -90,8 +90,10 @@ class Renderer:
                 "depth_map": depth.view(n_batch, n_pixel)}
 
     # -- if_clight_renderer.py:94-122
-    def render(self, batch, t_rand=None, want_raw=False, ray_range=None):
-        """ray_range = (begin, end) renders a contiguous slice of the rays (multi-GPU sharding)."""
+    def render(self, batch, t_rand=None, want_raw=False, ray_range=None, feature_volume=None):
+        """ray_range = (begin, end) renders a contiguous slice of the rays (multi-GPU sharding).
+        feature_volume: volumes of a previous `net.encode_sparse_voxels` of the SAME frame (same coord, out_sh, weights):
+        the encoder is then skipped — novel-view loops render many views of one frame (NovelViewRenderer.reuse_volumes)."""
         if self.cfg.raw_noise_std != 0.0:
             raise NotImplementedError("raw_noise_std != 0 (every shipped config uses 0)")
         ray_o, ray_d, near, far = batch["ray_o"], batch["ray_d"], batch["near"], batch["far"]
@@ -106,7 +108,8 @@ class Renderer:
                 t_rand = torch.rand((n_batch, n_pixel, self.cfg.N_samples), device=ray_o.device)
             return training.render_train(self, batch, t_rand)
         sp_input = self.prepare_sp_input(batch)
-        feature_volume = self.net.encode_sparse_voxels(sp_input)
+        if feature_volume is None:
+            feature_volume = self.net.encode_sparse_voxels(sp_input)
         b, e = (0, n_pixel) if ray_range is None else ray_range
         if self.cfg.perturb > 0.0 and self.net.training:
             if t_rand is None:

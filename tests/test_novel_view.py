@@ -146,6 +146,7 @@ def test_novel_view_loop_matches_oracle(precision):
     rend = H_.make_renderer(net, r)
     frame = {k: v for k, v in H_.device_batch(batch, dev).items() if k in ("coord", "out_sh", "bounds", "R", "Th", "latent_index")}
     nvr = nv.NovelViewRenderer(rend, Hh, Ww, dev)
+    nvr_reuse = nv.NovelViewRenderer(rend, Hh, Ww, dev, reuse_volumes=True)
     sdt = orc.tensor_state_dict(sd)
     checked = 0
     for RT in path[:3]:
@@ -165,5 +166,8 @@ def test_novel_view_loop_matches_oracle(precision):
         img[np.asarray(mask).reshape(-1)] = ref["rgb_map"][0].numpy()
         err = np.abs(out["img"].cpu().numpy().reshape(-1, 3) - img).max()
         assert err <= H_.RGB_TOL, err
+        # encoding the frame once and reusing the volumes gives the very same image
+        again = nvr_reuse.render_view(K0, RT, body["can_bounds"], frame)
+        assert torch.equal(again["img"], out["img"]) and torch.equal(again["depth"], out["depth"])
         checked += 1
     assert checked >= 2, "the spiral must see the body"
