@@ -193,7 +193,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)  # >= 3 warm-ups
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
