@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 9
+#define NB_ABI_VERSION 10
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -60,12 +60,14 @@ int nb_device_count(void);
 typedef struct nb_scene {
     const float *vol[NB_N_LEVELS]; /* dev */
     int32_t vol_dhw[NB_N_LEVELS][3];
-    float R[9];          /* row-major 3x3; canonical = (p_world - Th) @ R  (latent_xyzc.py:41-47) */
-    float Th[3];
-    float bounds_min[3]; /* SMPL-space AABB minimum, xyz order (sp_input['bounds'][0]) */
+    /* dev, NB_POSE_FLOATS floats: R[9] row-major (canonical = (p_world - Th) @ R, latent_xyzc.py:41-47) | Th[3] |
+     * bounds_min[3] (SMPL-space AABB minimum, xyz order = sp_input['bounds'][0]).  The per-frame tensors of sp_input
+     * are read by the kernels themselves: they never visit the host, so nothing about a frame is cached host-side. */
+    const float *pose;
     float voxel_size[3]; /* cfg.voxel_size, dhw order (latent_xyzc.py:54) */
     int32_t out_sh[3];   /* full-resolution grid D,H,W (sp_input['out_sh']) */
 } nb_scene;
+#define NB_POSE_FLOATS 15
 
 /* ---------------------------------------------------------------------------------
  * Packed decoder weights.  nb_mlp_pack_size() floats; produced by nb_mlp_pack() from
@@ -119,16 +121,15 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
  * (if_clight_renderer_mmsk.py:54-59).  pre_affine != 0 (the _msk variant) first maps the point
  * world -> SMPL space of the rendered pose (scene R, Th) -> world of the snapshot frame (R0, Th0).
  * ------------------------------------------------------------------------------- */
-#define NB_MAX_CULL_VIEWS 4
+#define NB_MAX_CULL_VIEWS 64 /* the reference loops over batch['Ks'].size(1) training views (4 or 6 in the shipped configs) */
+#define NB_CULL_CAM_FLOATS 21
 typedef struct nb_cull {
-    int32_t n_views;                       /* 1..NB_MAX_CULL_VIEWS */
-    int32_t H, W;                          /* mask size = int(cfg.H * cfg.ratio), int(cfg.W * cfg.ratio) */
+    int32_t n_views;    /* 1..NB_MAX_CULL_VIEWS */
+    int32_t H, W;       /* mask size = int(cfg.H * cfg.ratio), int(cfg.W * cfg.ratio) */
     int32_t pre_affine;
-    const uint8_t *msk[NB_MAX_CULL_VIEWS]; /* dev [H,W] uint8, non-zero = inside */
-    float RT[NB_MAX_CULL_VIEWS][12];       /* row-major 3x4 [R|T] (batch['RT']) */
-    float K[NB_MAX_CULL_VIEWS][9];         /* batch['Ks'] / batch['K'] */
-    float R0[9];                           /* batch['R0_snap'] */
-    float Th0[3];                          /* batch['Th0_snap'] */
+    const uint8_t *msk; /* dev [n_views,H,W] uint8, non-zero = inside (batch['msks'][0] / batch['msk']) */
+    const float *cam;   /* dev [n_views, NB_CULL_CAM_FLOATS]: row-major 3x4 [R|T] (batch['RT']) | K 3x3 (batch['Ks'] / batch['K']) */
+    const float *snap;  /* dev 12 floats: batch['R0_snap'] (9) | batch['Th0_snap'] (3); NULL unless pre_affine */
 } nb_cull;
 
 /* ---------------------------------------------------------------------------------
@@ -143,7 +144,7 @@ typedef struct nb_cull {
  *   ray_order dev [n_rays] int32 permutation or NULL: lane slot i marches ray ray_order[i].  Results are
  *           written at the ray's own index, so this only changes WHICH rays share a wavefront (e.g. 8x4
  *           pixel tiles instead of row segments, for gather locality); outputs are bit-identical.
- *   cull    HOST pointer to an nb_cull or NULL (no culling)
+ *   cull    HOST pointer to an nb_cull (whose msk / cam / snap members are DEVICE pointers) or NULL (no culling)
  *   outputs dev: rgb_map [n_rays,3], disp_map/acc_map/depth_map [n_rays],
  *           weights [n_rays,n_samples]; raw (optional, may be NULL) [n_rays,n_samples,4]
  * ------------------------------------------------------------------------------- */

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2}
 
 
@@ -17,9 +17,7 @@ class NbScene(C.Structure):
     _fields_ = [
         ("vol", C.c_void_p * NB_N_LEVELS),
         ("vol_dhw", (C.c_int32 * 3) * NB_N_LEVELS),
-        ("R", C.c_float * 9),
-        ("Th", C.c_float * 3),
-        ("bounds_min", C.c_float * 3),
+        ("pose", C.c_void_p),  # dev: R[9] | Th[3] | bounds_min[3]
         ("voxel_size", C.c_float * 3),
         ("out_sh", C.c_int32 * 3),
     ]
@@ -28,11 +26,9 @@ class NbScene(C.Structure):
 class NbCull(C.Structure):
     _fields_ = [
         ("n_views", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("pre_affine", C.c_int32),
-        ("msk", C.c_void_p * 4),
-        ("RT", (C.c_float * 12) * 4),
-        ("K", (C.c_float * 9) * 4),
-        ("R0", C.c_float * 9),
-        ("Th0", C.c_float * 3),
+        ("msk", C.c_void_p),   # dev [n_views, H, W] uint8
+        ("cam", C.c_void_p),   # dev [n_views, 21]: RT 3x4 | K 3x3
+        ("snap", C.c_void_p),  # dev R0 (9) | Th0 (3) or NULL
     ]
 
 

@@ -50,12 +50,29 @@ __host__ __device__ inline int col_pe(int c, int hi) {
     return -1;
 }
 
+// per-frame pose block in DEVICE memory (nb_scene.pose): R[9] row-major | Th[3] | bounds_min[3] (xyz).  The kernels read
+// it through the constant address space (wave-uniform scalar loads), so sp_input's R / Th / bounds never visit the host.
+typedef const float __attribute__((address_space(4))) *cfloat_ptr;
+struct Pose {
+    float R[9], Th[3], bmin[3];
+};
+__device__ __forceinline__ Pose load_pose(const float *pose) {
+    cfloat_ptr p = (cfloat_ptr)pose;
+    Pose q;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) q.R[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        q.Th[k] = p[9 + k];
+        q.bmin[k] = p[12 + k];
+    }
+    return q;
+}
+
 struct SceneDev {
     const float *vol[4];
     int dhw[4][3];
-    float R[9];
-    float Th[3];
-    float bmin[3];
+    const float *pose;
     float vs[3];
     float osh[3];
 };
@@ -63,11 +80,9 @@ struct SceneDev {
 // sample culling against training-view silhouettes (nb_cull): the reference's fp32 operation order
 struct CullDev {
     int n_views, H, W, pre;
-    const unsigned char *msk[4];
-    float RT[4][12];
-    float K[4][9];
-    float R0[9];
-    float Th0[3];
+    const unsigned char *msk;  // [n_views, H, W]
+    const float *cam;          // [n_views, 21]: RT (3x4 row-major) | K (3x3)
+    const float *snap;         // R0 (9) | Th0 (3), pre != 0 only
 };
 
 __device__ __forceinline__ int cull_pixel(float f, int size) {
@@ -81,29 +96,32 @@ __device__ __forceinline__ int cull_pixel(float f, int size) {
 __device__ __forceinline__ bool cull_inside(const CullDev &c, const SceneDev &sc, float px, float py, float pz) {
     float p[3] = {px, py, pz};
     if (c.pre) {  // if_clight_renderer_msk.py:18-32
-        const float q[3] = {__fsub_rn(px, sc.Th[0]), __fsub_rn(py, sc.Th[1]), __fsub_rn(pz, sc.Th[2])};
+        const Pose ps = load_pose(sc.pose);
+        cfloat_ptr sn = (cfloat_ptr)c.snap;
+        const float q[3] = {__fsub_rn(px, ps.Th[0]), __fsub_rn(py, ps.Th[1]), __fsub_rn(pz, ps.Th[2])};
         float can[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-            can[j] = __fadd_rn(__fadd_rn(__fmul_rn(q[0], sc.R[j]), __fmul_rn(q[1], sc.R[3 + j])), __fmul_rn(q[2], sc.R[6 + j]));
+            can[j] = __fadd_rn(__fadd_rn(__fmul_rn(q[0], ps.R[j]), __fmul_rn(q[1], ps.R[3 + j])), __fmul_rn(q[2], ps.R[6 + j]));
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            p[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(can[0], c.R0[i * 3]), __fmul_rn(can[1], c.R0[i * 3 + 1])),
-                                       __fmul_rn(can[2], c.R0[i * 3 + 2])), c.Th0[i]);
+            p[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(can[0], sn[i * 3]), __fmul_rn(can[1], sn[i * 3 + 1])),
+                                       __fmul_rn(can[2], sn[i * 3 + 2])), sn[9 + i]);
     }
     bool inside = true;
-    for (int v = 0; v < c.n_views; ++v) {  // if_clight_renderer_mmsk.py:21-38
+    for (int v = 0; v < c.n_views; ++v) {  // if_clight_renderer_mmsk.py:21-38 (loops over batch['Ks'].size(1) views)
+        cfloat_ptr RT = (cfloat_ptr)(c.cam + v * 21), K = RT + 12;
         float t[3], q[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            t[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p[0], c.RT[v][i * 4]), __fmul_rn(p[1], c.RT[v][i * 4 + 1])),
-                                       __fmul_rn(p[2], c.RT[v][i * 4 + 2])), c.RT[v][i * 4 + 3]);
+            t[i] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(p[0], RT[i * 4]), __fmul_rn(p[1], RT[i * 4 + 1])),
+                                       __fmul_rn(p[2], RT[i * 4 + 2])), RT[i * 4 + 3]);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            q[i] = __fadd_rn(__fadd_rn(__fmul_rn(t[0], c.K[v][i * 3]), __fmul_rn(t[1], c.K[v][i * 3 + 1])),
-                             __fmul_rn(t[2], c.K[v][i * 3 + 2]));
+            q[i] = __fadd_rn(__fadd_rn(__fmul_rn(t[0], K[i * 3]), __fmul_rn(t[1], K[i * 3 + 1])),
+                             __fmul_rn(t[2], K[i * 3 + 2]));
         const int x = cull_pixel(__fdiv_rn(q[0], q[2]), c.W), y = cull_pixel(__fdiv_rn(q[1], q[2]), c.H);
-        inside = inside && c.msk[v][(size_t)y * c.W + x] != 0;
+        inside = inside && c.msk[((size_t)v * c.H + y) * c.W + x] != 0;
     }
     return inside;
 }
@@ -180,15 +198,16 @@ struct GridCoord {
 
 __device__ __forceinline__ GridCoord grid_coords(const SceneDev &sc, float px, float py, float pz) {
     // (p - Th) @ R
-    const float qx = px - sc.Th[0], qy = py - sc.Th[1], qz = pz - sc.Th[2];
-    const float cx = fmaf(qz, sc.R[6], fmaf(qy, sc.R[3], qx * sc.R[0]));
-    const float cy = fmaf(qz, sc.R[7], fmaf(qy, sc.R[4], qx * sc.R[1]));
-    const float cz = fmaf(qz, sc.R[8], fmaf(qy, sc.R[5], qx * sc.R[2]));
+    const Pose ps = load_pose(sc.pose);
+    const float qx = px - ps.Th[0], qy = py - ps.Th[1], qz = pz - ps.Th[2];
+    const float cx = fmaf(qz, ps.R[6], fmaf(qy, ps.R[3], qx * ps.R[0]));
+    const float cy = fmaf(qz, ps.R[7], fmaf(qy, ps.R[4], qx * ps.R[1]));
+    const float cz = fmaf(qz, ps.R[8], fmaf(qy, ps.R[5], qx * ps.R[2]));
     // dhw = (xyz[[2,1,0]] - min_dhw) / voxel_size / out_sh * 2 - 1 ; back to xyz order for grid_sample
     GridCoord g;
-    g.gd = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cz - sc.bmin[2], sc.vs[0]), sc.osh[0]), 2.f), 1.f);
-    g.gh = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cy - sc.bmin[1], sc.vs[1]), sc.osh[1]), 2.f), 1.f);
-    g.gw = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cx - sc.bmin[0], sc.vs[2]), sc.osh[2]), 2.f), 1.f);
+    g.gd = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cz - ps.bmin[2], sc.vs[0]), sc.osh[0]), 2.f), 1.f);
+    g.gh = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cy - ps.bmin[1], sc.vs[1]), sc.osh[1]), 2.f), 1.f);
+    g.gw = __fsub_rn(__fmul_rn(__fdiv_rn(__fdiv_rn(cx - ps.bmin[0], sc.vs[2]), sc.osh[2]), 2.f), 1.f);
     return g;
 }
 
@@ -490,10 +509,9 @@ inline int fill_scene(const nb_scene *s, SceneDev *d) {
             d->dhw[l][k] = s->vol_dhw[l][k];
         }
     }
-    for (int k = 0; k < 9; ++k) d->R[k] = s->R[k];
+    NB_REQUIRE(s->pose != nullptr, "nb_scene.pose is NULL (device block R[9] | Th[3] | bounds_min[3])");
+    d->pose = s->pose;
     for (int k = 0; k < 3; ++k) {
-        d->Th[k] = s->Th[k];
-        d->bmin[k] = s->bounds_min[k];
         d->vs[k] = s->voxel_size[k];
         d->osh[k] = (float)s->out_sh[k];
         NB_REQUIRE(s->voxel_size[k] > 0.f && s->out_sh[k] > 0, "nb_scene voxel_size/out_sh must be positive");
@@ -511,14 +529,11 @@ inline int fill_cull(const nb_cull *c, CullDev *d) {
     d->H = c->H;
     d->W = c->W;
     d->pre = c->pre_affine;
-    for (int v = 0; v < c->n_views; ++v) {
-        NB_REQUIRE(c->msk[v] != nullptr, "nb_cull: msk[%d] is NULL", v);
-        d->msk[v] = c->msk[v];
-        for (int k = 0; k < 12; ++k) d->RT[v][k] = c->RT[v][k];
-        for (int k = 0; k < 9; ++k) d->K[v][k] = c->K[v][k];
-    }
-    for (int k = 0; k < 9; ++k) d->R0[k] = c->R0[k];
-    for (int k = 0; k < 3; ++k) d->Th0[k] = c->Th0[k];
+    NB_REQUIRE(c->msk != nullptr && c->cam != nullptr, "nb_cull: msk / cam is NULL");
+    NB_REQUIRE(!c->pre_affine || c->snap != nullptr, "nb_cull: pre_affine needs snap (R0 | Th0)");
+    d->msk = c->msk;
+    d->cam = c->cam;
+    d->snap = c->snap;
     return NB_OK;
 }
 

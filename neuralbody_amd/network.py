@@ -139,7 +139,7 @@ class Network(nn.Module):
         self.rgb_fc = nn.Conv1d(128, 3, 1)
         self._packed = None
         self._packed_key = None
-        self._host_cache = {}
+        self._t_vals = {}
 
     # ------------------------------------------------------------------ packed decoder weights
     def _mlp_param_dict(self):
@@ -157,8 +157,13 @@ class Network(nn.Module):
     def packed_weights(self):
         """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed."""
         d = self._mlp_param_dict()
-        key = tuple((t.data_ptr(), t._version, str(t.device)) for t in d.values())
-        if self._packed is None or key != self._packed_key:
+        # keyed on the parameters' storages, which the entry keeps alive (so an address cannot be recycled under the
+        # key), and on their version counters (optimizer steps and load_state_dict write in place)
+        key = tuple((t.untyped_storage(), t.data_ptr(), t._version) for t in d.values())
+        old = self._packed_key
+        same = old is not None and len(old) == len(key) and all(
+            a[0]._cdata == b[0]._cdata and a[1:] == b[1:] for a, b in zip(old, key))
+        if self._packed is None or not same:
             self._packed = ops.mlp_pack(d, None)
             self._packed_key = key
         return self._packed
@@ -173,29 +178,18 @@ class Network(nn.Module):
         return ops.mlp_latent_bias(self._mlp_param_dict(), row)
 
     # ------------------------------------------------------------------ scene description
-    def _host(self, t):
-        """Small per-frame tensors (R, Th, bounds) are needed as kernel arguments: one D2H copy per
-        distinct tensor, cached on (data_ptr, version)."""
-        key = (t.data_ptr(), t._version, tuple(t.shape))
-        v = self._host_cache.get(key)
-        if v is None:
-            if len(self._host_cache) > 64:
-                self._host_cache.clear()
-            v = t.detach().float().cpu().numpy()
-            self._host_cache[key] = v
-        return v
-
     def make_scene(self, feature_volume, sp_input):
+        """nb_scene of one frame.  R / Th / bounds stay on the device (ops.make_pose packs them into the 15-float
+        block the kernels read): no host copy, no sync and — unlike round 1's address-keyed host cache — nothing
+        that could hand frame k+1 the pose of frame k when the allocator recycles the batch's addresses."""
         vols = []
         for v in feature_volume:
             vols.append(v if v.dim() == 4 else ops.volume_as_channels_last(v))
-        R = self._host(sp_input["R"]).reshape(-1, 3, 3)
-        if R.shape[0] != 1:
+        R, Th, bounds = sp_input["R"], sp_input["Th"], sp_input["bounds"]
+        if R.numel() != 9 or bounds.numel() != 6:
             raise NotImplementedError("batch size 1 only (train.batch_size / test batch are 1 in every shipped config)")
-        Th = self._host(sp_input["Th"]).reshape(-1)[:3]
-        bmin = self._host(sp_input["bounds"]).reshape(-1, 2, 3)[0, 0]
         out_sh = [int(s) for s in sp_input["out_sh"]]
-        return ops.make_scene(vols, R[0], Th, bmin, self.voxel_size, out_sh)
+        return ops.make_scene(vols, ops.make_pose(R, Th, bounds, device=vols[0].device), self.voxel_size, out_sh)
 
     # ------------------------------------------------------------------ reference API
     def encode_sparse_voxels(self, sp_input, save=None):
@@ -244,11 +238,11 @@ class Network(nn.Module):
         """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
         scene = self.make_scene(feature_volume, sp_input)
         lb = self.latent_bias(sp_input["latent_index"])
-        key = ("t_vals", int(n_samples), str(ray_o.device))
-        t_vals = self._host_cache.get(key)
+        key = (int(n_samples), str(ray_o.device))  # a constant of (S, device), not of the frame
+        t_vals = self._t_vals.get(key)
         if t_vals is None:
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
-            self._host_cache[key] = t_vals
+            self._t_vals[key] = t_vals
         return ops.march(scene, self.packed_weights(), lb, ray_o, ray_d, near, far, t_vals, t_rand,
                          white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision, ray_order=ray_order,
                          cull=cull)

@@ -139,13 +139,19 @@ class NovelViewRenderer:
         if not self.reuse_volumes:
             return None
         net = self.renderer.net
-        coord = batch["coord"]
-        key = (coord.data_ptr(), coord._version, tuple(coord.shape), tuple(int(v) for v in batch["out_sh"].reshape(-1).tolist()),
-               net.training, tuple((p.data_ptr(), p._version) for p in net.xyzc_net.parameters()),
-               (net.c.weight.data_ptr(), net.c.weight._version))
-        if key != self._vol_key:
+        coord, out_sh = batch["coord"], batch["out_sh"]
+        # The cache entry HOLDS the tensors it was computed from and compares identity + version counters: a new
+        # frame's `coord` is a different tensor object even when the allocator hands it the old one's address
+        # (round 1 keyed on data_ptr, which a freed-and-reallocated batch reproduces).
+        params = list(net.xyzc_net.parameters()) + [net.c.weight]
+        src = (coord, out_sh, net.training, params)
+        ver = (coord._version, out_sh._version, tuple(p._version for p in params))
+        old = self._vol_key
+        same = old is not None and old[0][0] is coord and old[0][1] is out_sh and old[0][2] == net.training and \
+            len(old[0][3]) == len(params) and all(a is b for a, b in zip(old[0][3], params)) and old[1] == ver
+        if not same:
             self._vols = net.encode_sparse_voxels(self.renderer.prepare_sp_input(batch))
-            self._vol_key = key
+            self._vol_key = (src, ver)
         return self._vols
 
     def view_batch(self, K, RT, can_bounds, frame):

@@ -44,9 +44,29 @@ def volume_as_channels_last(v):
     return v[0].permute(1, 2, 3, 0).contiguous()  # no copy when the storage is already channels-last
 
 
-def make_scene(volumes_cl, R, Th, bounds_min, voxel_size, out_sh):
-    """volumes_cl: four contiguous [D,H,W,C] fp32 device tensors.  R (3x3), Th (3), bounds_min (3,
-    xyz), voxel_size (3, dhw) and out_sh (3) are HOST sequences.  Returns (NbScene, keepalive)."""
+def make_pose(R, Th, bounds, device=None):
+    """The per-frame pose block the kernels read from DEVICE memory: R[9] row-major | Th[3] | bounds_min[3] (15 fp32).
+    R (any shape with 9 elements), Th (>= 3 elements), bounds ([..,2,3] or 3 elements: the minimum corner is taken) may
+    be device tensors — sp_input['R'|'Th'|'bounds'] as they are, no host round trip, no sync — or host sequences."""
+    def dev_flat(x, n):
+        if not isinstance(x, torch.Tensor):
+            import numpy as np
+
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32)))
+        x = x.detach().reshape(-1)[:n].to(device=device if device is not None else x.device, dtype=torch.float32)
+        if x.numel() != n:
+            raise ValueError("pose component has %d elements, expected >= %d" % (x.numel(), n))
+        return x
+
+    if device is None:
+        device = next((x.device for x in (R, Th, bounds) if isinstance(x, torch.Tensor)), None)
+    pose = torch.cat([dev_flat(R, 9), dev_flat(Th, 3), dev_flat(bounds, 3)])
+    return _req(pose, torch.float32, (15,), "pose")
+
+
+def make_scene(volumes_cl, pose, voxel_size, out_sh):
+    """volumes_cl: four contiguous [D,H,W,C] fp32 device tensors; pose: the 15-float DEVICE block of make_pose;
+    voxel_size (3, dhw) and out_sh (3) are HOST sequences.  Returns (NbScene, keepalive)."""
     sc = NbScene()
     if len(volumes_cl) != 4:
         raise ValueError("expected 4 feature volumes")
@@ -55,15 +75,12 @@ def make_scene(volumes_cl, R, Th, bounds_min, voxel_size, out_sh):
         sc.vol[l] = v.data_ptr()
         for k in range(3):
             sc.vol_dhw[l][k] = int(v.shape[k])
-    Rf = [float(x) for row in R for x in row]
-    for k in range(9):
-        sc.R[k] = Rf[k]
+    _req(pose, torch.float32, (15,), "pose")
+    sc.pose = pose.data_ptr()
     for k in range(3):
-        sc.Th[k] = float(Th[k])
-        sc.bounds_min[k] = float(bounds_min[k])
         sc.voxel_size[k] = float(voxel_size[k])
         sc.out_sh[k] = int(out_sh[k])
-    return sc, list(volumes_cl)
+    return sc, list(volumes_cl) + [pose]
 
 
 def mlp_pack_size():
@@ -476,29 +493,27 @@ def enc_scatter_codes_bwd(drows, rows_vert, n_rows, n_rows_max, n_codes):
     return dcodes
 
 
-def make_cull(masks, RTs, Ks, H, W, R0=None, Th0=None):
-    """nb_cull from device uint8 masks [H,W] (1..4 views) and HOST 3x4 / 3x3 matrices.  R0 / Th0 (host) select the
-    _msk variant (snapshot-frame placement).  Returns (NbCull, keepalive)."""
-    if not 1 <= len(masks) <= 4:
-        raise ValueError("1..4 mask views supported")
+def make_cull(masks, RT, K, R0=None, Th0=None):
+    """nb_cull from DEVICE tensors: masks [n_views,H,W] uint8 (non-zero = inside), RT [n_views,3,4], K [n_views,3,3]
+    (batch['msks'][0], batch['RT'][0], batch['Ks'][0]); R0 [3,3] / Th0 [3] select the _msk variant (snapshot-frame
+    placement).  Nothing visits the host.  Returns (NbCull, keepalive)."""
+    masks = masks if masks.dtype == torch.uint8 else masks.to(torch.uint8)
+    masks = masks.contiguous()
+    _req(masks, torch.uint8, (None, None, None), "masks")
+    nv, H, W = (int(v) for v in masks.shape)
+    if not 1 <= nv <= 64:
+        raise ValueError("1..64 mask views supported, got %d" % nv)
+    cam = torch.cat([RT.detach().reshape(nv, 12).float(), K.detach().reshape(nv, 9).float()], 1).contiguous()
+    _req(cam, torch.float32, (nv, 21), "cam")
     c = NbCull()
-    c.n_views, c.H, c.W = len(masks), int(H), int(W)
+    c.n_views, c.H, c.W = nv, H, W
     c.pre_affine = 0 if R0 is None else 1
-    keep = []
-    for v, m in enumerate(masks):
-        _req(m, torch.uint8, (int(H), int(W)), "mask[%d]" % v)
-        c.msk[v] = m.data_ptr()
-        keep.append(m)
-        rt = [float(x) for row in RTs[v] for x in row]
-        k = [float(x) for row in Ks[v] for x in row]
-        for i in range(12):
-            c.RT[v][i] = rt[i]
-        for i in range(9):
-            c.K[v][i] = k[i]
+    c.msk = masks.data_ptr()
+    c.cam = cam.data_ptr()
+    keep = [masks, cam]
     if R0 is not None:
-        r0 = [float(x) for row in R0 for x in row]
-        for i in range(9):
-            c.R0[i] = r0[i]
-        for i in range(3):
-            c.Th0[i] = float(Th0[i])
+        snap = torch.cat([R0.detach().reshape(9).float(), Th0.detach().reshape(-1)[:3].float()]).contiguous()
+        _req(snap, torch.float32, (12,), "snap")
+        c.snap = snap.data_ptr()
+        keep.append(snap)
     return c, keep

@@ -135,20 +135,20 @@ class Renderer:
         mask = batch.get("mask_at_box")
         if not H or not W or mask is None or mask.numel() != int(H) * int(W) or e - b < 64:
             return None
-        key = (mask.data_ptr(), mask._version, int(W), b, e)
+        # cached on the mask tensor's IDENTITY: the entry holds the tensor itself, so its address cannot be recycled
+        # for another frame's mask while the entry lives (round 1 keyed on data_ptr/_version, which a freed-and-
+        # reallocated batch reproduces).  A caller that rewrites the same tensor in place through a raw pointer
+        # (nb_raygen) bumps nothing, so the frame token `batch.get("frame_token")` is part of the key when given.
         cached = getattr(self, "_order_cache", None)
-        if cached is not None and cached[0] == key:
-            return cached[1]
+        token = batch.get("frame_token")
+        if cached is not None and cached[0] is mask and cached[1] == (mask._version, int(W), b, e, token):
+            return cached[2]
         pix = torch.nonzero(mask.reshape(-1), as_tuple=False).reshape(-1)
         if pix.numel() != n_pixel:
             return None
         order = ops.tile_order(pix[b:e], int(W))
-        self._order_cache = (key, order)
+        self._order_cache = (mask, (mask._version, int(W), b, e, token), order)
         return order
-
-
-def _host(t):
-    return t.detach().float().cpu().numpy()
 
 
 class RendererMmsk(Renderer):
@@ -159,10 +159,7 @@ class RendererMmsk(Renderer):
     def make_cull(self, batch):
         if "Ks" not in batch:
             raise KeyError("the _mmsk renderer needs batch['msks'], batch['Ks'], batch['RT']")
-        msks = batch["msks"][0]
-        nv, H, W = msks.shape
-        masks = [msks[v].to(torch.uint8).contiguous() for v in range(nv)]
-        return ops.make_cull(masks, _host(batch["RT"][0]), _host(batch["Ks"][0]), H, W)
+        return ops.make_cull(batch["msks"][0], batch["RT"][0], batch["Ks"][0])
 
 
 class RendererMsk(Renderer):
@@ -172,10 +169,8 @@ class RendererMsk(Renderer):
     def make_cull(self, batch):
         if "R0_snap" not in batch:
             raise KeyError("the _msk renderer needs batch['msk'], batch['K'], batch['RT'], batch['R0_snap'], batch['Th0_snap']")
-        msk = batch["msk"][0]
-        H, W = msk.shape
-        return ops.make_cull([msk.to(torch.uint8).contiguous()], [_host(batch["RT"][0])], [_host(batch["K"][0])], H, W,
-                             R0=_host(batch["R0_snap"][0]), Th0=_host(batch["Th0_snap"][0]).reshape(-1))
+        return ops.make_cull(batch["msk"][:1], batch["RT"][:1], batch["K"][:1], R0=batch["R0_snap"][0],
+                             Th0=batch["Th0_snap"][0])
 
 
 class RendererMesh(Renderer):

@@ -8,6 +8,7 @@ from tests.golden import scenes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 RGB_TOL = 1e-4  # BASELINE.json north_star: <= 1e-4 RGB L-inf against the reference renderer
+from neuralbody_amd.network import DEFAULT_PRECISION  # noqa: E402,F401  (the arithmetic Renderer.render uses by default)
 
 
 def golden(name):

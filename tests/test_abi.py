@@ -21,17 +21,37 @@ def test_library_exports_every_header_symbol(lib):
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.nb_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.nb_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_sizes_and_struct_layout(lib):
     # 8*44*256 + 256 + 2*(8*32*256 + 256) + 256 + 4 + 8*32*256 + 4*44*256 + 128 + 384 + 4
     assert lib.nb_mlp_pack_size() == 333320 + 650 * 2048 // 4 + 4 * 328 * 1024 // 4  # fp32 fragments + bf16 ring stream + M-split streams
     assert lib.nb_mlp_latent_bias_size() == 256
-    assert C.sizeof(_lib.NbScene) == 168  # == sizeof(nb_scene) compiled with gcc (164 + tail padding)
-    assert _lib.NbScene.out_sh.offset == 152 and _lib.NbScene.R.offset == 80
     assert C.sizeof(_lib.NbMlpParams) == 16 * 8
     assert lib.nb_scan_scratch_size(0) >= 256 and lib.nb_scan_scratch_size(1 << 20) >= 2 * 4 * (1 << 20)
+
+
+def test_ctypes_structs_match_the_header_compiled_by_gcc(tmp_path):
+    """sizeof / offsetof of nb_scene and nb_cull as a C compiler lays them out == the ctypes mirrors in _lib.py."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    src = tmp_path / "layout.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "nb_hip.h"\n'
+        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nb_scene), offsetof(nb_scene, vol_dhw), '
+        'offsetof(nb_scene, pose), offsetof(nb_scene, voxel_size), offsetof(nb_scene, out_sh), sizeof(nb_cull), '
+        'offsetof(nb_cull, msk), offsetof(nb_cull, cam), offsetof(nb_cull, snap), sizeof(nb_mlp_params)); return 0; }\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call([gcc, "-I", os.path.dirname(_lib.HEADER), str(src), "-o", str(exe)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    S, K = _lib.NbScene, _lib.NbCull
+    want = [C.sizeof(S), S.vol_dhw.offset, S.pose.offset, S.voxel_size.offset, S.out_sh.offset, C.sizeof(K), K.msk.offset,
+            K.cam.offset, K.snap.offset, C.sizeof(_lib.NbMlpParams)]
+    assert got == want, (got, want)
 
 
 def test_error_codes_without_touching_a_device(lib):

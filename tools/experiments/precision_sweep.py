@@ -1,0 +1,233 @@
+"""Per-layer precision sensitivity of the decoder MLP — CPU emulation.
+
+For every golden scene the gathered features come from the oracle (fp32); each MLP layer is then evaluated with
+its operands rounded the way an MFMA scheme would round them (products exact, fp32 accumulation), the result is
+composited with the oracle's raw2outputs and compared with the REFERENCE renderer's rgb_map stored in the fixture.
+
+Schemes (per layer):
+    f32      exact fp32
+    bf16x3   W_hi.X_hi + W_hi.X_lo + W_lo.X_hi, bf16 parts         (round-1 kernel)
+    bf16x1   single bf16 product
+    f16x1    single fp16 product
+    f16x2w   (W_hi + W_lo).X_hi: weights exact to 22 bits, activations rounded to fp16
+    f16x2x   W_hi.(X_hi + X_lo)
+    f16x3    three fp16 products
+    f16c8    fp16 main product + the two cross terms with BOTH operands rounded to fp8 e4m3 after an exact 2^k block
+             scale (what a scaled f8f6f4 MFMA would compute)
+
+Run:  python tools/experiments/precision_sweep.py [--wide]      (CPU, ~1 min)
+The same table measured on the HIP kernels is produced by tools/experiments/precision_gpu.py.
+"""
+import argparse
+import itertools
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import neuralbody_oracle as orc  # noqa: E402
+from tests import helpers as H  # noqa: E402
+from tests.golden import scenes  # noqa: E402
+
+LAYERS = ("fc_0", "fc_1", "fc_2", "merged", "view_fc")
+
+
+def _bf16(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def _f16(x):
+    return x.to(torch.float16).to(torch.float32)
+
+
+def _f8_scaled(x, dim):
+    """fp8 e4m3 with one exact power-of-two scale per 32 consecutive elements along `dim` (MX-style block scale)."""
+    xm = x.movedim(dim, -1)
+    sh = xm.shape
+    pad = (-sh[-1]) % 32
+    if pad:
+        xm = torch.nn.functional.pad(xm, (0, pad))
+    blk = xm.reshape(*xm.shape[:-1], -1, 32)
+    amax = blk.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - 7.0)  # block max lands in [128, 256) <= 448
+    q = (blk / scale).to(torch.float8_e4m3fn).to(torch.float32) * scale
+    q = q.reshape(*xm.shape)[..., :sh[-1]]
+    return q.movedim(-1, dim)
+
+
+def _f8_static(x, log2_scale):
+    """fp8 e4m3 after a fixed power-of-two pre-scale (saturating at +-448), result scaled back."""
+    sc = 2.0 ** log2_scale
+    q = (x * sc).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+    return q / sc
+
+
+def _bf8_static(x, log2_scale):
+    """bf8 e5m2 after a fixed power-of-two pre-scale (saturating at +-57344), result scaled back."""
+    sc = 2.0 ** log2_scale
+    q = (x * sc).clamp(-57344.0, 57344.0).to(torch.float8_e5m2).to(torch.float32)
+    return q / sc
+
+
+def _w_scale(W):
+    """per-layer static weight scale chosen at pack time: the largest power of two keeping max|W| <= 448"""
+    m = float(W.abs().max())
+    return 0 if m == 0 else int(np.floor(np.log2(448.0 / m)))
+
+
+def mm(W, X, scheme):
+    """W [M,K] @ X [K,N] with the operand roundings of `scheme` (fp32 accumulation)."""
+    if scheme == "f32":
+        return W @ X
+    if scheme == "bf16x1":
+        return _bf16(W) @ _bf16(X)
+    if scheme == "f16x1":
+        return _f16(W) @ _f16(X)
+    if scheme in ("bf16x3", "f16x3", "f16x2w", "f16x2x", "f16c8", "f16c8s", "f16c8b"):
+        r = _bf16 if scheme == "bf16x3" else _f16
+        Wh, Xh = r(W), r(X)
+        Wl, Xl = r(W - Wh), r(X - Xh)
+        if scheme == "f16x2w":
+            return Wh @ Xh + Wl @ Xh
+        if scheme == "f16x2x":
+            return Wh @ Xh + Wh @ Xl
+        if scheme == "f16c8":
+            return Wh @ Xh + _f8_scaled(Wh, 1) @ _f8_scaled(Xl, 0) + _f8_scaled(Wl, 1) @ _f8_scaled(Xh, 0)
+        if scheme == "f16c8s":  # static scales: activations 2^-2 (hi) / 2^8 (lo), weights per layer from max|W|
+            return Wh @ Xh + _f8_static(Wh, _w_scale(Wh)) @ _f8_static(Xl, 8) + _f8_static(Wl, _w_scale(Wl)) @ _f8_static(Xh, -2)
+        if scheme == "f16c8b":  # activations in bf8 e5m2 (no range worries), weights in fp8 e4m3 with pack-time scales
+            return Wh @ Xh + _f8_static(Wh, _w_scale(Wh)) @ _bf8_static(Xl, 12) + _f8_static(Wl, _w_scale(Wl)) @ _bf8_static(Xh, 0)
+        return Wh @ Xh + Wh @ Xl + Wl @ Xh
+    raise ValueError(scheme)
+
+
+def decode(sd, feat, wpts, viewdir, latent_index, mix):
+    """raw [N,4] from gathered features [N,352]; `mix` maps layer -> scheme.  Merged feature/latent layer as in
+    nb_mlp_pack (fp64 product rounded to fp32, latent folded into the bias)."""
+    w = {k: v[..., 0] if v.dim() == 3 else v for k, v in sd.items()}
+    x = feat.T
+    h = torch.relu(mm(w["fc_0.weight"], x, mix["fc_0"]) + w["fc_0.bias"][:, None])
+    h = torch.relu(mm(w["fc_1.weight"], h, mix["fc_1"]) + w["fc_1.bias"][:, None])
+    h = torch.relu(mm(w["fc_2.weight"], h, mix["fc_2"]) + w["fc_2.bias"][:, None])
+    alpha = w["alpha_fc.weight"] @ h + w["alpha_fc.bias"][:, None]
+    Lw = w["latent_fc.weight"].double()
+    Wm = (Lw[:, :256] @ w["feature_fc.weight"].double()).float()
+    lat = w["latent.weight"][latent_index].double().reshape(128)
+    bm = (Lw[:, :256] @ w["feature_fc.bias"].double() + Lw[:, 256:] @ lat + w["latent_fc.bias"].double()).float()
+    g = mm(Wm, h, mix["merged"]) + bm[:, None]
+    pe = torch.cat([orc.embed(viewdir, 4), orc.embed(wpts, 10)], -1).T
+    v = torch.relu(mm(w["view_fc.weight"], torch.cat([g, pe], 0), mix["view_fc"]) + w["view_fc.bias"][:, None])
+    rgb = w["rgb_fc.weight"] @ v + w["rgb_fc.bias"][:, None]
+    return torch.cat([rgb, alpha], 0).T
+
+
+def scene_inputs(name, widen=None):
+    r, sd, body, batch, cam, t_rand = scenes.build(name)
+    if widen is not None:
+        sd = widen(sd)
+    training = r["mode"] == "train"
+    sdt, vols, out_sh = H.oracle_volumes(sd, batch, training)
+    ray_o, ray_d = torch.from_numpy(batch["ray_o"]), torch.from_numpy(batch["ray_d"])
+    near, far = torch.from_numpy(batch["near"]), torch.from_numpy(batch["far"])
+    tr = None if t_rand is None else torch.from_numpy(t_rand)
+    with torch.no_grad():
+        wpts, z = orc.get_sampling_points(ray_o, ray_d, near, far, r["n_samples"], tr)
+        vd = ray_d / torch.norm(ray_d, dim=2, keepdim=True)
+        ns = r["n_samples"]
+        w = wpts.reshape(-1, 3)
+        v = vd[:, :, None].repeat(1, 1, ns, 1).reshape(-1, 3)
+        pp = orc.pts_to_can_pts(w[None], torch.from_numpy(batch["R"]), torch.from_numpy(batch["Th"]))
+        g = orc.get_grid_coords(pp, torch.from_numpy(batch["bounds"]), out_sh, (0.005,) * 3)[:, None, None]
+        feat = orc.interpolate_features(g, vols)[0].T.contiguous()
+    return dict(r=r, sdt=sdt, feat=feat, w=w, v=v, z=z.reshape(-1, ns), rd=ray_d.reshape(-1, 3),
+                li=int(batch["latent_index"][0]))
+
+
+def rgb_of(s, mix):
+    with torch.no_grad():
+        raw = decode(s["sdt"], s["feat"], s["w"], s["v"], s["li"], mix)
+        rgb, *_ = orc.raw2outputs(raw.reshape(-1, s["r"]["n_samples"], 4), s["z"], s["rd"], s["r"]["white_bkgd"])
+    return rgb.numpy()
+
+
+def widen_weights(sd):
+    """Wide-dynamic-range variant of a state dict: every MLP weight matrix gets per-column and per-row log-uniform
+    gains spanning 2^-6..2^6 whose product over a layer pair cancels on average (activations stay O(1))."""
+    rs = np.random.RandomState(99)
+    sd = dict(sd)
+    prev = None
+    for name in ("fc_0", "fc_1", "fc_2", "feature_fc", "latent_fc", "view_fc"):
+        W = np.array(sd[name + ".weight"])
+        out_gain = np.exp2(rs.uniform(-6, 6, W.shape[0])).astype(np.float32)
+        if prev is not None and name in ("fc_1", "fc_2", "feature_fc"):
+            W[:, :, 0] = W[:, :, 0] / prev[None, :]  # undo the previous layer's row gains (relu is positively homogeneous)
+        if name in ("fc_0", "fc_1"):
+            W = W * out_gain[:, None, None]
+            sd[name + ".bias"] = np.array(sd[name + ".bias"]) * out_gain
+            prev = out_gain
+        else:
+            prev = None
+        sd[name + ".weight"] = W.astype(np.float32)
+    return sd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--wide", action="store_true", help="also run the wide-dynamic-range weights variant")
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--quick", action="store_true", help="only the candidate shipping mixes")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    names = list(scenes.SCENES)
+    data = {n: scene_inputs(n) for n in names}
+    gold = {n: H.golden(n)["rgb_map"][0] for n in names}
+    if a.wide:
+        data["small_wide"] = scene_inputs("small", widen_weights)
+        gold["small_wide"] = rgb_of(data["small_wide"], {l: "f32" for l in LAYERS})  # emulation-only reference
+    lines = []
+
+    def report(tag, mix):
+        errs = {n: float(np.abs(rgb_of(data[n], mix) - gold[n]).max()) for n in data}
+        worst = max(errs.values())
+        line = "| %-46s | %s | **%.2e** |" % (tag, " | ".join("%.1e" % errs[n] for n in data), worst)
+        print(line, flush=True)
+        lines.append(line)
+        return worst
+
+    print("| mix | " + " | ".join(data) + " | worst |")
+    print("|---|" + "---|" * (len(data) + 1))
+    if a.quick:
+        report("all bf16x3", {l: "bf16x3" for l in LAYERS})
+        report("all f16c8s", {l: "f16c8s" for l in LAYERS})
+        mix = {l: "f16c8s" for l in LAYERS}
+        mix["merged"] = "f16x1"
+        report("f16c8s, merged f16x1", mix)
+        mix = {l: "bf16x3" for l in LAYERS}
+        mix["merged"] = "f16x1"
+        report("bf16x3, merged f16x1", mix)
+        report("all f16c8b", {l: "f16c8b" for l in LAYERS})
+        mix = {l: "f16c8b" for l in LAYERS}
+        mix["merged"] = "f16x1"
+        report("f16c8b, merged f16x1", mix)
+        return
+    for s in ("f32", "bf16x3", "f16x3", "f16c8", "f16x2w", "f16x2x", "f16x1", "bf16x1"):
+        report("all " + s, {l: s for l in LAYERS})
+    for s in ("f16x1", "f16c8", "bf16x1"):
+        for l in LAYERS:
+            mix = {k: "bf16x3" for k in LAYERS}
+            mix[l] = s
+            report("bf16x3 except %s=%s" % (l, s), mix)
+    for trunk, head in itertools.product(("bf16x3", "f16c8", "f16x1"), ("f16x1", "bf16x1")):
+        mix = {"fc_0": trunk, "fc_1": trunk, "fc_2": trunk, "merged": head, "view_fc": head}
+        report("trunk %s / colour head %s" % (trunk, head), mix)
+    if a.out:
+        with open(a.out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
