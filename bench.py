@@ -41,6 +41,9 @@ PRECISION_INFO = {
     "bf16x3": ("bf16", "nb_march16_kernel", 1944 * 32768 / 32.0, 2500.0),
     # M-split organisation of the same arithmetic: 4 waves x 984 MFMAs per 64 samples (encoding K padded to 128)
     "bf16x3s": ("bf16", "nb_march16s_kernel", 4 * 984 * 32768 / 64.0, 2500.0),
+    # fp16 main product (648 K=16 MFMAs per 32 samples) + 336 K=64 scaled 8-bit MFMAs for the two cross terms; the 8-bit
+    # flops are counted at half weight (their dense peak is 2x the fp16 peak), i.e. in fp16-equivalent matrix-pipe time
+    "f16f8": ("f16+f8", "nb_march_f16_kernel", (648 * 32768 + 336 * 131072 / 2.0) / 32.0, 2500.0),
 }
 
 
@@ -197,7 +200,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3", "bf16x3s"])
+    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3", "bf16x3s", "f16f8"])
     ap.add_argument("--reuse-volumes", action="store_true", help="turntable mode: encode the frame once for all views")
     ap.add_argument("--mode", default="render", choices=["render", "train", "turntable"])
     args = ap.parse_args()
@@ -287,7 +290,10 @@ def main():
                                   "bf16x3": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
                                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate",
                                   "bf16x3s": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
-                                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate (M-split workgroups)"}[net.precision],
+                                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate (M-split workgroups)",
+                                  "f16f8": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
+                                           "terms in 8 bits (fp8 e4m3 weights, bf8 e5m2 activations) on "
+                                           "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate"}[net.precision],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,

@@ -37,6 +37,10 @@ extern "C" {
 #define NB_PREC_BF16X3 1 /* bf16 hi+lo split of both operands, 3 products on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
 #define NB_PREC_BF16X3S 2 /* nb_march only: the same arithmetic, workgroup organised by output-feature quarters
                              (activations in LDS, weights straight from L2, two workgroups per CU) */
+#define NB_PREC_F16F8 3   /* nb_march only: fp16 main product on v_mfma_f32_32x32x16_f16 + the two cross terms of the
+                             fp16 head/remainder split in 8 bits (weights fp8 e4m3, activations bf8 e5m2) on
+                             v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate: ~2^-15 relative error per term at 1.8
+                             instead of 3 matrix-pipe units */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */

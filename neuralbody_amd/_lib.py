@@ -10,7 +10,7 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
 ABI_VERSION = 10
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2, "f16f8": 3}
 
 
 class NbScene(C.Structure):

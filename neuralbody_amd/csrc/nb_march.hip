@@ -415,7 +415,7 @@ __global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__
 
 extern "C" {
 
-int64_t nb_mlp_pack_size(void) { return PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(); }
+int64_t nb_mlp_pack_size(void) { return PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats() + nbm::f16_stream_floats(); }
 int64_t nb_mlp_latent_bias_size(void) { return 256; }
 
 static int check_params(const nb_mlp_params *p) {
@@ -432,7 +432,8 @@ int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream) {
     hipLaunchKernelGGL(nb_pack_kernel, dim3(nb_ceil_div(PACK_SIZE, 256)), dim3(256), 0, (hipStream_t)stream, *p, packed);
     NB_CHECK_LAUNCH("nb_pack_kernel");
     if (int rc = nbm::pack_bf16_stream(p, packed, (hipStream_t)stream)) return rc;  // reads the merged layer from the fp32 section
-    return nbm::pack_msplit_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream);
+    if (int rc = nbm::pack_msplit_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream)) return rc;
+    return nbm::pack_f16_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(), (hipStream_t)stream);
 }
 
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream) {
@@ -490,8 +491,10 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, ray_order,
                     white_bkgd,
                     rgb_map, disp_map, acc_map, weights, depth_map, raw);
-    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_BF16X3S,
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_BF16X3S || precision == NB_PREC_F16F8,
                "nb_march: precision %d", precision);
+    if (precision == NB_PREC_F16F8)
+        return nbm::launch_march_f16(a, PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(), (hipStream_t)stream);
     // the M-split kernel has no sample culling: culled marches take the ring kernel (same arithmetic)
     if (precision == NB_PREC_BF16X3S && !cull)
         return nbm::launch_march_msplit(a, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream);

@@ -1,0 +1,649 @@
+// nb_march_f16.hip — "f16f8" march kernel for gfx950 (MI355X): fp16 main product + scaled 8-bit cross terms.
+//
+// Same per-wave organisation as nb_march_bf16.hip (one wave = 32 sample columns, activations resident in registers,
+// layers computed transposed so the C/D fragment of layer l is the B operand of layer l+1, weights streamed through an
+// LDS ring by LDS-DMA), different arithmetic.  With W = W_h + W_l and X = X_h + X_l (fp16 head + remainder):
+//
+//     W.X  ~=  W_h.X_h                                   v_mfma_f32_32x32x16_f16            (products exact, fp32 accumulate)
+//            + fp8(W_h 2^a).bf8(X_l 2^12) 2^-(a+12)      v_mfma_scale_f32_32x32x64_f8f6f4   (K = 64 per instruction; the
+//            + fp8(W_l 2^b).bf8(X_h)      2^-b            E8M0 scale operands undo the 2^k)
+//
+// The cross terms are 2^-11 of the main term, so 3-4 significant bits are enough for them: ~2^-15 relative error per
+// term (round 1's three bf16 products: 2^-16) at 1.8 instead of 3 matrix-pipe units — on MI355X the K=64 scaled 8-bit
+// MFMA costs 1.6x a K=16 fp16 MFMA (profiles/r02_probe_filler.log).  Activations use bf8 e5m2 (fp16's exponent range:
+// nothing to clamp), weights fp8 e4m3 with one power-of-two scale per layer chosen at pack time from max|W_h|, max|W_l|
+// (nb_f16_scales_kernel).  Operand layout of the scaled MFMA (probed, profiles/r02_probe_mx.log): lane l holds
+// row/column l%32 and K elements 32*(l/32)..+31 in its 8 registers, little endian; the scale byte of lane l applies to
+// that row/column and K half.
+//
+// Measured RGB error against the reference renderer over all fixtures: profiles/r02_precision_sweep.md.
+#include <type_traits>
+#include <utility>
+
+#include "nb_march_common.h"
+
+using namespace nbm;
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+namespace nbm {
+
+// --------------------------------------------------------------- weight stream geometry
+// 2-KiB records.  A layer phase (NT output tiles in pairs, NBLK K-blocks of 64, the last block with NCH_LAST 16-wide
+// chunks) is streamed pair by pair, block by block:  M(c) = [A16(c,t0) | A16(c,t1)] for every chunk c of the block, then
+// X8h(t0), X8h(t1), X8l(t0), X8l(t1) = fp8 fragments (64 lanes x 32 B) of W_h and W_l for that block.
+constexpr int FREC_BYTES = 2048;
+constexpr int FPAGE_RECS = 12;
+constexpr int FPAGE_BYTES = FPAGE_RECS * FREC_BYTES;  // 24 KiB
+constexpr int FN_SLOTS = 5;
+constexpr int FAHEAD = FN_SLOTS - 1;
+constexpr int FDMA_PER_WAVE = FPAGE_BYTES / 1024 / 4;  // 6
+
+__host__ __device__ constexpr int recs_per_pair(int nblk, int nch_last) { return (nblk - 1) * 8 + nch_last + 4; }
+__host__ __device__ constexpr int recs_phase(int nt, int nblk, int nch_last) { return (nt / 2) * recs_per_pair(nblk, nch_last); }
+// fc_0 is consumed level by level (levels 0..3 = 32, 64, 128, 128 channels = 16, 32, 64, 64 values per lane)
+constexpr int FR_F0 = 0;
+constexpr int FR_F1 = FR_F0 + recs_phase(8, 1, 2);
+constexpr int FR_F2 = FR_F1 + recs_phase(8, 1, 4);
+constexpr int FR_F3 = FR_F2 + recs_phase(8, 2, 4);
+constexpr int FR_L1 = FR_F3 + recs_phase(8, 2, 4);
+constexpr int FR_L2 = FR_L1 + recs_phase(8, 4, 4);
+constexpr int FR_L4 = FR_L2 + recs_phase(8, 4, 4);
+constexpr int FR_VG = FR_L4 + recs_phase(8, 4, 4);   // view_fc over the merged layer's 256 outputs
+constexpr int FR_VP = FR_VG + recs_phase(4, 4, 4);   // view_fc over the 45 (x2 halves) positional-encoding slots, padded to 64
+constexpr int FN_RECS = FR_VP + recs_phase(4, 2, 2);
+constexpr int FN_PAGES = FN_RECS / FPAGE_RECS;
+static_assert(FN_RECS == 660 && FN_RECS % FPAGE_RECS == 0, "stream must be a whole number of pages");
+static_assert(FN_PAGES % FN_SLOTS == 0, "page p must always land in slot p % FN_SLOTS, also across the step wrap-around");
+constexpr int F_N_SCALES = 16;  // ints behind the stream: E8M0 scale operands (W_h, W_l) of fc_0, fc_1, fc_2, merged, view_fc
+
+}  // namespace nbm
+
+namespace {
+
+// fp32 section of the packed blob (written by nb_pack_kernel, nb_march.hip): offsets in floats
+constexpr int F_OFF_B0 = 8 * 44 * 256;
+constexpr int F_OFF_B1 = F_OFF_B0 + 256 + 8 * 32 * 256;
+constexpr int F_OFF_B2 = F_OFF_B1 + 256 + 8 * 32 * 256;
+constexpr int F_OFF_AW = F_OFF_B2 + 256;
+constexpr int F_OFF_AB = F_OFF_AW + 256;
+constexpr int F_OFF_L4 = F_OFF_AB + 4;
+constexpr int F_OFF_LV = F_OFF_L4 + 8 * 32 * 256;
+constexpr int F_OFF_BV = F_OFF_LV + 4 * 44 * 256;
+constexpr int F_OFF_RW = F_OFF_BV + 128;
+constexpr int F_OFF_RB = F_OFF_RW + 384;
+
+// small parameters staged in LDS behind the ring: offsets in floats (P_SC: the 10 scale operands, ints)
+constexpr int P_B0 = 0, P_B1 = 256, P_B2 = 512, P_LB = 768, P_BV = 1024, P_AW = 1152, P_RW = 1408, P_AB = 1792, P_RB = 1796,
+              P_SC = 1800, P_SIZE = 1800 + F_N_SCALES;
+constexpr int RING_BYTES = FN_SLOTS * FPAGE_BYTES;  // 120 KiB
+constexpr int PARAM_BYTES = 8192;
+constexpr int TILE_BYTES = 8192;
+constexpr int LDS_BYTES = RING_BYTES + PARAM_BYTES + 4 * TILE_BYTES;
+static_assert(LDS_BYTES <= 163840, "LDS budget (160 KiB per workgroup)");
+static_assert((P_SIZE + 4) * 4 <= PARAM_BYTES, "parameter region overflow (4 ints of cull flags follow the parameters)");
+
+typedef const void __attribute__((address_space(1))) *gptr_t;
+typedef void __attribute__((address_space(3))) *lptr_t;
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant expression
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+struct FRing {
+    const char *stream;  // this wave's share of the stream (uniform)
+    char *lds;
+    int wave_off;
+    int lane;
+    char *tile;
+    int base[FN_SLOTS];  // lane * 16 + slot * FPAGE_BYTES
+};
+
+__device__ __forceinline__ void f_issue_page(const FRing &rg, int page) {
+    const int slot = page % FN_SLOTS;
+#pragma unroll
+    for (int i = 0; i < FDMA_PER_WAVE; ++i) {
+        const char *src = rg.stream + (size_t)page * FPAGE_BYTES + i * 1024 + rg.lane * 16;
+        char *dst = rg.lds + slot * FPAGE_BYTES + rg.wave_off + i * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+    }
+}
+
+// before the first record of `page` is read: everything but the DMAs of the FAHEAD-1 younger pages has landed, and every
+// wave is done with the slot that is refilled next
+__device__ __forceinline__ void f_turn_page(const FRing &rg, int page) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((FAHEAD - 1) * FDMA_PER_WAVE) : "memory");
+    asm volatile("s_barrier" ::: "memory");
+    f_issue_page(rg, (page + FAHEAD) % FN_PAGES);
+}
+
+struct Rec {
+    i32x4 p0, p1;  // the lane's two 16-byte pieces of a 2-KiB record
+};
+
+static_assert(FPAGE_BYTES <= 65536, "a page must be addressable with the 16-bit ds_read offset");
+// fragment reads are issued from inline asm (not counted by the compiler) and waited for with hand-counted lgkmcnt,
+// exactly as in nb_march_bf16.hip
+template <int REC>
+__device__ __forceinline__ void load_rec(const FRing &rg, Rec &f) {
+    if (REC % FPAGE_RECS == 0) f_turn_page(rg, REC / FPAGE_RECS);
+    constexpr int slot = (REC / FPAGE_RECS) % FN_SLOTS;
+    constexpr int off = (REC % FPAGE_RECS) * FREC_BYTES;
+    asm volatile(
+        "ds_read_b128 %0, %2 offset:%3\n\t"
+        "ds_read_b128 %1, %2 offset:%4"
+        : "=&v"(f.p0), "=&v"(f.p1)
+        : "v"(rg.base[slot]), "n"(off), "n"(off + 1024)
+        : "memory");
+}
+// LDS operations retire in order: "at most NEWER outstanding" = everything older than the NEWER reads issued last has landed
+template <int NEWER>
+__device__ __forceinline__ void wait_rec(Rec &f) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.p0), "+v"(f.p1) : "n"(NEWER));
+}
+
+__device__ __forceinline__ f32x16 mfma_main(const i32x4 a, const f16x8 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), b, c, 0, 0, 0);
+}
+// A: fp8 e4m3 (cbsz 0), B: bf8 e5m2 (blgp 1); scale operands: E8M0 in byte 0 of each lane's register
+__device__ __forceinline__ f32x16 mfma_cross(const Rec &a, const i32x8 b, const f32x16 c, int scale_a, int scale_b) {
+    const i32x8 av = {a.p0.x, a.p0.y, a.p0.z, a.p0.w, a.p1.x, a.p1.y, a.p1.z, a.p1.w};
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b, c, 0, 1, 0, scale_a, 0, scale_b);
+}
+
+__device__ __forceinline__ f32x16 f_bias_tile(const float *bp, int t, int hi) {
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(bp + (t * 2 + hi) * 16);
+    const f32x4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+    return f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+}
+
+// ---------------------------------------------------------------- operands
+// 16 consecutive values of a lane (one accumulator tile, or 16 gathered features / encodings) in the three forms the
+// MFMAs consume: fp16 head (two K=16 chunks), bf8 of the remainder * 2^12 and bf8 of the value (half a K=64 block each)
+constexpr int LO_SHIFT = 12;  // |X_l| <= 2^-11 |X|: the scaled remainder stays below 2 |X|, inside bf8's range whenever X_h is finite
+
+template <bool RELU, class Get>
+__device__ __forceinline__ void make_ops16(Get get, f16x8 &h0, f16x8 &h1, i32x4 &l, i32x4 &x) {
+    int lw[4], xw[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {  // one 32-bit word of the 8-bit forms = 4 values
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i] = get(4 * w + i);
+            if (RELU) v[i] = relu1(v[i]);
+        }
+        const f16x2 ha = {(_Float16)v[0], (_Float16)v[1]}, hb = {(_Float16)v[2], (_Float16)v[3]};
+        f16x8 &h = w < 2 ? h0 : h1;
+        h[4 * (w & 1) + 0] = ha[0];
+        h[4 * (w & 1) + 1] = ha[1];
+        h[4 * (w & 1) + 2] = hb[0];
+        h[4 * (w & 1) + 3] = hb[1];
+        // the scaled conversion DIVIDES by its scale operand (probed, tools/experiments/probe_cvt.hip)
+        constexpr float inv = 1.0f / (float)(1 << LO_SHIFT);
+        const i16x2 zero = {0, 0};
+        i16x2 lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(zero, v[0] - (float)ha[0], v[1] - (float)ha[1], inv, false);
+        lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(lp, v[2] - (float)hb[0], v[3] - (float)hb[1], inv, true);
+        lw[w] = __builtin_bit_cast(int, lp);
+        int xp = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+        xw[w] = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], xp, true);
+    }
+    l = i32x4{lw[0], lw[1], lw[2], lw[3]};
+    x = i32x4{xw[0], xw[1], xw[2], xw[3]};
+}
+
+__device__ __forceinline__ i32x8 cat8(const i32x4 a, const i32x4 b) { return i32x8{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}; }
+
+// NG groups of 16 values -> 2 NG chunks and ceil(NG / 2) blocks (an odd last group is padded with zeros)
+template <int NG, bool RELU, class Get>
+__device__ __forceinline__ void make_operands(Get get, f16x8 (&xh)[2 * NG], i32x8 (&xl)[(NG + 1) / 2], i32x8 (&xx)[(NG + 1) / 2]) {
+    i32x4 l[NG + 1], x[NG + 1];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) make_ops16<RELU>([&](int i) { return get(16 * g + i); }, xh[2 * g], xh[2 * g + 1], l[g], x[g]);
+    l[NG] = i32x4{0, 0, 0, 0};
+    x[NG] = i32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < (NG + 1) / 2; ++b) {
+        xl[b] = cat8(l[2 * b], l[2 * b + 1]);
+        xx[b] = cat8(x[2 * b], x[2 * b + 1]);
+    }
+    // pin the conversions HERE: they are pure, and left alone the compiler sinks them (and the MFMAs that consume them)
+    // past the fragment reads of the following layer phase, whose records then pile up in registers (238 spills)
+#pragma unroll
+    for (int c = 0; c < 2 * NG; ++c) asm volatile("" : "+v"(xh[c]));
+#pragma unroll
+    for (int b = 0; b < (NG + 1) / 2; ++b) asm volatile("" : "+v"(xl[b]), "+v"(xx[b]));
+}
+
+// ---------------------------------------------------------------- one layer phase
+// acc[NT] (+)= W[:, K range of this phase] . X, X given as NBLK blocks (4 fp16 chunks + bf8 remainder + bf8 value each; the
+// last block may carry only NCH_LAST chunks).  sc_h / sc_l: E8M0 scale operands of W_h / W_l for this layer.
+template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT>
+__device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f32x16 (&acc)[NT], const f16x8 *xh, const i32x8 *xl,
+                                            const i32x8 *xx, int sc_h, int sc_l) {
+    const int hi = rg.lane >> 5;
+    constexpr int RPP = recs_per_pair(NBLK, NCH_LAST);
+    constexpr int NREC = (NT / 2) * RPP;
+    constexpr int SC_XL = 127 - LO_SHIFT, SC_ONE = 127;
+    Rec buf[2];
+    load_rec<REC0>(rg, buf[0]);
+    f32x16 c0, c1;
+    static_for<NREC>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        constexpr int tp = k / RPP, j0 = k % RPP;
+        constexpr int b = j0 / 8 < NBLK - 1 ? j0 / 8 : NBLK - 1;  // every block before the last has 4 + 4 records
+        constexpr int j = j0 - 8 * b;
+        constexpr int nch = b == NBLK - 1 ? NCH_LAST : 4;
+        if (j0 == 0) {
+            if (INIT) {
+                c0 = f_bias_tile(bp, 2 * tp, hi);
+                c1 = f_bias_tile(bp, 2 * tp + 1, hi);
+            } else {
+                c0 = acc[2 * tp];
+                c1 = acc[2 * tp + 1];
+            }
+        }
+        Rec &cur = buf[k & 1];
+        if constexpr (k + 1 < NREC) {
+            load_rec<REC0 + k + 1>(rg, buf[(k + 1) & 1]);
+            wait_rec<2>(cur);
+        } else {
+            wait_rec<0>(cur);
+        }
+        if constexpr (j < nch) {
+            c0 = mfma_main(cur.p0, xh[4 * b + j], c0);
+            c1 = mfma_main(cur.p1, xh[4 * b + j], c1);
+        } else if constexpr (j == nch) {
+            c0 = mfma_cross(cur, xl[b], c0, sc_h, SC_XL);
+        } else if constexpr (j == nch + 1) {
+            c1 = mfma_cross(cur, xl[b], c1, sc_h, SC_XL);
+        } else if constexpr (j == nch + 2) {
+            c0 = mfma_cross(cur, xx[b], c0, sc_l, SC_ONE);
+        } else {
+            c1 = mfma_cross(cur, xx[b], c1, sc_l, SC_ONE);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (j0 == RPP - 1) {
+            // pin the end of the pair's accumulator chains here: the MFMAs are pure, and code sinking otherwise moves the
+            // tail of every chain into the block that first reads the tile (past the next level's gather), keeping the
+            // records they read alive in registers
+            asm volatile("" : "+a"(c0), "+a"(c1));
+            acc[2 * tp] = c0;
+            acc[2 * tp + 1] = c1;
+        }
+    });
+}
+
+// relu (optional) + conversion of a finished 8-tile layer into the next layer's operands: tile t = chunks 2t, 2t+1 and
+// half of block t / 2
+template <bool RELU>
+__device__ __forceinline__ void tiles_to_operands(const f32x16 (&acc)[8], f16x8 (&xh)[16], i32x8 (&xl)[4], i32x8 (&xx)[4]) {
+    make_operands<8, RELU>([&](int i) { return acc[i >> 4][i & 15]; }, xh, xl, xx);
+}
+
+template <int L, int NG>
+__device__ __forceinline__ void level_phase(const SceneDev &sc, const FRing &rg, const GridCoord &g, const WaveBox &wb, const float *bp,
+                                            f32x16 (&acc)[8], int sc_h, int sc_l) {
+    constexpr int REC0 = L == 0 ? FR_F0 : (L == 1 ? FR_F1 : (L == 2 ? FR_F2 : FR_F3));
+    const int hi = rg.lane >> 5;
+    float f[16 * NG];
+    gather_level_coop<L, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
+    f16x8 fh[2 * NG];
+    i32x8 fl[(NG + 1) / 2], fx[(NG + 1) / 2];
+    make_operands<NG, false>([&](int i) { return f[i]; }, fh, fl, fx);
+    layer_phase<REC0, 8, (NG + 1) / 2, NG == 1 ? 2 : 4, L == 0>(rg, bp, acc, fh, fl, fx, sc_h, sc_l);
+}
+
+__device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, float px, float py, float pz, float vx, float vy, float vz,
+                                           float (&pe)[N_PE], float (&out)[4]) {
+    const int hi = rg.lane >> 5;
+    const float *prm = reinterpret_cast<const float *>(rg.lds + RING_BYTES);
+    const int *scl = reinterpret_cast<const int *>(prm + P_SC);
+    f32x16 acc[8];
+    f16x8 xh[16];
+    i32x8 xl[4], xx[4];
+    {
+        // fc_0 level by level: gather one pyramid level (fp32), convert it, accumulate its K range into all 8 tiles
+        const GridCoord g = grid_coords(sc, px, py, pz);
+        const WaveBox wb = wave_box(g);
+        const int sh = scl[0], sl = scl[1];
+        level_phase<0, 1>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
+        level_phase<1, 2>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
+        level_phase<2, 4>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
+        level_phase<3, 4>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
+    }
+    tiles_to_operands<true>(acc, xh, xl, xx);
+    layer_phase<FR_L1, 8, 4, 4, true>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3]);
+    tiles_to_operands<true>(acc, xh, xl, xx);
+    layer_phase<FR_L2, 8, 4, 4, true>(rg, prm + P_B2, acc, xh, xl, xx, scl[4], scl[5]);
+    // alpha_fc in fp32 on the VALU from the un-split fc_2 output
+    {
+        const f32x4 *aw = reinterpret_cast<const f32x4 *>(prm + P_AW + hi * 128);
+        float s = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 32; ++q4) {
+            const f32x4 w = aw[q4];
+            s = fmaf(w.x, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 0]), s);
+            s = fmaf(w.y, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 1]), s);
+            s = fmaf(w.z, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 2]), s);
+            s = fmaf(w.w, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 3]), s);
+        }
+        s = add_halves(s);
+        out[3] = s + prm[P_AB];
+    }
+    tiles_to_operands<true>(acc, xh, xl, xx);
+    layer_phase<FR_L4, 8, 4, 4, true>(rg, prm + P_LB, acc, xh, xl, xx, scl[6], scl[7]);
+    // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings
+    f32x16 v[4];
+    tiles_to_operands<false>(acc, xh, xl, xx);
+    layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, scl[8], scl[9]);
+    {
+        pe_xyz(pe, px, py, pz, vx, vy, vz, hi);
+        f16x8 ph[6];
+        i32x8 pl[2], pxx[2];
+        make_operands<3, false>([&](int i) { return i < N_PE ? pe[i < N_PE ? i : 0] : 0.f; }, ph, pl, pxx);
+        layer_phase<FR_VP, 4, 2, 2, false>(rg, prm + P_BV, v, ph, pl, pxx, scl[8], scl[9]);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const f32x4 *rw = reinterpret_cast<const f32x4 *>(prm + P_RW + (ch * 2 + hi) * 64);
+        float s = 0.f;
+#pragma unroll
+        for (int q4 = 0; q4 < 16; ++q4) {
+            const f32x4 w = rw[q4];
+            s = fmaf(w.x, relu1(v[q4 >> 2][(q4 & 3) * 4 + 0]), s);
+            s = fmaf(w.y, relu1(v[q4 >> 2][(q4 & 3) * 4 + 1]), s);
+            s = fmaf(w.z, relu1(v[q4 >> 2][(q4 & 3) * 4 + 2]), s);
+            s = fmaf(w.w, relu1(v[q4 >> 2][(q4 & 3) * 4 + 3]), s);
+        }
+        s = add_halves(s);
+        out[ch] = s + prm[P_RB + ch];
+    }
+}
+
+__device__ __forceinline__ FRing f_ring_begin(const float *pk, const float *lb, const char *stream, char *lds) {
+    {
+        float *prm = reinterpret_cast<float *>(lds + RING_BYTES);
+        const int *scales = reinterpret_cast<const int *>(stream + (size_t)FN_RECS * FREC_BYTES);
+        for (int i = threadIdx.x; i < P_SIZE; i += 256) {
+            float v;
+            if (i < P_B1) v = pk[F_OFF_B0 + i - P_B0];
+            else if (i < P_B2) v = pk[F_OFF_B1 + i - P_B1];
+            else if (i < P_LB) v = pk[F_OFF_B2 + i - P_B2];
+            else if (i < P_BV) v = lb[i - P_LB];
+            else if (i < P_AW) v = pk[F_OFF_BV + i - P_BV];
+            else if (i < P_RW) v = pk[F_OFF_AW + i - P_AW];
+            else if (i < P_AB) v = pk[F_OFF_RW + i - P_RW];
+            else if (i < P_RB) v = pk[F_OFF_AB + i - P_AB];
+            else if (i < P_SC) v = pk[F_OFF_RB + i - P_RB];
+            else v = __int_as_float(scales[i - P_SC]);
+            prm[i] = v;
+        }
+        __syncthreads();
+    }
+    FRing rg;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    rg.wave_off = wave * (FDMA_PER_WAVE * 1024);
+    rg.stream = stream + rg.wave_off;
+    rg.lds = lds;
+    rg.lane = threadIdx.x & 63;
+    rg.tile = lds + RING_BYTES + PARAM_BYTES + wave * TILE_BYTES;
+#pragma unroll
+    for (int sl = 0; sl < FN_SLOTS; ++sl) {
+        rg.base[sl] = rg.lane * 16 + sl * FPAGE_BYTES;
+        asm volatile("" : "+v"(rg.base[sl]));
+    }
+#pragma unroll
+    for (int p = 0; p < FAHEAD; ++p) f_issue_page(rg, p);
+    return rg;
+}
+
+// ---------------------------------------------------------------- ray mode
+__global__ __launch_bounds__(256) void nb_march_f16_kernel(MarchArgs a, const char *stream) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const FRing rg = f_ring_begin(a.pk, a.lb, stream, lds);
+    const int lane = rg.lane, j = lane & 31, hi = lane >> 5;
+    const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
+    const long long wave = (long long)grp * 4 + rg.wave_off / (FDMA_PER_WAVE * 1024);
+    long long ray = wave * 32 + j;
+    const bool valid = ray < a.n_rays;
+    if (!valid) ray = a.n_rays - 1;
+    if (a.ray_order) ray = a.ray_order[ray];
+    const int S = a.n_samples;
+    const float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
+    const float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
+    const float near = a.near[ray], far = a.far[ray];
+    const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float vx = dx / dn, vy = dy / dn, vz = dz / dn;
+    float pe[N_PE];
+    pe_view(pe, vx, vy, vz, hi);
+    const float *tr = a.t_rand ? a.t_rand + ray * S : nullptr;
+
+    auto z_at = [&](int s) -> float {
+        const float zc = z_lin(near, far, a.t_vals[s]);
+        if (!tr) return zc;
+        const float lower = s == 0 ? zc : 0.5f * __fadd_rn(zc, z_lin(near, far, a.t_vals[s - 1]));
+        const float upper = s == S - 1 ? zc : 0.5f * __fadd_rn(z_lin(near, far, a.t_vals[s + 1]), zc);
+        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), tr[s]));
+    };
+
+    RayAccum ra;
+    WeightStore wstore;
+    float z_cur = z_at(0);
+    for (int s = 0; s < S; ++s) {
+        // see nb_march_bf16.hip: a compiler-visible vmcnt(0) at the top of the step (the pages in flight were requested a
+        // whole step ago) so that the gather's ordinary loads get counted waits; loop-invariant roots are laundered
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        const float z_next = (s + 1 < S) ? z_at(s + 1) : 0.f;
+        const float px = __fadd_rn(ox, __fmul_rn(dx, z_cur));
+        const float py = __fadd_rn(oy, __fmul_rn(dy, z_cur));
+        const float pz = __fadd_rn(oz, __fmul_rn(dz, z_cur));
+        float out[4];
+        int zero = 0, lane_i = rg.lane;
+        asm volatile("" : "+s"(zero), "+v"(lane_i));
+        FRing r2;
+        r2.lds = rg.lds;
+        r2.lane = lane_i;
+        r2.stream = rg.stream + zero;
+        r2.wave_off = rg.wave_off + zero;
+        r2.tile = rg.tile + zero;
+#pragma unroll
+        for (int sl = 0; sl < FN_SLOTS; ++sl) {
+            r2.base[sl] = lane_i * 16 + sl * FPAGE_BYTES;
+            asm volatile("" : "+v"(r2.base[sl]));
+        }
+        // sample culling (nb_cull): a WORKGROUP decision, the four waves walk the weight ring in lock step
+        bool ins = true, run = true;
+        if (a.cull.n_views) {
+            ins = cull_inside(a.cull, a.sc, px, py, pz);
+            int *flags = reinterpret_cast<int *>(rg.lds + RING_BYTES) + P_SIZE;
+            const int any_wave = __any(ins) ? 1 : 0;
+            if (lane_i == 0) flags[rg.wave_off / (FDMA_PER_WAVE * 1024)] = any_wave;
+            __syncthreads();
+            run = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
+            __syncthreads();
+        }
+        if (run) decode_f16(a.sc, r2, px, py, pz, vx, vy, vz, pe, out);
+        if (!ins || !run) out[0] = out[1] = out[2] = out[3] = 0.f;
+        float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
+        dist = __fmul_rn(dist, dn);
+        const float w = ra.add(out, z_cur, dist);
+        wstore.push(a, ray, s, S, hi, valid, w);
+        if (valid && hi == 0 && a.raw)
+            *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
+        z_cur = z_next;
+    }
+    if (valid && hi == 0) ra.store(a, ray);
+    // pages prefetched past the end of the work are still in flight: let them land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+}
+
+// ---------------------------------------------------------------- weight stream packing
+// weight of layer phase `ph` at (output row, operand element q of a lane with half index kg); 0 for padding
+__device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const float *f32_blob, int ph, int row, int q, int kg) {
+    if (ph < 4) {  // fc_0, pyramid level ph: q-th gathered value of the level
+        const int half = lvl_c(ph) / 2;
+        if (q >= half) return 0.f;
+        return p.fc0_w[row * 352 + col_feat(lvl_reg_base(ph) + q, kg)];
+    }
+    if (ph == 4) return p.fc1_w[row * 256 + col_hidden(q, kg)];
+    if (ph == 5) return p.fc2_w[row * 256 + col_hidden(q, kg)];
+    if (ph == 6) {
+        // merged latent_fc[:, :256] @ feature_fc from the fp32 section (computed in fp64 there): invert col_hidden
+        const int col = col_hidden(q, kg);
+        const int tt = col >> 5, rr = col & 31, hi2 = (rr >> 2) & 1, r2 = (rr & 3) + 4 * (rr >> 3), q2 = 16 * tt + r2;
+        return f32_blob[F_OFF_L4 + (((row >> 5) * 32 + (q2 >> 2)) * 64 + (hi2 * 32 + (row & 31))) * 4 + (q2 & 3)];
+    }
+    if (ph == 7) return p.view_w[row * 346 + col_hidden(q, kg)];
+    const int col = col_pe(q, kg);  // q >= 45 -> -1
+    return col < 0 ? 0.f : p.view_w[row * 346 + col];
+}
+__device__ __forceinline__ int phase_layer(int ph) { return ph < 4 ? 0 : (ph < 7 ? ph - 3 : 4); }
+
+struct PhaseGeom {
+    int rec0, nt, nblk, nch_last;
+};
+__device__ __forceinline__ PhaseGeom phase_geom(int ph) {
+    switch (ph) {
+        case 0: return {FR_F0, 8, 1, 2};
+        case 1: return {FR_F1, 8, 1, 4};
+        case 2: return {FR_F2, 8, 2, 4};
+        case 3: return {FR_F3, 8, 2, 4};
+        case 4: return {FR_L1, 8, 4, 4};
+        case 5: return {FR_L2, 8, 4, 4};
+        case 6: return {FR_L4, 8, 4, 4};
+        case 7: return {FR_VG, 4, 4, 4};
+        default: return {FR_VP, 4, 2, 2};
+    }
+}
+
+// per layer: max |W_h| and max |W_l| -> largest power-of-two scales that keep the fp8 images inside +-448, stored as the
+// E8M0 operands (127 - exponent) the scaled MFMA needs to undo them; out[2 * layer] for W_h, out[2 * layer + 1] for W_l
+__global__ void nb_f16_scales_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, int *__restrict__ out) {
+    const int layer = blockIdx.x;  // fc_0, fc_1, fc_2, merged, view_fc
+    __shared__ float mh[256], ml[256];
+    float a = 0.f, b = 0.f;
+    const int ph0 = layer == 0 ? 0 : (layer < 4 ? layer + 3 : 7), ph1 = layer == 0 ? 4 : (layer < 4 ? layer + 4 : 9);
+    for (int ph = ph0; ph < ph1; ++ph) {
+        const PhaseGeom g = phase_geom(ph);
+        const int rows = 32 * g.nt, nq = 32 * g.nblk;
+        for (int e = threadIdx.x; e < rows * nq * 2; e += blockDim.x) {
+            const int kg = e & 1, q = (e >> 1) % nq, row = (e >> 1) / nq;
+            const float w = phase_weight(p, f32_blob, ph, row, q, kg);
+            const float h = (float)(_Float16)w;
+            a = fmaxf(a, fabsf(h));
+            b = fmaxf(b, fabsf(w - h));
+        }
+    }
+    mh[threadIdx.x] = a;
+    ml[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            mh[threadIdx.x] = fmaxf(mh[threadIdx.x], mh[threadIdx.x + s]);
+            ml[threadIdx.x] = fmaxf(ml[threadIdx.x], ml[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 2) {
+        const float m = threadIdx.x == 0 ? mh[0] : ml[0];
+        int e = 0;
+        if (m > 0.f && m < 3.0e38f) {
+            e = ilogbf(448.f / m);          // 2^e <= 448 / m
+            e = min(max(e, -100), 100);
+            if (ldexpf(m, e) > 448.f) --e;  // guard the rounding of the division
+        }
+        out[2 * layer + threadIdx.x] = 127 - e;
+    }
+}
+
+__device__ __forceinline__ unsigned fp8_e4m3_bits(float v) {
+    v = fminf(fmaxf(v, -448.f), 448.f);
+    return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xffu;
+}
+
+// one thread per (record, lane): the lane's 32 bytes of the record
+__global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, const int *__restrict__ scales,
+                                   unsigned *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= FN_RECS * 64) return;
+    const int rec = t >> 6, lane = t & 63, i = lane & 31, kg = lane >> 5;
+    int ph = 8;
+    for (int q = 0; q < 8; ++q)
+        if (rec < phase_geom(q + 1).rec0) {
+            ph = q;
+            break;
+        }
+    const PhaseGeom g = phase_geom(ph);
+    const int rpp = recs_per_pair(g.nblk, g.nch_last);
+    const int rel = rec - g.rec0, tp = rel / rpp, j0 = rel % rpp;
+    const int b = j0 / 8 < g.nblk - 1 ? j0 / 8 : g.nblk - 1, j = j0 - 8 * b, nch = b == g.nblk - 1 ? g.nch_last : 4;
+    unsigned w32[8];
+    if (j < nch) {  // main record: A16(c, t0) | A16(c, t1)
+        const int c = 4 * b + j;
+        for (int half = 0; half < 2; ++half) {
+            const int row = 32 * (2 * tp + half) + i;
+            for (int r = 0; r < 8; r += 2) {
+                const f16x2 hp = {(_Float16)phase_weight(p, f32_blob, ph, row, 8 * c + r, kg),
+                                  (_Float16)phase_weight(p, f32_blob, ph, row, 8 * c + r + 1, kg)};
+                w32[half * 4 + r / 2] = __builtin_bit_cast(unsigned, hp);
+            }
+        }
+    } else {  // X8h(t0), X8h(t1), X8l(t0), X8l(t1): 32 fp8 values of K-block b
+        const int which = j - nch, row = 32 * (2 * tp + (which & 1)) + i, lo = which >> 1;
+        const int e8 = scales[2 * phase_layer(ph) + lo];  // 127 - exponent
+        const float mul = ldexpf(1.f, 127 - e8);
+        for (int e = 0; e < 32; e += 4) {
+            unsigned word = 0;
+            for (int k = 0; k < 4; ++k) {
+                const float w = phase_weight(p, f32_blob, ph, row, 32 * b + e + k, kg);
+                const float h = (float)(_Float16)w;
+                word |= fp8_e4m3_bits((lo ? w - h : h) * mul) << (8 * k);
+            }
+            w32[e / 4] = word;
+        }
+    }
+    // piece 0 (bytes 0..15 of the lane) at lane * 16, piece 1 at 1024 + lane * 16
+    unsigned *recp = out + (size_t)rec * (FREC_BYTES / 4);
+    for (int k = 0; k < 4; ++k) {
+        recp[lane * 4 + k] = w32[k];
+        recp[256 + lane * 4 + k] = w32[4 + k];
+    }
+}
+
+}  // namespace
+
+namespace nbm {
+
+long long f16_stream_floats() { return ((long long)FN_RECS * FREC_BYTES + F_N_SCALES * 4) / 4; }
+
+// `packed` = [fp32 section][bf16 ring stream][M-split stream][f16f8 stream | scales]; stream_off = float offset of the last
+int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st) {
+    unsigned *stream = reinterpret_cast<unsigned *>(packed + stream_off);
+    int *scales = reinterpret_cast<int *>(stream + (size_t)FN_RECS * FREC_BYTES / 4);
+    hipLaunchKernelGGL(nb_f16_scales_kernel, dim3(5), dim3(256), 0, st, *p, packed, scales);
+    NB_CHECK_LAUNCH("nb_f16_scales_kernel");
+    hipLaunchKernelGGL(nb_pack_f16_kernel, dim3(nb_ceil_div((long long)FN_RECS * 64, 256)), dim3(256), 0, st, *p, packed, scales, stream);
+    NB_CHECK_LAUNCH("nb_pack_f16_kernel");
+    return NB_OK;
+}
+
+int launch_march_f16(const MarchArgs &a, long long stream_off, hipStream_t st) {
+    hipLaunchKernelGGL(nb_march_f16_kernel, dim3(a.n_wave_groups), dim3(256), 0, st, a,
+                       reinterpret_cast<const char *>(a.pk + stream_off));
+    NB_CHECK_LAUNCH("nb_march_f16_kernel");
+    return NB_OK;
+}
+
+}  // namespace nbm

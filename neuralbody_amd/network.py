@@ -120,8 +120,8 @@ class Network(nn.Module):
         # decoder GEMM arithmetic: "bf16x3" (split-bf16 MFMA, 3 products, fp32 accumulate) or "f32" (exact
         # fp32 MFMA); both stay inside the 1e-4 RGB parity budget, see DESIGN.md
         self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
-        if self.precision not in ("f32", "bf16x3", "bf16x3s"):
-            raise ValueError("precision must be 'f32', 'bf16x3' or 'bf16x3s'")
+        if self.precision not in ("f32", "bf16x3", "bf16x3s", "f16f8"):
+            raise ValueError("precision must be 'f32', 'bf16x3', 'bf16x3s' or 'f16f8'")
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -151,8 +151,9 @@ class Network(nn.Module):
         return d
 
     def _point_precision(self):
-        """nb_decode_points has two kernel families; 'bf16x3s' only changes how nb_march is organised."""
-        return "bf16x3" if self.precision == "bf16x3s" else self.precision
+        """nb_decode_points has two kernel families (exact fp32, split bf16); the march-only arithmetics ('bf16x3s',
+        'f16f8') decode stand-alone points with the split-bf16 kernels."""
+        return "bf16x3" if self.precision in ("bf16x3s", "f16f8") else self.precision
 
     def packed_weights(self):
         """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed."""

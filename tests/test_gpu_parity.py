@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 ALL = list(scenes.SCENES)
-PRECISIONS = ["f32", "bf16x3", "bf16x3s"]  # nb_march kernel families
+PRECISIONS = ["f32", "bf16x3", "bf16x3s", "f16f8"]  # nb_march kernel families
 POINT_PRECISIONS = ["f32", "bf16x3"]  # nb_decode_points kernel families ("bf16x3s" only reorganises the march)
 
 
