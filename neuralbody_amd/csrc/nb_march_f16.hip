@@ -111,12 +111,16 @@ struct FRing {
 
 __device__ __forceinline__ void f_issue_page(const FRing &rg, int page) {
     const int slot = page % FN_SLOTS;
-#pragma unroll
-    for (int i = 0; i < FDMA_PER_WAVE; ++i) {
-        const char *src = rg.stream + (size_t)page * FPAGE_BYTES + i * 1024 + rg.lane * 16;
-        char *dst = rg.lds + slot * FPAGE_BYTES + rg.wave_off + i * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
-    }
+    // uniform 64-bit base (scalar adds) + the lane's 32-bit byte offset: `global_load_lds_dwordx4 v_off, s[base] offset:imm`
+    const char *base = rg.stream + (size_t)page * FPAGE_BYTES;
+    const unsigned voff = (unsigned)rg.lane * 16u;
+    // the instruction offset (13-bit signed: at most 4095) advances BOTH the global and the LDS address: one M0 value
+    // per four pieces
+    char *dst = rg.lds + slot * FPAGE_BYTES + rg.wave_off;
+    static_for<FDMA_PER_WAVE>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, grp = i / 4, off = (i % 4) * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(base + grp * 4096 + voff), (lptr_t)(dst + grp * 4096), 16, off, 0);
+    });
 }
 
 // before the first record of `page` is read: everything but the DMAs of the FAHEAD-1 younger pages has landed, and every
@@ -172,9 +176,25 @@ __device__ __forceinline__ f32x16 f_bias_tile(const float *bp, int t, int hi) {
 // MFMAs consume: fp16 head (two K=16 chunks), bf8 of the remainder * 2^12 and bf8 of the value (half a K=64 block each)
 constexpr int LO_SHIFT = 12;  // |X_l| <= 2^-11 |X|: the scaled remainder stays below 2 |X|, inside bf8's range whenever X_h is finite
 
+// fp16 head of two values (round to nearest even) and the exact fp32 remainder x - fp16(x) as ONE v_fma_mix_f32 each
+// (hipcc's own lowering of `x - (float)(_Float16)x` converts every value twice: 9 instead of 5 instructions per pair)
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int SEL>
+__device__ __forceinline__ float rem16(float x, unsigned h) {
+    float r;
+    if (SEL == 0) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+    return r;
+}
+
 template <bool RELU, class Get>
 __device__ __forceinline__ void make_ops16(Get get, f16x8 &h0, f16x8 &h1, i32x4 &l, i32x4 &x) {
     int lw[4], xw[4];
+    unsigned hw[8];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {  // one 32-bit word of the 8-bit forms = 4 values
         float v[4];
@@ -183,21 +203,21 @@ __device__ __forceinline__ void make_ops16(Get get, f16x8 &h0, f16x8 &h1, i32x4 
             v[i] = get(4 * w + i);
             if (RELU) v[i] = relu1(v[i]);
         }
-        const f16x2 ha = {(_Float16)v[0], (_Float16)v[1]}, hb = {(_Float16)v[2], (_Float16)v[3]};
-        f16x8 &h = w < 2 ? h0 : h1;
-        h[4 * (w & 1) + 0] = ha[0];
-        h[4 * (w & 1) + 1] = ha[1];
-        h[4 * (w & 1) + 2] = hb[0];
-        h[4 * (w & 1) + 3] = hb[1];
+        const unsigned ha = cvt_pk_f16(v[0], v[1]), hb = cvt_pk_f16(v[2], v[3]);
+        hw[2 * w] = ha;
+        hw[2 * w + 1] = hb;
         // the scaled conversion DIVIDES by its scale operand (probed, tools/experiments/probe_cvt.hip)
         constexpr float inv = 1.0f / (float)(1 << LO_SHIFT);
         const i16x2 zero = {0, 0};
-        i16x2 lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(zero, v[0] - (float)ha[0], v[1] - (float)ha[1], inv, false);
-        lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(lp, v[2] - (float)hb[0], v[3] - (float)hb[1], inv, true);
+        i16x2 lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(zero, rem16<0>(v[0], ha), rem16<1>(v[1], ha), inv, false);
+        lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(lp, rem16<0>(v[2], hb), rem16<1>(v[3], hb), inv, true);
         lw[w] = __builtin_bit_cast(int, lp);
-        int xp = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
+        const int xp = __builtin_amdgcn_cvt_pk_bf8_f32(v[0], v[1], 0, false);
         xw[w] = __builtin_amdgcn_cvt_pk_bf8_f32(v[2], v[3], xp, true);
     }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    h0 = __builtin_bit_cast(f16x8, u32x4{hw[0], hw[1], hw[2], hw[3]});
+    h1 = __builtin_bit_cast(f16x8, u32x4{hw[4], hw[5], hw[6], hw[7]});
     l = i32x4{lw[0], lw[1], lw[2], lw[3]};
     x = i32x4{xw[0], xw[1], xw[2], xw[3]};
 }
@@ -235,8 +255,11 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
     constexpr int RPP = recs_per_pair(NBLK, NCH_LAST);
     constexpr int NREC = (NT / 2) * RPP;
     constexpr int SC_XL = 127 - LO_SHIFT, SC_ONE = 127;
-    Rec buf[2];
+    // fragment reads run TWO records ahead of the MFMAs (one record = 64-100 matrix-pipe cycles, less than the LDS
+    // latency under load)
+    Rec buf[3];
     load_rec<REC0>(rg, buf[0]);
+    if (NREC > 1) load_rec<REC0 + (NREC > 1 ? 1 : 0)>(rg, buf[1]);
     f32x16 c0, c1;
     static_for<NREC>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -253,9 +276,11 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
                 c1 = acc[2 * tp + 1];
             }
         }
-        Rec &cur = buf[k & 1];
-        if constexpr (k + 1 < NREC) {
-            load_rec<REC0 + k + 1>(rg, buf[(k + 1) & 1]);
+        Rec &cur = buf[k % 3];
+        if constexpr (k + 2 < NREC) {
+            load_rec<REC0 + k + 2>(rg, buf[(k + 2) % 3]);
+            wait_rec<4>(cur);
+        } else if constexpr (k + 1 < NREC) {
             wait_rec<2>(cur);
         } else {
             wait_rec<0>(cur);
