@@ -123,12 +123,31 @@ __device__ __forceinline__ void f_issue_page(const FRing &rg, int page) {
     });
 }
 
+// one 1-KiB piece of a page (the lane's 16 bytes): pieces 4, 5 take a second M0 / base (13-bit instruction offset)
+template <int I>
+__device__ __forceinline__ void f_issue_piece(const FRing &rg, int page) {
+    const int slot = page % FN_SLOTS;
+    const char *base = rg.stream + (size_t)page * FPAGE_BYTES;
+    const unsigned voff = (unsigned)rg.lane * 16u;
+    char *dst = rg.lds + slot * FPAGE_BYTES + rg.wave_off;
+    constexpr int grp = I / 4, off = (I % 4) * 1024;
+    __builtin_amdgcn_global_load_lds((gptr_t)(base + grp * 4096 + voff), (lptr_t)(dst + grp * 4096), 16, off, 0);
+}
+
 // before the first record of `page` is read: everything but the DMAs of the FAHEAD-1 younger pages has landed, and every
 // wave is done with the slot that is refilled next
 __device__ __forceinline__ void f_turn_page(const FRing &rg, int page) {
+#ifdef F_ABL_NODMA
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((FAHEAD - 1) * FDMA_PER_WAVE) : "memory");
+#endif
+#ifndef F_ABL_NOBAR
     asm volatile("s_barrier" ::: "memory");
+#endif
+#if !defined(F_ABL_NODMA) && defined(F_DMA_BURST)
     f_issue_page(rg, (page + FAHEAD) % FN_PAGES);
+#endif
 }
 
 struct Rec {
@@ -143,12 +162,23 @@ __device__ __forceinline__ void load_rec(const FRing &rg, Rec &f) {
     if (REC % FPAGE_RECS == 0) f_turn_page(rg, REC / FPAGE_RECS);
     constexpr int slot = (REC / FPAGE_RECS) % FN_SLOTS;
     constexpr int off = (REC % FPAGE_RECS) * FREC_BYTES;
+#ifdef F_ABL_NOLDS
+    asm volatile("" : "=v"(f.p0), "=v"(f.p1) : "v"(rg.base[slot]));
+    return;
+#endif
     asm volatile(
         "ds_read_b128 %0, %2 offset:%3\n\t"
         "ds_read_b128 %1, %2 offset:%4"
         : "=&v"(f.p0), "=&v"(f.p1)
         : "v"(rg.base[slot]), "n"(off), "n"(off + 1024)
         : "memory");
+#if !defined(F_DMA_BURST) && !defined(F_ABL_NODMA)
+    // the six DMA pieces of the page FAHEAD pages ahead ride on the odd records of this page instead of forming a burst
+    // behind the page's barrier (where the matrix pipe has nothing to do); same issue order as the burst, so the
+    // counted vmcnt of f_turn_page is unchanged
+    if constexpr ((REC % FPAGE_RECS) % 2 == 1 && (REC % FPAGE_RECS) / 2 < FDMA_PER_WAVE)
+        f_issue_piece<(REC % FPAGE_RECS) / 2>(rg, (REC / FPAGE_RECS + FAHEAD) % FN_PAGES);
+#endif
 }
 // LDS operations retire in order: "at most NEWER outstanding" = everything older than the NEWER reads issued last has landed
 template <int NEWER>
@@ -157,10 +187,16 @@ __device__ __forceinline__ void wait_rec(Rec &f) {
 }
 
 __device__ __forceinline__ f32x16 mfma_main(const i32x4 a, const f16x8 b, const f32x16 c) {
+#ifdef F_ABL_NOM
+    return c;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), b, c, 0, 0, 0);
 }
 // A: fp8 e4m3 (cbsz 0), B: bf8 e5m2 (blgp 1); scale operands: E8M0 in byte 0 of each lane's register
 __device__ __forceinline__ f32x16 mfma_cross(const Rec &a, const i32x8 b, const f32x16 c, int scale_a, int scale_b) {
+#ifdef F_ABL_NOX
+    return c;
+#endif
     const i32x8 av = {a.p0.x, a.p0.y, a.p0.z, a.p0.w, a.p1.x, a.p1.y, a.p1.z, a.p1.w};
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b, c, 0, 1, 0, scale_a, 0, scale_b);
 }
@@ -176,6 +212,12 @@ __device__ __forceinline__ f32x16 f_bias_tile(const float *bp, int t, int hi) {
 // MFMAs consume: fp16 head (two K=16 chunks), bf8 of the remainder * 2^12 and bf8 of the value (half a K=64 block each)
 constexpr int LO_SHIFT = 12;  // |X_l| <= 2^-11 |X|: the scaled remainder stays below 2 |X|, inside bf8's range whenever X_h is finite
 
+// relu as exactly one v_max_f32 (hipcc lowers fmaxf / fmed3 on a value that feeds inline asm to canonicalise + max)
+__device__ __forceinline__ float relu_asm(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 // fp16 head of two values (round to nearest even) and the exact fp32 remainder x - fp16(x) as ONE v_fma_mix_f32 each
 // (hipcc's own lowering of `x - (float)(_Float16)x` converts every value twice: 9 instead of 5 instructions per pair)
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
@@ -203,6 +245,13 @@ __device__ __forceinline__ void make_ops16(Get get, f16x8 &h0, f16x8 &h1, i32x4 
             v[i] = get(4 * w + i);
             if (RELU) v[i] = relu1(v[i]);
         }
+#ifdef F_ABL_NOCONV
+        hw[2 * w] = __float_as_uint(v[0]);
+        hw[2 * w + 1] = __float_as_uint(v[1]);
+        lw[w] = __float_as_int(v[2]);
+        xw[w] = __float_as_int(v[3]);
+        continue;
+#endif
         const unsigned ha = cvt_pk_f16(v[0], v[1]), hb = cvt_pk_f16(v[2], v[3]);
         hw[2 * w] = ha;
         hw[2 * w + 1] = hb;
@@ -246,21 +295,95 @@ __device__ __forceinline__ void make_operands(Get get, f16x8 (&xh)[2 * NG], i32x
 }
 
 // ---------------------------------------------------------------- one layer phase
+// A finished accumulator tile pair is converted into the next layer's operands IN THE SHADOW of the following pair's
+// MFMAs: 8 slices of 4 values (relu, fp16 head, remainder, two 8-bit packs: ~14 VALU) per tile, one slice behind each of
+// the first 16 records of the next pair, fenced in place with sched_barrier (fillers placed like this are ~70 % hidden,
+// anything left to the scheduler clusters after the MFMAs: profiles/r02_probe_filler.log).  Only the last pair's
+// conversion stays exposed.  `Extra` rides on every slice with the 4 (activated) values: alpha_fc / rgb_fc partial sums.
+struct NoExtra {
+    __device__ __forceinline__ void operator()(int, int, float, float) const {}
+};
+struct NextOps {  // operands of the next layer being assembled word by word
+    unsigned h[64];
+    int l[32], x[32];
+};
+// values 2 * p, 2 * p + 1 (p = 0..7) of `tile` -> their share of tile t's operand words
+template <bool RELU, int P, class Extra>
+__device__ __forceinline__ void cv_slice(const f32x16 &tile, int t, NextOps &o, Extra &&extra) {
+    float v0 = tile[2 * P], v1 = tile[2 * P + 1];
+    if (RELU) {
+        v0 = relu_asm(v0);
+        v1 = relu_asm(v1);
+    }
+#ifdef F_ABL_NOCONV
+    o.h[8 * t + P] = __float_as_uint(v0);
+    o.l[4 * t + (P >> 1)] = __float_as_int(v1);
+    o.x[4 * t + (P >> 1)] = __float_as_int(v0);
+    extra(t, P, v0, v1);
+    return;
+#endif
+    const unsigned h = cvt_pk_f16(v0, v1);
+    o.h[8 * t + P] = h;
+    constexpr float inv = 1.0f / (float)(1 << LO_SHIFT);
+    constexpr int w = P >> 1;
+    if (P & 1) {
+        const i16x2 lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(i16x2, o.l[4 * t + w]), rem16<0>(v0, h), rem16<1>(v1, h), inv, true);
+        o.l[4 * t + w] = __builtin_bit_cast(int, lp);
+        o.x[4 * t + w] = __builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, o.x[4 * t + w], true);
+    } else {
+        const i16x2 zero = {0, 0};
+        const i16x2 lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(zero, rem16<0>(v0, h), rem16<1>(v1, h), inv, false);
+        o.l[4 * t + w] = __builtin_bit_cast(int, lp);
+        o.x[4 * t + w] = __builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false);
+    }
+    extra(t, P, v0, v1);
+}
+template <int NT8>
+__device__ __forceinline__ void ops_from(const NextOps &o, f16x8 (&xh)[2 * NT8], i32x8 (&xl)[NT8 / 2], i32x8 (&xx)[NT8 / 2]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int c = 0; c < 2 * NT8; ++c) xh[c] = __builtin_bit_cast(f16x8, u32x4{o.h[4 * c], o.h[4 * c + 1], o.h[4 * c + 2], o.h[4 * c + 3]});
+#pragma unroll
+    for (int b = 0; b < NT8 / 2; ++b) {
+        xl[b] = i32x8{o.l[8 * b], o.l[8 * b + 1], o.l[8 * b + 2], o.l[8 * b + 3], o.l[8 * b + 4], o.l[8 * b + 5], o.l[8 * b + 6], o.l[8 * b + 7]};
+        xx[b] = i32x8{o.x[8 * b], o.x[8 * b + 1], o.x[8 * b + 2], o.x[8 * b + 3], o.x[8 * b + 4], o.x[8 * b + 5], o.x[8 * b + 6], o.x[8 * b + 7]};
+    }
+}
+
 // acc[NT] (+)= W[:, K range of this phase] . X, X given as NBLK blocks (4 fp16 chunks + bf8 remainder + bf8 value each; the
 // last block may carry only NCH_LAST chunks).  sc_h / sc_l: E8M0 scale operands of W_h / W_l for this layer.
-template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT>
+// CV: 0 = leave the result in acc; 1 / 2 = convert finished tiles into `out` with / without relu (in-flight, see above);
+// 3 = no conversion, but `extra` still sees the relu'd values of every finished tile (rgb_fc over view_fc's output).
+template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT, int CV = 0, class Extra = NoExtra>
 __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f32x16 (&acc)[NT], const f16x8 *xh, const i32x8 *xl,
-                                            const i32x8 *xx, int sc_h, int sc_l) {
+                                            const i32x8 *xx, int sc_h, int sc_l, NextOps *out = nullptr, Extra &&extra = Extra()) {
     const int hi = rg.lane >> 5;
     constexpr int RPP = recs_per_pair(NBLK, NCH_LAST);
     constexpr int NREC = (NT / 2) * RPP;
     constexpr int SC_XL = 127 - LO_SHIFT, SC_ONE = 127;
+    // Conversion slices sit BETWEEN the two MFMAs of a main record (measured, tools/experiments/probe_filler2.hip: a
+    // 9-instruction slice costs +6 % there and +26 % after the pair, in front of the next record's fragment reads and
+    // counted wait).  A pair has NMAIN main records; slices of 2 values when that gives one slice per main record, else of
+    // 4 values with the overflow placed behind the first cross-term MFMAs.
+    constexpr int NMAIN = (NBLK - 1) * 4 + NCH_LAST;
+    constexpr int SPT = NMAIN >= 16 ? 8 : 4;  // slices per tile
+    constexpr int NSL = 2 * SPT;              // slices per pair
+    static_assert(CV == 0 || RPP >= NSL, "the next pair must have one record per slice of the previous pair");
     // fragment reads run TWO records ahead of the MFMAs (one record = 64-100 matrix-pipe cycles, less than the LDS
     // latency under load)
     Rec buf[3];
     load_rec<REC0>(rg, buf[0]);
     if (NREC > 1) load_rec<REC0 + (NREC > 1 ? 1 : 0)>(rg, buf[1]);
     f32x16 c0, c1;
+    auto slice = [&](auto tc, auto sc) {  // slice sc (0..SPT-1) of tile tc: 16 / SPT values
+        constexpr int t = decltype(tc)::value, sl = decltype(sc)::value;
+        static_for<8 / SPT>([&](auto qc) {
+            constexpr int p = sl * (8 / SPT) + decltype(qc)::value;  // value pair 0..7 of the tile
+            if constexpr (CV == 1) cv_slice<true, p>(acc[t], t, *out, extra);
+            else if constexpr (CV == 2) cv_slice<false, p>(acc[t], t, *out, extra);
+            else if constexpr (CV == 3) extra(t, p, relu_asm(acc[t][2 * p]), relu_asm(acc[t][2 * p + 1]));
+        });
+    };
     static_for<NREC>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int tp = k / RPP, j0 = k % RPP;
@@ -285,17 +408,34 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
         } else {
             wait_rec<0>(cur);
         }
+        // slice index carried by this record (-1: none): main record m -> slice m; overflow slices behind cross records
+        constexpr int m = 4 * b + (j < nch ? j : 0);
+        constexpr bool is_main = j < nch;
+        constexpr int n_cross_before = 4 * b + (j >= nch ? j - nch : 0);
+        constexpr int sl_idx = is_main ? (m < NSL ? m : -1) : (NMAIN + n_cross_before < NSL ? NMAIN + n_cross_before : -1);
+        auto run_slice = [&]() {
+            if constexpr (CV != 0 && tp > 0 && sl_idx >= 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                slice(std::integral_constant<int, 2 * (tp - 1) + sl_idx / SPT>{}, std::integral_constant<int, sl_idx % SPT>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         if constexpr (j < nch) {
             c0 = mfma_main(cur.p0, xh[4 * b + j], c0);
+            run_slice();
             c1 = mfma_main(cur.p1, xh[4 * b + j], c1);
         } else if constexpr (j == nch) {
             c0 = mfma_cross(cur, xl[b], c0, sc_h, SC_XL);
+            run_slice();
         } else if constexpr (j == nch + 1) {
             c1 = mfma_cross(cur, xl[b], c1, sc_h, SC_XL);
+            run_slice();
         } else if constexpr (j == nch + 2) {
             c0 = mfma_cross(cur, xx[b], c0, sc_l, SC_ONE);
+            run_slice();
         } else {
             c1 = mfma_cross(cur, xx[b], c1, sc_l, SC_ONE);
+            run_slice();
         }
         __builtin_amdgcn_sched_barrier(0);
         if (j0 == RPP - 1) {
@@ -307,93 +447,128 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             acc[2 * tp + 1] = c1;
         }
     });
+    if constexpr (CV != 0) {  // the last pair: exposed
+        static_for<2 * SPT>([&](auto sc) {
+            constexpr int sl = decltype(sc)::value;
+            slice(std::integral_constant<int, NT - 2 + sl / SPT>{}, std::integral_constant<int, sl % SPT>{});
+        });
+    }
 }
 
-// relu (optional) + conversion of a finished 8-tile layer into the next layer's operands: tile t = chunks 2t, 2t+1 and
-// half of block t / 2
-template <bool RELU>
-__device__ __forceinline__ void tiles_to_operands(const f32x16 (&acc)[8], f16x8 (&xh)[16], i32x8 (&xl)[4], i32x8 (&xx)[4]) {
-    make_operands<8, RELU>([&](int i) { return acc[i >> 4][i & 15]; }, xh, xl, xx);
-}
-
-template <int L, int NG>
+// F_TIMING (experiment builds): wave 0 of workgroup 0 stamps s_memtime at the phase boundaries of every depth step into
+// the `raw` output (tools/experiments/phase_times.py turns them into a cycle budget)
+#ifdef F_TIMING
+#define F_STAMP(i) do { if (tbuf) { const unsigned long long t__ = __builtin_readcyclecounter(); if (rg.lane == 0) tbuf[(i)] = (unsigned)t__; } } while (0)
+#else
+#define F_STAMP(i) do { } while (0)
+#endif
+template <int L, int NG, int CV>
 __device__ __forceinline__ void level_phase(const SceneDev &sc, const FRing &rg, const GridCoord &g, const WaveBox &wb, const float *bp,
-                                            f32x16 (&acc)[8], int sc_h, int sc_l) {
+                                            f32x16 (&acc)[8], int sc_h, int sc_l, NextOps *out, unsigned *tbuf, int stamp0) {
     constexpr int REC0 = L == 0 ? FR_F0 : (L == 1 ? FR_F1 : (L == 2 ? FR_F2 : FR_F3));
     const int hi = rg.lane >> 5;
     float f[16 * NG];
+#ifdef F_ABL_NOGATHER
+#pragma unroll
+    for (int i = 0; i < 16 * NG; ++i) f[i] = g.gw * (float)(i + 1) + g.gh;
+#else
     gather_level_coop<L, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
+#endif
+    F_STAMP(stamp0);
     f16x8 fh[2 * NG];
     i32x8 fl[(NG + 1) / 2], fx[(NG + 1) / 2];
     make_operands<NG, false>([&](int i) { return f[i]; }, fh, fl, fx);
-    layer_phase<REC0, 8, (NG + 1) / 2, NG == 1 ? 2 : 4, L == 0>(rg, bp, acc, fh, fl, fx, sc_h, sc_l);
+    F_STAMP(stamp0 + 1);
+    layer_phase<REC0, 8, (NG + 1) / 2, NG == 1 ? 2 : 4, L == 0, CV>(rg, bp, acc, fh, fl, fx, sc_h, sc_l, out);
 }
 
 __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, float px, float py, float pz, float vx, float vy, float vz,
-                                           float (&pe)[N_PE], float (&out)[4]) {
+                                           float (&pe)[N_PE], float (&out)[4], unsigned *tbuf) {
     const int hi = rg.lane >> 5;
     const float *prm = reinterpret_cast<const float *>(rg.lds + RING_BYTES);
     const int *scl = reinterpret_cast<const int *>(prm + P_SC);
     f32x16 acc[8];
     f16x8 xh[16];
     i32x8 xl[4], xx[4];
+    NextOps nx;
     {
-        // fc_0 level by level: gather one pyramid level (fp32), convert it, accumulate its K range into all 8 tiles
+        // fc_0 level by level: gather one pyramid level (fp32), convert it, accumulate its K range into all 8 tiles;
+        // the last level's phase converts the finished tiles (relu) into fc_1's operands on the fly
         const GridCoord g = grid_coords(sc, px, py, pz);
         const WaveBox wb = wave_box(g);
         const int sh = scl[0], sl = scl[1];
-        level_phase<0, 1>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
-        level_phase<1, 2>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
-        level_phase<2, 4>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
-        level_phase<3, 4>(sc, rg, g, wb, prm + P_B0, acc, sh, sl);
+        F_STAMP(1);
+        level_phase<0, 1, 0>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, nullptr, tbuf, 2);
+        F_STAMP(4);
+        level_phase<1, 2, 0>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, nullptr, tbuf, 5);
+        F_STAMP(7);
+        level_phase<2, 4, 0>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, nullptr, tbuf, 8);
+        F_STAMP(10);
+        level_phase<3, 4, 1>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, &nx, tbuf, 11);
+        F_STAMP(13);
     }
-    tiles_to_operands<true>(acc, xh, xl, xx);
-    layer_phase<FR_L1, 8, 4, 4, true>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3]);
-    tiles_to_operands<true>(acc, xh, xl, xx);
-    layer_phase<FR_L2, 8, 4, 4, true>(rg, prm + P_B2, acc, xh, xl, xx, scl[4], scl[5]);
-    // alpha_fc in fp32 on the VALU from the un-split fc_2 output
+    ops_from<8>(nx, xh, xl, xx);
+    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx);
+    F_STAMP(14);
+    ops_from<8>(nx, xh, xl, xx);
+    // fc_2.  alpha_fc (fp32, VALU) is NOT folded into the conversion slices: its weights come from LDS, and a
+    // compiler-visible LDS read inside the record loop makes hipcc wait lgkmcnt(0), which drains the fragment prefetch
+    // at every slice (measured with F_TIMING: fc_2 took 22.5k cycles against 13.3k for the identical fc_1).  It runs on
+    // the finished accumulators before the tail conversion overwrites nothing it needs (acc stays intact).
+    layer_phase<FR_L2, 8, 4, 4, true, 1>(rg, prm + P_B2, acc, xh, xl, xx, scl[4], scl[5], &nx);
+    float s_alpha = 0.f;
     {
         const f32x4 *aw = reinterpret_cast<const f32x4 *>(prm + P_AW + hi * 128);
-        float s = 0.f;
 #pragma unroll
         for (int q4 = 0; q4 < 32; ++q4) {
             const f32x4 w = aw[q4];
-            s = fmaf(w.x, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 0]), s);
-            s = fmaf(w.y, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 1]), s);
-            s = fmaf(w.z, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 2]), s);
-            s = fmaf(w.w, relu1(acc[q4 >> 2][(q4 & 3) * 4 + 3]), s);
+            s_alpha = fmaf(w.x, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 0]), s_alpha);
+            s_alpha = fmaf(w.y, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 1]), s_alpha);
+            s_alpha = fmaf(w.z, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 2]), s_alpha);
+            s_alpha = fmaf(w.w, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 3]), s_alpha);
         }
-        s = add_halves(s);
-        out[3] = s + prm[P_AB];
     }
-    tiles_to_operands<true>(acc, xh, xl, xx);
-    layer_phase<FR_L4, 8, 4, 4, true>(rg, prm + P_LB, acc, xh, xl, xx, scl[6], scl[7]);
-    // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings
+    out[3] = add_halves(s_alpha) + prm[P_AB];
+    F_STAMP(15);
+    ops_from<8>(nx, xh, xl, xx);
+    layer_phase<FR_L4, 8, 4, 4, true, 2>(rg, prm + P_LB, acc, xh, xl, xx, scl[6], scl[7], &nx);
+    F_STAMP(16);
+    ops_from<8>(nx, xh, xl, xx);
+    // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings; rgb_fc (fp32,
+    // VALU) rides on the finished tiles of the second phase
     f32x16 v[4];
-    tiles_to_operands<false>(acc, xh, xl, xx);
     layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, scl[8], scl[9]);
+    F_STAMP(17);
+    float s_rgb[3] = {0.f, 0.f, 0.f};
     {
+#ifdef F_ABL_NOPE
+#pragma unroll
+        for (int c = 12; c < N_PE; ++c) pe[c] = px * (float)c;
+#else
         pe_xyz(pe, px, py, pz, vx, vy, vz, hi);
+#endif
         f16x8 ph[6];
         i32x8 pl[2], pxx[2];
         make_operands<3, false>([&](int i) { return i < N_PE ? pe[i < N_PE ? i : 0] : 0.f; }, ph, pl, pxx);
+        F_STAMP(18);
         layer_phase<FR_VP, 4, 2, 2, false>(rg, prm + P_BV, v, ph, pl, pxx, scl[8], scl[9]);
     }
+    // rgb_fc in fp32 on the VALU (outside the record loop for the same reason as alpha_fc)
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const f32x4 *rw = reinterpret_cast<const f32x4 *>(prm + P_RW + (ch * 2 + hi) * 64);
-        float s = 0.f;
 #pragma unroll
         for (int q4 = 0; q4 < 16; ++q4) {
             const f32x4 w = rw[q4];
-            s = fmaf(w.x, relu1(v[q4 >> 2][(q4 & 3) * 4 + 0]), s);
-            s = fmaf(w.y, relu1(v[q4 >> 2][(q4 & 3) * 4 + 1]), s);
-            s = fmaf(w.z, relu1(v[q4 >> 2][(q4 & 3) * 4 + 2]), s);
-            s = fmaf(w.w, relu1(v[q4 >> 2][(q4 & 3) * 4 + 3]), s);
+            s_rgb[ch] = fmaf(w.x, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 0]), s_rgb[ch]);
+            s_rgb[ch] = fmaf(w.y, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 1]), s_rgb[ch]);
+            s_rgb[ch] = fmaf(w.z, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 2]), s_rgb[ch]);
+            s_rgb[ch] = fmaf(w.w, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 3]), s_rgb[ch]);
         }
-        s = add_halves(s);
-        out[ch] = s + prm[P_RB + ch];
     }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) out[ch] = add_halves(s_rgb[ch]) + prm[P_RB + ch];
+    F_STAMP(19);
 }
 
 __device__ __forceinline__ FRing f_ring_begin(const float *pk, const float *lb, const char *stream, char *lds) {
@@ -498,14 +673,24 @@ __global__ __launch_bounds__(256) void nb_march_f16_kernel(MarchArgs a, const ch
             run = __builtin_amdgcn_readfirstlane(flags[0] | flags[1] | flags[2] | flags[3]) != 0;
             __syncthreads();
         }
-        if (run) decode_f16(a.sc, r2, px, py, pz, vx, vy, vz, pe, out);
+#ifdef F_TIMING
+        unsigned *tbuf = (blockIdx.x == 0 && rg.wave_off == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + 32 * s : nullptr;
+        if (tbuf && lane_i == 0) tbuf[0] = (unsigned)__builtin_readcyclecounter();
+#else
+        unsigned *tbuf = nullptr;
+#endif
+        if (run) decode_f16(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, tbuf);
         if (!ins || !run) out[0] = out[1] = out[2] = out[3] = 0.f;
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
         const float w = ra.add(out, z_cur, dist);
         wstore.push(a, ray, s, S, hi, valid, w);
+#ifdef F_TIMING
+        if (tbuf && lane_i == 0) tbuf[20] = (unsigned)__builtin_readcyclecounter();
+#else
         if (valid && hi == 0 && a.raw)
             *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
+#endif
         z_cur = z_next;
     }
     if (valid && hi == 0) ra.store(a, ray);
