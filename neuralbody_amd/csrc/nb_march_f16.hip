@@ -198,6 +198,9 @@ __device__ __forceinline__ f32x16 mfma_cross(const Rec &a, const i32x8 b, const 
     return c;
 #endif
     const i32x8 av = {a.p0.x, a.p0.y, a.p0.z, a.p0.w, a.p1.x, a.p1.y, a.p1.z, a.p1.w};
+#ifdef F_ABL_UNSCALED
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b, c, 0, 1, 0, 0, 0, 0);
+#endif
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b, c, 0, 1, 0, scale_a, 0, scale_b);
 }
 
@@ -356,7 +359,8 @@ __device__ __forceinline__ void ops_from(const NextOps &o, f16x8 (&xh)[2 * NT8],
 // 3 = no conversion, but `extra` still sees the relu'd values of every finished tile (rgb_fc over view_fc's output).
 template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT, int CV = 0, class Extra = NoExtra>
 __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f32x16 (&acc)[NT], const f16x8 *xh, const i32x8 *xl,
-                                            const i32x8 *xx, int sc_h, int sc_l, NextOps *out = nullptr, Extra &&extra = Extra()) {
+                                            const i32x8 *xx, int sc_h, int sc_l, NextOps *out = nullptr, Extra &&extra = Extra(),
+                                            unsigned *trace = nullptr) {
     const int hi = rg.lane >> 5;
     constexpr int RPP = recs_per_pair(NBLK, NCH_LAST);
     constexpr int NREC = (NT / 2) * RPP;
@@ -371,9 +375,14 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
     static_assert(CV == 0 || RPP >= NSL, "the next pair must have one record per slice of the previous pair");
     // fragment reads run TWO records ahead of the MFMAs (one record = 64-100 matrix-pipe cycles, less than the LDS
     // latency under load)
-    Rec buf[3];
-    load_rec<REC0>(rg, buf[0]);
-    if (NREC > 1) load_rec<REC0 + (NREC > 1 ? 1 : 0)>(rg, buf[1]);
+#ifndef F_PF
+#define F_PF 2  // records of lookahead
+#endif
+    Rec buf[F_PF + 1];
+    static_for<F_PF>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr (i < NREC) load_rec<REC0 + i>(rg, buf[i]);
+    });
     f32x16 c0, c1;
     auto slice = [&](auto tc, auto sc) {  // slice sc (0..SPT-1) of tile tc: 16 / SPT values
         constexpr int t = decltype(tc)::value, sl = decltype(sc)::value;
@@ -399,14 +408,12 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
                 c1 = acc[2 * tp + 1];
             }
         }
-        Rec &cur = buf[k % 3];
-        if constexpr (k + 2 < NREC) {
-            load_rec<REC0 + k + 2>(rg, buf[(k + 2) % 3]);
-            wait_rec<4>(cur);
-        } else if constexpr (k + 1 < NREC) {
-            wait_rec<2>(cur);
+        Rec &cur = buf[k % (F_PF + 1)];
+        if constexpr (k + F_PF < NREC) {
+            load_rec<REC0 + k + F_PF>(rg, buf[(k + F_PF) % (F_PF + 1)]);
+            wait_rec<2 * F_PF>(cur);
         } else {
-            wait_rec<0>(cur);
+            wait_rec<2 * (NREC - 1 - k)>(cur);
         }
         // slice index carried by this record (-1: none): main record m -> slice m; overflow slices behind cross records
         constexpr int m = 4 * b + (j < nch ? j : 0);
@@ -438,6 +445,12 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             run_slice();
         }
         __builtin_amdgcn_sched_barrier(0);
+#ifdef F_TIMING
+        if (trace) {
+            const unsigned long long t__ = __builtin_readcyclecounter();
+            if (rg.lane == 0) trace[k] = (unsigned)t__;
+        }
+#endif
         if (j0 == RPP - 1) {
             // pin the end of the pair's accumulator chains here: the MFMAs are pure, and code sinking otherwise moves the
             // tail of every chain into the block that first reads the tile (past the next level's gather), keeping the
@@ -483,7 +496,7 @@ __device__ __forceinline__ void level_phase(const SceneDev &sc, const FRing &rg,
 }
 
 __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, float px, float py, float pz, float vx, float vy, float vz,
-                                           float (&pe)[N_PE], float (&out)[4], unsigned *tbuf) {
+                                           float (&pe)[N_PE], float (&out)[4], unsigned *tbuf, unsigned *tbuf0 = nullptr) {
     const int hi = rg.lane >> 5;
     const float *prm = reinterpret_cast<const float *>(rg.lds + RING_BYTES);
     const int *scl = reinterpret_cast<const int *>(prm + P_SC);
@@ -508,7 +521,11 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         F_STAMP(13);
     }
     ops_from<8>(nx, xh, xl, xx);
+#ifdef F_TIMING
+    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx, NoExtra(), tbuf ? tbuf + 8192 + 96 * ((tbuf - tbuf0) / 32) : nullptr);
+#else
     layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx);
+#endif
     F_STAMP(14);
     ops_from<8>(nx, xh, xl, xx);
     // fc_2.  alpha_fc (fp32, VALU) is NOT folded into the conversion slices: its weights come from LDS, and a
@@ -679,7 +696,7 @@ __global__ __launch_bounds__(256) void nb_march_f16_kernel(MarchArgs a, const ch
 #else
         unsigned *tbuf = nullptr;
 #endif
-        if (run) decode_f16(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, tbuf);
+        if (run) decode_f16(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, tbuf, reinterpret_cast<unsigned *>(a.raw));
         if (!ins || !run) out[0] = out[1] = out[2] = out[3] = 0.f;
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);

@@ -33,3 +33,11 @@ tot = d.sum(1).mean()
 for i in range(1, 21):
     print("| %s | %.0f | %.1f %% |" % (NAMES[i], d[:, i - 1].mean(), 100 * d[:, i - 1].mean() / tot))
 print("| one depth step | %.0f | |" % tot)
+
+# per-record trace of fc_1 (F_TIMING): cycles between consecutive records, averaged over the steps
+tr = out["raw"].view(torch.int32).reshape(-1)[8192:8192 + 64 * 128].cpu().numpy().astype(np.int64).reshape(64, 128)
+dr = (np.diff(tr, axis=1) & 0xffffffff)[2:-1]
+m = dr.mean(0)
+print("fc_1 record-to-record cycles (records 1..127; a pair = 32 records: 4 x [4 main, 4 cross]; page turns every 12):")
+for i in range(0, 127, 16):
+    print(" ".join("%4d" % v for v in m[i:i + 16]))
