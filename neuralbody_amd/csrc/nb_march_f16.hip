@@ -43,8 +43,15 @@ constexpr int FN_SLOTS = 5;
 constexpr int FAHEAD = FN_SLOTS - 1;
 constexpr int FDMA_PER_WAVE = FPAGE_BYTES / 1024 / 4;  // 6
 
-__host__ __device__ constexpr int recs_per_pair(int nblk, int nch_last) { return (nblk - 1) * 8 + nch_last + 4; }
-__host__ __device__ constexpr int recs_phase(int nt, int nblk, int nch_last) { return (nt / 2) * recs_per_pair(nblk, nch_last); }
+// x = 0: a phase WITHOUT cross-term records (single fp16 product)
+__host__ __device__ constexpr int recs_per_pair(int nblk, int nch_last, int x = 1) { return (nblk - 1) * (4 + 4 * x) + nch_last + 4 * x; }
+__host__ __device__ constexpr int recs_phase(int nt, int nblk, int nch_last, int x = 1) { return (nt / 2) * recs_per_pair(nblk, nch_last, x); }
+// The merged feature_fc / latent_fc layer runs as a single fp16 product: its output only feeds the colour head, and the
+// measured sensitivity (profiles/r02_precision_sweep.md) leaves room for it (worst fixture 4.2e-5 of the 1e-4 budget
+// against 9e-6 with the cross terms); -DF_MERGED_X=1 restores the cross terms.
+#ifndef F_MERGED_X
+#define F_MERGED_X 0
+#endif
 // fc_0 is consumed level by level (levels 0..3 = 32, 64, 128, 128 channels = 16, 32, 64, 64 values per lane)
 constexpr int FR_F0 = 0;
 constexpr int FR_F1 = FR_F0 + recs_phase(8, 1, 2);
@@ -53,11 +60,12 @@ constexpr int FR_F3 = FR_F2 + recs_phase(8, 2, 4);
 constexpr int FR_L1 = FR_F3 + recs_phase(8, 2, 4);
 constexpr int FR_L2 = FR_L1 + recs_phase(8, 4, 4);
 constexpr int FR_L4 = FR_L2 + recs_phase(8, 4, 4);
-constexpr int FR_VG = FR_L4 + recs_phase(8, 4, 4);   // view_fc over the merged layer's 256 outputs
+constexpr int FR_VG = FR_L4 + recs_phase(8, 4, 4, F_MERGED_X);   // view_fc over the merged layer's 256 outputs
 constexpr int FR_VP = FR_VG + recs_phase(4, 4, 4);   // view_fc over the 45 (x2 halves) positional-encoding slots, padded to 64
 constexpr int FN_RECS = FR_VP + recs_phase(4, 2, 2);
-constexpr int FN_PAGES = FN_RECS / FPAGE_RECS;
-static_assert(FN_RECS == 660 && FN_RECS % FPAGE_RECS == 0, "stream must be a whole number of pages");
+constexpr int FN_RECS_PAD = (FN_RECS + 5 * FPAGE_RECS - 1) / (5 * FPAGE_RECS) * (5 * FPAGE_RECS);  // zero records up to a multiple of FN_SLOTS pages
+static_assert(FN_RECS == 596 + 64 * F_MERGED_X, "record count");
+constexpr int FN_PAGES = FN_RECS_PAD / FPAGE_RECS;
 static_assert(FN_PAGES % FN_SLOTS == 0, "page p must always land in slot p % FN_SLOTS, also across the step wrap-around");
 constexpr int F_N_SCALES = 16;  // ints behind the stream: E8M0 scale operands (W_h, W_l) of fc_0, fc_1, fc_2, merged, view_fc
 
@@ -311,7 +319,7 @@ struct NextOps {  // operands of the next layer being assembled word by word
     int l[32], x[32];
 };
 // values 2 * p, 2 * p + 1 (p = 0..7) of `tile` -> their share of tile t's operand words
-template <bool RELU, int P, class Extra>
+template <bool RELU, int P, bool HEAD_ONLY = false, class Extra>
 __device__ __forceinline__ void cv_slice(const f32x16 &tile, int t, NextOps &o, Extra &&extra) {
     float v0 = tile[2 * P], v1 = tile[2 * P + 1];
     if (RELU) {
@@ -327,6 +335,10 @@ __device__ __forceinline__ void cv_slice(const f32x16 &tile, int t, NextOps &o, 
 #endif
     const unsigned h = cvt_pk_f16(v0, v1);
     o.h[8 * t + P] = h;
+    if constexpr (HEAD_ONLY) {
+        extra(t, P, v0, v1);
+        return;
+    }
     constexpr float inv = 1.0f / (float)(1 << LO_SHIFT);
     constexpr int w = P >> 1;
     if (P & 1) {
@@ -357,12 +369,13 @@ __device__ __forceinline__ void ops_from(const NextOps &o, f16x8 (&xh)[2 * NT8],
 // last block may carry only NCH_LAST chunks).  sc_h / sc_l: E8M0 scale operands of W_h / W_l for this layer.
 // CV: 0 = leave the result in acc; 1 / 2 = convert finished tiles into `out` with / without relu (in-flight, see above);
 // 3 = no conversion, but `extra` still sees the relu'd values of every finished tile (rgb_fc over view_fc's output).
-template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT, int CV = 0, class Extra = NoExtra>
+template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT, int CV = 0, class Extra = NoExtra, int XT = 1>
 __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f32x16 (&acc)[NT], const f16x8 *xh, const i32x8 *xl,
                                             const i32x8 *xx, int sc_h, int sc_l, NextOps *out = nullptr, Extra &&extra = Extra(),
                                             unsigned *trace = nullptr) {
     const int hi = rg.lane >> 5;
-    constexpr int RPP = recs_per_pair(NBLK, NCH_LAST);
+    constexpr int RPP = recs_per_pair(NBLK, NCH_LAST, XT);
+    constexpr int BR = 4 + 4 * XT;  // records per full block
     constexpr int NREC = (NT / 2) * RPP;
     constexpr int SC_XL = 127 - LO_SHIFT, SC_ONE = 127;
     // Conversion slices sit BETWEEN the two MFMAs of a main record (measured, tools/experiments/probe_filler2.hip: a
@@ -390,14 +403,15 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             constexpr int p = sl * (8 / SPT) + decltype(qc)::value;  // value pair 0..7 of the tile
             if constexpr (CV == 1) cv_slice<true, p>(acc[t], t, *out, extra);
             else if constexpr (CV == 2) cv_slice<false, p>(acc[t], t, *out, extra);
+            else if constexpr (CV == 4) cv_slice<true, p, true>(acc[t], t, *out, extra);  // relu, fp16 heads only
             else if constexpr (CV == 3) extra(t, p, relu_asm(acc[t][2 * p]), relu_asm(acc[t][2 * p + 1]));
         });
     };
     static_for<NREC>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int tp = k / RPP, j0 = k % RPP;
-        constexpr int b = j0 / 8 < NBLK - 1 ? j0 / 8 : NBLK - 1;  // every block before the last has 4 + 4 records
-        constexpr int j = j0 - 8 * b;
+        constexpr int b = j0 / BR < NBLK - 1 ? j0 / BR : NBLK - 1;  // every block before the last has 4 (+ 4) records
+        constexpr int j = j0 - BR * b;
         constexpr int nch = b == NBLK - 1 ? NCH_LAST : 4;
         if (j0 == 0) {
             if (INIT) {
@@ -532,7 +546,7 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     // compiler-visible LDS read inside the record loop makes hipcc wait lgkmcnt(0), which drains the fragment prefetch
     // at every slice (measured with F_TIMING: fc_2 took 22.5k cycles against 13.3k for the identical fc_1).  It runs on
     // the finished accumulators before the tail conversion overwrites nothing it needs (acc stays intact).
-    layer_phase<FR_L2, 8, 4, 4, true, 1>(rg, prm + P_B2, acc, xh, xl, xx, scl[4], scl[5], &nx);
+    layer_phase<FR_L2, 8, 4, 4, true, F_MERGED_X ? 1 : 4>(rg, prm + P_B2, acc, xh, xl, xx, scl[4], scl[5], &nx);
     float s_alpha = 0.f;
     {
         const f32x4 *aw = reinterpret_cast<const f32x4 *>(prm + P_AW + hi * 128);
@@ -548,7 +562,7 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     out[3] = add_halves(s_alpha) + prm[P_AB];
     F_STAMP(15);
     ops_from<8>(nx, xh, xl, xx);
-    layer_phase<FR_L4, 8, 4, 4, true, 2>(rg, prm + P_LB, acc, xh, xl, xx, scl[6], scl[7], &nx);
+    layer_phase<FR_L4, 8, 4, 4, true, 2, NoExtra, F_MERGED_X>(rg, prm + P_LB, acc, xh, xl, xx, scl[6], scl[7], &nx);
     F_STAMP(16);
     ops_from<8>(nx, xh, xl, xx);
     // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings; rgb_fc (fp32,
@@ -585,13 +599,21 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     }
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) out[ch] = add_halves(s_rgb[ch]) + prm[P_RB + ch];
+#if !defined(F_DMA_BURST) && !defined(F_ABL_NODMA)
+    // the stream is zero-padded to a whole number of ring rounds: the DMA pieces that would ride on the padding records
+    static_for<FN_RECS_PAD - FN_RECS>([&](auto ic) {
+        constexpr int REC = FN_RECS + decltype(ic)::value;
+        if constexpr ((REC % FPAGE_RECS) % 2 == 1 && (REC % FPAGE_RECS) / 2 < FDMA_PER_WAVE)
+            f_issue_piece<(REC % FPAGE_RECS) / 2>(rg, (REC / FPAGE_RECS + FAHEAD) % FN_PAGES);
+    });
+#endif
     F_STAMP(19);
 }
 
 __device__ __forceinline__ FRing f_ring_begin(const float *pk, const float *lb, const char *stream, char *lds) {
     {
         float *prm = reinterpret_cast<float *>(lds + RING_BYTES);
-        const int *scales = reinterpret_cast<const int *>(stream + (size_t)FN_RECS * FREC_BYTES);
+        const int *scales = reinterpret_cast<const int *>(stream + (size_t)FN_RECS_PAD * FREC_BYTES);
         for (int i = threadIdx.x; i < P_SIZE; i += 256) {
             float v;
             if (i < P_B1) v = pk[F_OFF_B0 + i - P_B0];
@@ -739,19 +761,19 @@ __device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const floa
 __device__ __forceinline__ int phase_layer(int ph) { return ph < 4 ? 0 : (ph < 7 ? ph - 3 : 4); }
 
 struct PhaseGeom {
-    int rec0, nt, nblk, nch_last;
+    int rec0, nt, nblk, nch_last, x;
 };
 __device__ __forceinline__ PhaseGeom phase_geom(int ph) {
     switch (ph) {
-        case 0: return {FR_F0, 8, 1, 2};
-        case 1: return {FR_F1, 8, 1, 4};
-        case 2: return {FR_F2, 8, 2, 4};
-        case 3: return {FR_F3, 8, 2, 4};
-        case 4: return {FR_L1, 8, 4, 4};
-        case 5: return {FR_L2, 8, 4, 4};
-        case 6: return {FR_L4, 8, 4, 4};
-        case 7: return {FR_VG, 4, 4, 4};
-        default: return {FR_VP, 4, 2, 2};
+        case 0: return {FR_F0, 8, 1, 2, 1};
+        case 1: return {FR_F1, 8, 1, 4, 1};
+        case 2: return {FR_F2, 8, 2, 4, 1};
+        case 3: return {FR_F3, 8, 2, 4, 1};
+        case 4: return {FR_L1, 8, 4, 4, 1};
+        case 5: return {FR_L2, 8, 4, 4, 1};
+        case 6: return {FR_L4, 8, 4, 4, F_MERGED_X};
+        case 7: return {FR_VG, 4, 4, 4, 1};
+        default: return {FR_VP, 4, 2, 2, 1};
     }
 }
 
@@ -804,8 +826,13 @@ __device__ __forceinline__ unsigned fp8_e4m3_bits(float v) {
 __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, const int *__restrict__ scales,
                                    unsigned *__restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= FN_RECS * 64) return;
+    if (t >= FN_RECS_PAD * 64) return;
     const int rec = t >> 6, lane = t & 63, i = lane & 31, kg = lane >> 5;
+    if (rec >= FN_RECS) {  // padding records: never read, zero for determinism
+        unsigned *padp = out + (size_t)rec * (FREC_BYTES / 4);
+        for (int k = 0; k < 4; ++k) padp[lane * 4 + k] = padp[256 + lane * 4 + k] = 0u;
+        return;
+    }
     int ph = 8;
     for (int q = 0; q < 8; ++q)
         if (rec < phase_geom(q + 1).rec0) {
@@ -813,9 +840,9 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
             break;
         }
     const PhaseGeom g = phase_geom(ph);
-    const int rpp = recs_per_pair(g.nblk, g.nch_last);
+    const int rpp = recs_per_pair(g.nblk, g.nch_last, g.x), br = 4 + 4 * g.x;
     const int rel = rec - g.rec0, tp = rel / rpp, j0 = rel % rpp;
-    const int b = j0 / 8 < g.nblk - 1 ? j0 / 8 : g.nblk - 1, j = j0 - 8 * b, nch = b == g.nblk - 1 ? g.nch_last : 4;
+    const int b = j0 / br < g.nblk - 1 ? j0 / br : g.nblk - 1, j = j0 - br * b, nch = b == g.nblk - 1 ? g.nch_last : 4;
     unsigned w32[8];
     if (j < nch) {  // main record: A16(c, t0) | A16(c, t1)
         const int c = 4 * b + j;
@@ -853,15 +880,15 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
 
 namespace nbm {
 
-long long f16_stream_floats() { return ((long long)FN_RECS * FREC_BYTES + F_N_SCALES * 4) / 4; }
+long long f16_stream_floats() { return ((long long)FN_RECS_PAD * FREC_BYTES + F_N_SCALES * 4) / 4; }
 
 // `packed` = [fp32 section][bf16 ring stream][M-split stream][f16f8 stream | scales]; stream_off = float offset of the last
 int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st) {
     unsigned *stream = reinterpret_cast<unsigned *>(packed + stream_off);
-    int *scales = reinterpret_cast<int *>(stream + (size_t)FN_RECS * FREC_BYTES / 4);
+    int *scales = reinterpret_cast<int *>(stream + (size_t)FN_RECS_PAD * FREC_BYTES / 4);
     hipLaunchKernelGGL(nb_f16_scales_kernel, dim3(5), dim3(256), 0, st, *p, packed, scales);
     NB_CHECK_LAUNCH("nb_f16_scales_kernel");
-    hipLaunchKernelGGL(nb_pack_f16_kernel, dim3(nb_ceil_div((long long)FN_RECS * 64, 256)), dim3(256), 0, st, *p, packed, scales, stream);
+    hipLaunchKernelGGL(nb_pack_f16_kernel, dim3(nb_ceil_div((long long)FN_RECS_PAD * 64, 256)), dim3(256), 0, st, *p, packed, scales, stream);
     NB_CHECK_LAUNCH("nb_pack_f16_kernel");
     return NB_OK;
 }

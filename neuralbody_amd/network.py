@@ -31,7 +31,7 @@ ENCODER_BLOCKS = [
 ]
 DENSE_AFTER = ("conv1", "conv2", "conv3", "conv4")  # latent_xyzc.py:188-201
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
-DEFAULT_PRECISION = "bf16x3"
+DEFAULT_PRECISION = "f16f8"
 
 
 class SparseConv3dParam(nn.Module):

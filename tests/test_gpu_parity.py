@@ -303,7 +303,10 @@ def test_render_end_to_end_matches_reference(name, precision):
         vols = net.encode_sparse_voxels(sp) if r["mode"] != "train" else None
         if vols is not None:
             pv = rend.get_pixel_value(bd["ray_o"], bd["ray_d"], bd["near"], bd["far"], vols, sp, bd)
-            H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 1e-5, "fused vs unfused rgb")
+            # the unfused path decodes points with the split-bf16 kernels whatever the march arithmetic is: for 'f16f8' the
+            # two sides round differently (each within its own budget against the reference), otherwise they agree closely
+            H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 6e-5 if precision == "f16f8" else 1e-5,
+                           "fused vs unfused rgb")
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
