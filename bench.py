@@ -11,6 +11,12 @@ seed 0).  One STEP = `Renderer.render(batch)` for one view per GPU: structured-l
 262 144 rays, inputs (rays, vertices, weights) resident in HBM.  With N GPUs the job is N views
 (weak scaling): rank r marches view r, then the rendered RGB tiles are all-gathered over RCCL.
 
+Hygiene: the timed region cycles through N_POSES = 8 distinct camera poses whose ray tensors were
+generated on the device beforehand (no per-view cache can hit: each step sees other ray / mask tensors), `ms_per_step` is
+total / K as the contract says and `median_ms_per_step` is the median of per-step HIP-event times; `parity_linf` is the
+rgb L-inf of >= 4096 rays of the timed views against the oracle on the same feature volumes (rank 0, N = 1).
+`--scaling strong` shards ONE view's rays over the ranks (parallel.render_sharded) instead of one view per rank.
+
 The JSON line also carries
   roofline     — the dominant kernel (nb_march16_kernel, or nb_march_kernel with --precision f32): algorithmic MLP
                  flops (859 904 per ray-sample) / its average launch duration measured with HIP
@@ -73,6 +79,46 @@ def build_scene(dev, H=512, W=512, n_samples=64, precision=None):
     return sd, body, net, rend, bd, n
 
 
+N_POSES = 8
+
+
+def build_poses(dev, body, bd, H, W, n_poses=N_POSES):
+    """`n_poses` batches of the same frame seen from different full-coverage cameras (yaw steps around the body): rays
+    generated on the device by nb_raygen, everything resident in HBM before the timed region."""
+    from neuralbody_amd import ops
+    from neuralbody_amd import synthetic as syn
+
+    poses = []
+    for i in range(n_poses):
+        K, R, T = syn.full_coverage_camera(body, H, W, yaw=0.35 + 0.12 * i, pitch=0.1 - 0.03 * i)
+        ro, rd, near, far, mask, n = ops.raygen(H, W, K, R, T, body["can_bounds"], dev)
+        n = int(n)
+        assert n == H * W, "throughput cameras must see the bbox in every pixel (pose %d: %d of %d)" % (i, n, H * W)
+        b = {k: v for k, v in bd.items() if k not in ("ray_o", "ray_d", "near", "far", "mask_at_box")}
+        b.update(ray_o=ro[None, :n], ray_d=rd[None, :n], near=near[None, :n], far=far[None, :n], mask_at_box=mask[None].bool())
+        poses.append(b)
+    return poses
+
+
+def parity_linf(sd, net, rend, batch, n_samples, n_check=4096):
+    """rgb L-inf of `n_check` rays spread over the view (HIP render of the FULL view vs the oracle marching the picked
+    rays through the same feature volumes, train-mode BatchNorm like the timed region)."""
+    from oracle import neuralbody_oracle as orc
+
+    with torch.no_grad():
+        out = rend.render(batch)
+        vols = net.encode_sparse_voxels(rend.prepare_sp_input(batch))
+    n = batch["ray_o"].shape[1]
+    sel = torch.linspace(0, n - 1, n_check).long()
+    b = {k: v.detach().cpu() for k, v in batch.items()}
+    b.update(ray_o=b["ray_o"][:, sel], ray_d=b["ray_d"][:, sel], near=b["near"][:, sel], far=b["far"][:, sel])
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    with torch.no_grad():
+        ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=n_samples, training=True,
+                         feature_volume=[v.detach().float().cpu().contiguous() for v in vols])
+    return float((out["rgb_map"][0, sel.to(out["rgb_map"].device)].cpu() - ref["rgb_map"][0]).abs().max()), n_check
+
+
 def cpu_baseline(sd, bd, vols, n_samples, budget_s=12.0, max_rays=8192):
     """The oracle (CPU restatement of the reference, chunked by 2048 rays like if_clight_renderer.py:107)
     marching a bounded sample of the bench rays through the same feature volumes.  torch's CPU thread
@@ -96,7 +142,7 @@ def cpu_baseline(sd, bd, vols, n_samples, budget_s=12.0, max_rays=8192):
 
     ncpu = os.cpu_count() or 1
     probe = {}
-    for nt in sorted({ncpu, min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+    for nt in sorted({min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):  # more than 64 torch threads only thrash
         torch.set_num_threads(nt)
         run(sel[:128])  # warm-up (thread pool, allocator)
         probe[nt] = run(sel[:256])
@@ -151,11 +197,11 @@ def train_bench(args, dev):
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"metric": "train_step_ms", "value": dt * 1e3, "unit": "ms", "higher_is_better": False, "n_gpus": 1,
+    return ({"metric": "train_step_ms", "value": dt * 1e3, "unit": "ms", "higher_is_better": False, "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "rays_per_step": 1024, "samples_per_ray": args.samples,
                       "ray_samples_per_sec": 1024 * args.samples / dt, "final_loss": float(loss.detach()),
                       "config": {"workload": "synthetic training step: 1024 random rays, forward + backward (decoder via rocBLAS "
-                                             "GEMMs + HIP kernels, encoder HIP kernels) + clip_grad_value_(40) + Adam"}}))
+                                             "GEMMs + HIP kernels, encoder HIP kernels) + clip_grad_value_(40) + Adam"}})
 
 
 def turntable_bench(args, dev):
@@ -184,12 +230,28 @@ def turntable_bench(args, dev):
         rays += nvr.render_view(K, RT, body["can_bounds"], frame, bgr=True, scale=255.0)["n_rays"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(json.dumps({"metric": "turntable_views_per_sec", "value": args.steps / dt, "unit": "views/s", "higher_is_better": True,
+    return ({"metric": "turntable_views_per_sec", "value": args.steps / dt, "unit": "views/s", "higher_is_better": True,
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_view": dt / args.steps * 1e3,
                       "rays_per_sec": rays / dt, "ray_samples_per_sec": rays * args.samples / dt,
                       "mean_rays_per_view": rays / args.steps,
                       "config": {"workload": "synthetic spiral path, %dx%d, %d samples/ray: raygen + encoder + march + image "
-                                             "assembly per view, all on device%s" % (H, W, args.samples, "; frame encoded once" if args.reuse_volumes else "")}}))
+                                             "assembly per view, all on device%s" % (H, W, args.samples, "; frame encoded once" if args.reuse_volumes else "")}})
+
+
+def extras(args, dev):
+    """Informational legs carried by the default JSON line: a short spiral turntable (every view = raygen + encoder + march
+    + image assembly, new pose each view) and a short training-step run (config 4 shape)."""
+    import copy
+
+    a = copy.copy(args)
+    a.steps, a.warmup, a.reuse_volumes = 8, 2, False
+    tt = turntable_bench(a, dev)
+    a.steps, a.warmup = 6, 2
+    tr = train_bench(a, dev)
+    return {"turntable_ms_per_view": tt["ms_per_view"], "turntable_rays_per_sec": tt["rays_per_sec"],
+            "train_step_ms": tr["value"], "train_ray_samples_per_sec": tr["ray_samples_per_sec"],
+            "note": "8 spiral views (512x512x64, each view: nb_raygen + encoder + march + nb_image_assemble) / 6 training steps "
+                    "(1024 random rays x 64 jittered samples, forward + backward + clip + Adam)"}
 
 
 def main():
@@ -201,6 +263,10 @@ def main():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3", "bf16x3s", "f16f8"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: one view per GPU per step (views shard with no collective but the tile all-gather); "
+                         "strong: one view per step, its rays split over the GPUs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informational turntable / train-step legs of the JSON line")
     ap.add_argument("--reuse-volumes", action="store_true", help="turntable mode: encode the frame once for all views")
     ap.add_argument("--mode", default="render", choices=["render", "train", "turntable"])
     args = ap.parse_args()
@@ -216,7 +282,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run (also with one process: exercises RCCL)
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)  # RCCL over xGMI
@@ -227,42 +293,54 @@ def main():
     if args.mode == "train":
         if world != 1:
             raise SystemExit("--mode train is a single-GPU informational run")
-        train_bench(args, dev)
+        print(json.dumps(train_bench(args, dev)))
         return
     if args.mode == "turntable":
         if world != 1:
             raise SystemExit("--mode turntable is a single-GPU informational run (views shard with render_views_sharded)")
-        turntable_bench(args, dev)
+        print(json.dumps(turntable_bench(args, dev)))
         return
     H = W = args.size
     sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
     S = args.samples
+    poses = build_poses(dev, body, bd, H, W)
+    from neuralbody_amd.parallel import render_sharded
 
-    def step():
-        out = rend.render(bd)
-        if world > 1:
+    def step(i):
+        b = poses[(i + rank) % len(poses)]
+        if args.scaling == "strong":
+            return render_sharded(rend, b, dist.group.WORLD if dist is not None else None)["rgb_map"][0]
+        out = rend.render(b)
+        if dist is not None:
             return all_gather_tiles(out["rgb_map"][0], dist.group.WORLD)
         return out["rgb_map"][0]
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
+        for i in range(args.warmup):
+            step(i)
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         ops.MARCH_EVENTS = []
+        step_events = []
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step(args.warmup + i)
+            e1.record()
+            step_events.append((e0, e1))
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         events, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
     march_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
-    if world > 1:
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -270,21 +348,25 @@ def main():
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_march16_traffic.json")
-    if net.precision == "bf16x3" and (H, W, S) == (512, 512, 64) and os.path.exists(tpath):
+    tpath = os.path.join(ROOT, "profiles", "r02_march_f16_traffic.json" if net.precision == "f16f8" else "r01_march16_traffic.json")
+    if net.precision in ("bf16x3", "f16f8") and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]
-    total_rays = n_rays * world * args.steps
+    views_per_step = world if args.scaling == "weak" else 1
+    rays_per_launch = n_rays if args.scaling == "weak" else (n_rays + world - 1) // world
+    total_rays = n_rays * views_per_step * args.steps
     samples_per_s = total_rays * S / elapsed
     dtype, kernel_name, exec_flop, peak = PRECISION_INFO[net.precision]
-    achieved_tflops = FLOP_PER_SAMPLE * n_rays * S / (march_ms * 1e-3) / 1e12
+    achieved_tflops = FLOP_PER_SAMPLE * rays_per_launch * S / (march_ms * 1e-3) / 1e12
     result = {
         "metric": "ray_samples_per_sec", "value": samples_per_s, "unit": "ray-samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": dtype,
+        "data": "synthetic",
         "rays_per_sec": total_rays / elapsed,
         "config": {"workload": "synthetic 6890-vertex SMPL scene, %dx%d full-coverage view, %d samples/ray, "
-                               "Renderer.render = encoder + fused march, one view per GPU per step" % (H, W, S),
+                               "Renderer.render = encoder + fused march, %s; the timed region cycles through %d camera poses" % (
+                                   H, W, S, "one view per GPU per step" if args.scaling == "weak" else "one view per step, rays split over the GPUs", len(poses)),
                    "rays_per_view": n_rays, "out_sh": [int(s) for s in body["out_sh"]],
                    "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                   "bf16x3": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
@@ -297,23 +379,28 @@ def main():
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC, profiles/r01_march16_traffic.json)",
+                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC, %s)" % os.path.relpath(tpath, ROOT),
                      "avg_launch_ms": march_ms,
-                     "executed_tflops": exec_flop * n_rays * S / (march_ms * 1e-3) / 1e12,
-                     "executed_frac": exec_flop * n_rays * S / (march_ms * 1e-3) / 1e12 / peak,
+                     "executed_tflops": exec_flop * rays_per_launch * S / (march_ms * 1e-3) / 1e12,
+                     "executed_frac": exec_flop * rays_per_launch * S / (march_ms * 1e-3) / 1e12 / peak,
                      "note": "achieved = 859904 algorithmic flop/sample x %d samples/launch / avg launch time (HIP events); "
                              "the kernel issues %.0f MFMA flop/sample (merged feature_fc.latent_fc layer%s), so "
                              "executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~219 MB/launch "
                              "(<0.1%% of the launch time at 8 TB/s)"
-                             % (n_rays * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.precision != "f32" else "")},
+                             % (rays_per_launch * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.precision.startswith("bf16") else "")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        err, n_chk = parity_linf(sd, net, rend, poses[1], S)
+        result["parity_linf"] = err
+        result["parity_note"] = "rgb L-inf of %d rays of a timed view vs the CPU oracle (same feature volumes); budget 1e-4" % n_chk
         with torch.no_grad():
-            vols = net.encode_sparse_voxels(rend.prepare_sp_input(bd))
-        result["cpu_baseline"] = cpu_baseline(sd, bd, vols, S)
+            vols = net.encode_sparse_voxels(rend.prepare_sp_input(poses[0]))
+        result["cpu_baseline"] = cpu_baseline(sd, poses[0], vols, S)
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["extras"] = extras(args, dev)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

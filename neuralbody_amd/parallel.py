@@ -28,10 +28,10 @@ def all_gather_tiles(tile, group=None, sizes=None):
     """All-gather per-rank tiles [n_r, ...] into one [sum n_r, ...] tensor on every rank.  Equal-size
     tiles go through a single all_gather_into_tensor; ragged ones are padded to the largest tile
     (`sizes` = per-rank row counts, computed with shard_range on the host — no size exchange)."""
-    world = dist.get_world_size(group)
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return tile
-    tile = tile.contiguous()
+    world = dist.get_world_size(group)
+    tile = tile.contiguous()  # a group of one still goes through the collective: the single-GPU tests exercise RCCL
     if sizes is None or len(set(sizes)) == 1:
         out = torch.empty((world * tile.shape[0],) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
         dist.all_gather_into_tensor(out, tile, group=group)
@@ -52,7 +52,7 @@ def render_sharded(renderer, batch, group=None, keys=("rgb_map",)):
     n = batch["ray_o"].shape[1]
     b, e = shard_range(n, rank, world)
     part = renderer.render(batch, ray_range=(b, e))
-    if world == 1:
+    if not dist.is_initialized():
         return {k: part[k] for k in keys}
     sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
     return {k: all_gather_tiles(part[k][0], group, sizes)[None] for k in keys}

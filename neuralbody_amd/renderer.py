@@ -104,6 +104,10 @@ class Renderer:
             # training step (lib/train/trainers/if_nerf_clight.py:18-36): differentiable HIP path
             from . import training
 
+            if feature_volume is not None or want_raw or self.make_cull(batch) is not None:
+                raise NotImplementedError("the differentiable path renders all samples of the batch from its own encoder pass: "
+                                          "feature_volume / want_raw / sample culling are inference-only (wrap the call in "
+                                          "torch.no_grad(), as run.py:66,98 does)")
             if self.cfg.perturb > 0.0 and self.net.training and t_rand is None:
                 t_rand = torch.rand((n_batch, n_pixel, self.cfg.N_samples), device=ray_o.device)
             return training.render_train(self, batch, t_rand)

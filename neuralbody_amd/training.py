@@ -121,6 +121,11 @@ class RenderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, renderer, batch, t_rand, *params):
         net, cfg = renderer.net, renderer.cfg
+        if not net.training:
+            # nb_enc_bn_relu_bwd implements the batch-statistics BatchNorm backward only; in eval() the forward normalises
+            # with the running statistics, for which that formula is wrong
+            raise RuntimeError("the differentiable HIP path needs net.train() (BatchNorm with batch statistics, as the "
+                               "reference trains: lib/train/trainers/trainer.py:28); use torch.no_grad() for eval-mode renders")
         sp_input = renderer.prepare_sp_input(batch)
         enc_ctx = []
         with torch.no_grad():

@@ -71,3 +71,45 @@ def assert_close(a, b, tol, name="", rel=True):
 def same_bits(a, b):
     """Bit-exact equality that treats NaNs at the same positions as equal."""
     return a.shape == b.shape and bool(torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32)))
+
+
+def load_plugin(fname, cfg=None):
+    """Import neuralbody_amd/plugins/<fname> the way the reference's imp.load_source factories do, with a stand-in for
+    the reference's global `lib.config.cfg` (the GPU box has no reference tree)."""
+    import importlib.util
+    import sys
+    import types
+
+    cfgmod = types.ModuleType("lib.config")
+    cfgmod.cfg = cfg or types.SimpleNamespace(N_samples=64, perturb=1.0, raw_noise_std=0.0, white_bkgd=False, H=512, W=512, ratio=1.0)
+    saved = {k: sys.modules.get(k) for k in ("lib", "lib.config")}
+    sys.modules["lib"] = types.ModuleType("lib")
+    sys.modules["lib.config"] = cfgmod
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("nb_plugin_" + fname.replace(".py", ""),
+                                                      os.path.join(root, "neuralbody_amd", "plugins", fname))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    return mod
+
+
+def training_batch(seed=0, n_rand=1024, size=64, latent_index=2, dev="cuda:0"):
+    """(state_dict_np, device batch) of one synthetic training iteration: n_rand random rays of one frame + rgb targets."""
+    from neuralbody_amd import synthetic as syn
+
+    sd = syn.make_weights(seed, num_train_frame=5)
+    body = syn.make_body(seed=seed, box=(0.3, 0.5, 0.2))
+    K, R, T = syn.make_camera(body, size, size, focal_factor=2.5, distance=1.5)
+    ro, rd, near, far, mask = syn.host_image_rays(size, size, K, R, T, body["can_bounds"])
+    rs = np.random.RandomState(seed)
+    pick = rs.choice(ro.shape[0], n_rand, replace=False)  # N_rand random rays (latent_xyzc_313.yaml:66)
+    batch = syn.make_batch(body, ro[pick], rd[pick], near[pick], far[pick], np.ones(n_rand, bool), latent_index=latent_index)
+    batch["rgb"] = rs.uniform(0, 1, (1, n_rand, 3)).astype(np.float32)
+    return sd, device_batch(batch, dev)

@@ -1,0 +1,99 @@
+"""The multi-GPU code paths executed for real on the one GPU of the test box: a RCCL ("nccl") process
+group of world_size 1 runs parallel.render_sharded with the REAL Renderer, the tile all-gather, bench.py under
+torch.distributed.run, and DistributedDataParallel(NetworkWrapper(net)) for one training step whose gradients must equal
+the non-DDP step's (lib/train/trainers/trainer.py:13-18 wraps the same module the same way)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from tests import helpers as H
+from tests.golden import scenes
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    yield dist.group.WORLD
+    dist.destroy_process_group()
+
+
+def test_render_sharded_and_tile_gather_with_the_real_renderer(nccl_group):
+    from neuralbody_amd import parallel
+
+    r, sd, body, batch, cam, _ = scenes.build("small")
+    net = H.make_network(sd, DEV, True)
+    rend = H.make_renderer(net, r)
+    bd = H.device_batch(batch, DEV)
+    with torch.no_grad():
+        full = rend.render(bd)
+        got = parallel.render_sharded(rend, bd, nccl_group, keys=("rgb_map", "acc_map"))
+        # the ragged path of the gather (sizes differ) through RCCL as well
+        n = bd["ray_o"].shape[1]
+        tiles = parallel.all_gather_tiles(full["rgb_map"][0], nccl_group, sizes=[n])
+    torch.cuda.synchronize()
+    assert H.same_bits(got["rgb_map"], full["rgb_map"]) and H.same_bits(got["acc_map"], full["acc_map"])
+    assert H.same_bits(tiles, full["rgb_map"][0])
+    # a ray range renders bit-identically to the same rays of the full render (what every rank relies on)
+    with torch.no_grad():
+        part = rend.render(bd, ray_range=(100, 357))
+    assert H.same_bits(part["rgb_map"], full["rgb_map"][:, 100:357])
+
+
+def test_ddp_training_step_equals_the_plain_step(nccl_group):
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    mod = H.load_plugin("if_nerf_clight.py")
+    sd, bd = H.training_batch(seed=1, n_rand=256, size=48)
+    t_rand = torch.rand((1, 256, 64), generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def one_step(wrap):
+        net = H.make_network(sd, DEV, True, "f32")
+        wrapper = mod.NetworkWrapper(net)
+        wrapper.renderer.render = (lambda orig: (lambda batch, **kw: orig(batch, t_rand=t_rand, **kw)))(wrapper.renderer.render)
+        model = DDP(wrapper, device_ids=[0]) if wrap else wrapper
+        opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+        ret, loss, stats, _ = model(bd)
+        opt.zero_grad()
+        loss.mean().backward()
+        grads = {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+        torch.nn.utils.clip_grad_value_(net.parameters(), 40)
+        opt.step()
+        return float(loss.detach()), grads, {n: p.detach().clone() for n, p in net.named_parameters()}
+
+    l0, g0, p0 = one_step(False)
+    l1, g1, p1 = one_step(True)
+    torch.cuda.synchronize()
+    assert abs(l0 - l1) <= 1e-6 * max(1.0, abs(l0)), (l0, l1)
+    assert set(g0) == set(g1) and len(g0) == 69
+    for name in g0:
+        # fp32 atomics in the weight-gradient kernels make a run reproducible to a few ulp of the largest entry, not bitwise
+        scale = float(g0[name].abs().max()) + 1e-30
+        assert float((g0[name] - g1[name]).abs().max()) <= 2e-5 * scale, name
+        assert float((p0[name] - p1[name]).abs().max()) <= 1e-6 + 2e-3 * 5e-4, name  # one Adam step of lr 5e-4
+
+
+def test_bench_under_torch_distributed_run():
+    """bench.py launched the way the driver launches it for N > 1 (one process here): env:// RCCL init, barrier-bracketed
+    timed region, tile all-gather, max-over-ranks reduction; both scaling modes."""
+    for scaling in ("weak", "strong"):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+               "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+               "--no-cpu-baseline", "--no-extras", "--size", "128", "--scaling", scaling]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        assert j["n_gpus"] == 1 and j["scaling"] == scaling and j["value"] > 0 and j["roofline"]["avg_launch_ms"] > 0

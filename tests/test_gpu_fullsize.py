@@ -1,0 +1,51 @@
+"""Parity AT SIZE: the headline 512x512x64 view and the 1024x1024x128 shape of BASELINE.json configs 3/5,
+rendered in train() mode (BatchNorm with batch statistics, as run.py:57,89 and bench.py do), thousands of rays spread over
+the image against the oracle marching the same rays through the same feature volumes (the encoder at full out_sh is covered
+by test_gpu_parity.py's 'full' scene; re-running its dense stand-in at (96, 352, 192) would take minutes of CPU)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _check(size, n_samples, n_check, precision):
+    from oracle import neuralbody_oracle as orc
+
+    dev = torch.device(DEV)
+    sd, body, net, rend, bd, n = bench.build_scene(dev, size, size, n_samples, precision)
+    assert net.training
+    pose = bench.build_poses(dev, body, bd, size, size, n_poses=2)[1]
+    with torch.no_grad():
+        out = rend.render(pose)
+        vols = net.encode_sparse_voxels(rend.prepare_sp_input(pose))
+    torch.cuda.synchronize()
+    assert out["rgb_map"].shape == (1, size * size, 3)
+    sel = torch.linspace(0, n - 1, n_check).long()
+    b = {k: v.detach().cpu() for k, v in pose.items()}
+    b.update(ray_o=b["ray_o"][:, sel], ray_d=b["ray_d"][:, sel], near=b["near"][:, sel], far=b["far"][:, sel])
+    with torch.no_grad():
+        ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=n_samples, training=True,
+                         feature_volume=[v.detach().float().cpu().contiguous() for v in vols])
+    seld = sel.to(dev)
+    err = H.assert_close(out["rgb_map"][0, seld].cpu().numpy(), ref["rgb_map"][0].numpy(), H.RGB_TOL, "rgb_map", rel=False)
+    H.assert_close(out["acc_map"][0, seld].cpu().numpy(), ref["acc_map"][0].numpy(), 2e-4, "acc_map")
+    H.assert_close(out["weights"][0, seld].cpu().numpy(), ref["weights"][0].numpy(), 2e-4, "weights")
+    H.assert_close(out["depth_map"][0, seld].cpu().numpy(), ref["depth_map"][0].numpy(), 2e-4, "depth_map")
+    assert float(ref["rgb_map"].max() - ref["rgb_map"].min()) > 0.1, "degenerate view"
+    print("%dx%dx%d %s: rgb L-inf of %d rays vs oracle %.2e" % (size, size, n_samples, precision, n_check, err))
+    return err
+
+
+@pytest.mark.parametrize("precision", ["f16f8", "bf16x3"])
+def test_headline_view_512x512x64_train_mode(precision):
+    _check(512, 64, 4096, precision)
+
+
+@pytest.mark.parametrize("precision", ["f16f8", "bf16x3"])
+def test_config3_view_1024x1024x128(precision):
+    _check(1024, 128, 1024, precision)

@@ -118,6 +118,43 @@ def test_decode_matches_reference_raw_subset():
     H.assert_close(dens.cpu().numpy(), g["density_subset"], 3e-4, "density vs reference")
 
 
+def test_network_forward_and_positional_encoding_tap():
+    """Network.forward (latent_xyzc.py:128-163 signature; the reference's body is broken, ours must work) equals
+    calculate_density_color on the same points, and the positional-encoding tap (TAP['PE'], the 90 view_fc inputs after the 256
+    feature columns) equals the reference embedder (embedder.py:10-36) applied to viewdir / world point."""
+    from neuralbody_amd import ops
+    from oracle import neuralbody_oracle as orc
+
+    r, sd, sdt, batch, bd, vols, vols_dev, sp, net, _ = _scene_with_oracle_volumes("small", "f32")
+    rend = H.make_renderer(net, r)
+    sel = slice(0, None, 11)
+    wpts, _z = rend.get_sampling_points(bd["ray_o"][:, sel], bd["ray_d"][:, sel], bd["near"][:, sel], bd["far"][:, sel])
+    vd = bd["ray_d"][:, sel] / torch.norm(bd["ray_d"][:, sel], dim=2, keepdim=True)
+    w = wpts.reshape(1, -1, 3)
+    v = vd[:, :, None].repeat(1, 1, r["n_samples"], 1).reshape(1, -1, 3)
+    # forward() takes the ENCODED inputs (their first three entries are the raw direction / point) and encodes the frame itself
+    sp_full = rend.prepare_sp_input(bd)
+    raw_fwd = net.forward(sp_full, None, orc.embed(v.cpu(), 4).to(DEV), orc.embed(w.cpu(), 10).to(DEV))
+    raw_ref = net.calculate_density_color(w, v, net.encode_sparse_voxels(sp_full), sp_full)
+    assert raw_fwd.shape == (1, w.shape[1], 4)
+    assert torch.equal(raw_fwd, raw_ref)
+    with torch.no_grad():
+        raw_orc = orc.calculate_density_color(sdt, w.cpu(), v.cpu(), orc.encode_sparse_voxels(
+            sdt, torch.from_numpy(batch["coord"]), sp["out_sh"], training=True),
+            {"R": torch.from_numpy(batch["R"]), "Th": torch.from_numpy(batch["Th"]), "bounds": torch.from_numpy(batch["bounds"]),
+             "latent_index": torch.from_numpy(batch["latent_index"]), "out_sh": sp["out_sh"]})
+    H.assert_close(raw_fwd.cpu().numpy(), raw_orc.numpy(), 3e-4, "Network.forward vs oracle")
+    # the PE tap
+    scene = net.make_scene(vols_dev, sp)
+    lb = net.latent_bias(bd["latent_index"])
+    _out, dbg = ops.decode_points(scene, net.packed_weights(), lb, w[0].contiguous(), v[0].contiguous(), debug=True, precision="f32")
+    a, b = ops.TAP["PE"]
+    pe = dbg[:, a:b].cpu().numpy()
+    ref = torch.cat([orc.embed(v[0].cpu(), 4), orc.embed(w[0].cpu(), 10)], -1).numpy()  # view_fc input order (latent_xyzc.py:118)
+    assert pe.shape == ref.shape == (w.shape[1], 90)
+    H.assert_close(pe, ref, 1e-6, "positional-encoding tap", rel=False)
+
+
 # ------------------------------------------------------------------------------------------- march
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ALL)

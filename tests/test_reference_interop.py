@@ -75,3 +75,36 @@ def test_plugins_resolve_through_reference_factories():
         assert callable(getattr(net, name))
     for name in ("get_sampling_points", "prepare_sp_input", "get_density_color", "get_pixel_value", "render"):
         assert callable(getattr(ren, name))
+
+
+def test_trainer_plugin_resolves_through_reference_wrapper_factory():
+    """lib/train/trainers/make_trainer.py:5-9: `_wrapper_factory(cfg, network)` imp.load_source's cfg.trainer_path and builds
+    NetworkWrapper(network).  (make_trainer itself goes on to Trainer(...), which moves the module to cuda:0 — not on this box.)"""
+    ns = rh.load()
+    cfg = ns.cfg
+    import importlib
+    import sys
+
+    importlib.import_module("lib.train.trainers.make_trainer")
+    mt = sys.modules["lib.train.trainers.make_trainer"]  # the package re-exports a function under the module's name
+
+    saved = (cfg.network_module, cfg.network_path, cfg.renderer_module, cfg.renderer_path, cfg.trainer_module, cfg.trainer_path)
+    cwd = os.getcwd()
+    os.chdir(ns.root)
+    try:
+        cfg.network_module, cfg.network_path = "lib.networks.latent_xyzc_hip", os.path.join(PLUGINS, "latent_xyzc.py")
+        cfg.trainer_module, cfg.trainer_path = "lib.train.trainers.if_nerf_clight_hip", os.path.join(PLUGINS, "if_nerf_clight.py")
+        net = ns.make_network(cfg)
+        wrapper = mt._wrapper_factory(cfg, net)
+    finally:
+        (cfg.network_module, cfg.network_path, cfg.renderer_module, cfg.renderer_path, cfg.trainer_module, cfg.trainer_path) = saved
+        os.chdir(cwd)
+    from neuralbody_amd.network import Network
+    from neuralbody_amd.renderer import Renderer
+
+    assert type(wrapper).__name__ == "NetworkWrapper" and isinstance(wrapper, torch.nn.Module)
+    assert isinstance(wrapper.net, Network) and wrapper.net is net and isinstance(wrapper.renderer, Renderer)
+    assert wrapper.renderer.cfg.N_samples == cfg.N_samples
+    # the Trainer drives exactly this surface (trainer.py:46-52): parameters() for clip/Adam, forward(batch) -> 4-tuple
+    assert len(list(wrapper.parameters())) == 69
+    assert set(dict(wrapper.named_parameters())) == {"net." + k for k, _ in net.named_parameters()}
