@@ -142,6 +142,8 @@ class RenderFunction(torch.autograd.Function):
             z = z_vals.reshape(-1, S).float().contiguous()
             rd = ray_d.reshape(-1, 3).float().contiguous()
             rgb, disp, acc, weights, depth = ops.composite(raw.view(-1, S, 4), z, rd, cfg.white_bkgd)
+        if DEBUG_CAPTURE is not None:
+            DEBUG_CAPTURE.update(tap=tap, enc_ctx=enc_ctx)
         ctx.renderer, ctx.sp_input, ctx.enc_ctx, ctx.scene = renderer, sp_input, enc_ctx, scene
         ctx.saved = (raw, tap, z, rd, w)
         ctx.n_params = len(params)
@@ -178,6 +180,9 @@ class RenderFunction(torch.autograd.Function):
         return (None, None, None) + tuple(out)
 
 
+# tests/test_gpu_backward.py sets this to a dict to receive the forward's activations (MLP tap, encoder records) so that
+# its float64 reference can differentiate through the SAME ReLU masks
+DEBUG_CAPTURE = None
 MAX_TAP_BYTES = 32 * 2 ** 30  # activation tap kept for the backward pass (ops.DBG_WIDTH floats per sample)
 
 

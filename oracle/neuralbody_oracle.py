@@ -97,12 +97,16 @@ def get_sampling_points(ray_o, ray_d, near, far, n_samples, t_rand=None):
 
 
 # ----------------------------------------------------------------------------- a5-a6
-def encode_sparse_voxels(sd, coord, out_sh, training=True, update_stats=None):
+def encode_sparse_voxels(sd, coord, out_sh, training=True, update_stats=None, relu_masks=None):
     """lib/networks/latent_xyzc.py:30-39 + SparseConvNet.forward :184-205 via the dense
     stand-in semantics (oracle/spconv_standin.py).  ``coord`` [B,N,3] int (d,h,w);
     returns the 4 NCDHW volumes.  BatchNorm1d(eps=1e-3, momentum=0.01) over ACTIVE rows
     (:215); in training mode batch statistics are used (run.py:57,89 renders in train()).
-    ``update_stats``: optional dict receiving the updated running stats."""
+    ``update_stats``: optional dict receiving the updated running stats.
+    ``relu_masks`` (gradient tests only): one bool [n_active_rows, C] per conv+BN+ReLU layer, rows in linear-voxel
+    order; the ReLU then keeps exactly those entries (`x * mask`), so that a float64 reference differentiates the SAME
+    piecewise-linear function as an fp32 implementation whose near-zero activations round to the other side."""
+    layer_no = 0
     dtype = sd["c.weight"].dtype
     B, N = coord.shape[0], coord.shape[1]
     # Renderer.prepare_sp_input (if_clight_renderer.py:33-41): prepend the batch index
@@ -135,7 +139,8 @@ def encode_sparse_voxels(sd, coord, out_sh, training=True, update_stats=None):
             else:
                 mean, var = sd[bnk + ".running_mean"], sd[bnk + ".running_var"]
             rows = (rows - mean) / torch.sqrt(var + 1e-3) * sd[bnk + ".weight"] + sd[bnk + ".bias"]
-            rows = torch.relu(rows)
+            rows = torch.relu(rows) if relu_masks is None else rows * relu_masks[layer_no].to(rows)
+            layer_no += 1
             g = torch.zeros(grid.shape[0], *grid.shape[2:], rows.shape[1], dtype=dtype)
             g[m] = rows
             grid = g.permute(0, 4, 1, 2, 3).contiguous()
@@ -196,14 +201,19 @@ def calculate_density(sd, wpts, feature_volume, sp, voxel_size=(0.005, 0.005, 0.
 
 
 def calculate_density_color(sd, wpts, viewdir, feature_volume, sp, voxel_size=(0.005, 0.005, 0.005),
-                            xyz_res=10, view_res=4):
-    """lib/networks/latent_xyzc.py:91-126 -> raw [B,N,4] = (rgb logits, sigma)."""
+                            xyz_res=10, view_res=4, relu_masks=None):
+    """lib/networks/latent_xyzc.py:91-126 -> raw [B,N,4] = (rgb logits, sigma).
+    ``relu_masks`` (gradient tests only): dict h1 / h2 / h3 [N,256], V [N,128] of bools replacing the four ReLUs by
+    `x * mask` (see encode_sparse_voxels)."""
+    def act(x, key):
+        return torch.relu(x) if relu_masks is None else x * relu_masks[key].T[None].to(x)
+
     ppts = pts_to_can_pts(wpts, sp["R"], sp["Th"])
     g = get_grid_coords(ppts, sp["bounds"], sp["out_sh"], voxel_size)[:, None, None]
     f = interpolate_features(g, feature_volume)
-    net = torch.relu(_conv1d(sd, "fc_0", f))
-    net = torch.relu(_conv1d(sd, "fc_1", net))
-    net = torch.relu(_conv1d(sd, "fc_2", net))
+    net = act(_conv1d(sd, "fc_0", f), "h1")
+    net = act(_conv1d(sd, "fc_1", net), "h2")
+    net = act(_conv1d(sd, "fc_2", net), "h3")
     alpha = _conv1d(sd, "alpha_fc", net)
     features = _conv1d(sd, "feature_fc", net)
     latent = sd["latent.weight"][sp["latent_index"]]
@@ -212,7 +222,7 @@ def calculate_density_color(sd, wpts, viewdir, feature_volume, sp, voxel_size=(0
     vd = embed(viewdir, view_res).transpose(1, 2)
     lp = embed(wpts, xyz_res).transpose(1, 2)
     features = torch.cat((features, vd, lp), dim=1)
-    net = torch.relu(_conv1d(sd, "view_fc", features))
+    net = act(_conv1d(sd, "view_fc", features), "V")
     rgb = _conv1d(sd, "rgb_fc", net)
     return torch.cat((rgb, alpha), dim=1).transpose(1, 2)
 
@@ -238,15 +248,17 @@ def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
 
 # ----------------------------------------------------------------------------- a12, a14
 def render(sd, batch, n_samples=64, voxel_size=(0.005, 0.005, 0.005), training=True, t_rand=None,
-           white_bkgd=False, chunk=2048, feature_volume=None):
-    """lib/networks/renderer/if_clight_renderer.py:62-122 (chunked by 2048 rays)."""
+           white_bkgd=False, chunk=2048, feature_volume=None, relu_masks=None):
+    """lib/networks/renderer/if_clight_renderer.py:62-122 (chunked by 2048 rays).
+    ``relu_masks`` (gradient tests only): {"encoder": [...], "mlp": {...}} as in encode_sparse_voxels / calculate_density_color."""
     dtype = sd["c.weight"].dtype
     b = {k: _t(v, dtype) if isinstance(v, (np.ndarray, torch.Tensor)) else v for k, v in batch.items()}
     out_sh = torch.max(b["out_sh"], dim=0)[0].tolist()
     sp = {"bounds": b["bounds"], "R": b["R"], "Th": b["Th"], "latent_index": b["latent_index"].long(),
           "out_sh": out_sh}
     if feature_volume is None:
-        feature_volume = encode_sparse_voxels(sd, b["coord"], out_sh, training=training)
+        feature_volume = encode_sparse_voxels(sd, b["coord"], out_sh, training=training,
+                                              relu_masks=None if relu_masks is None else relu_masks["encoder"])
     ray_o, ray_d, near, far = b["ray_o"], b["ray_d"], b["near"], b["far"]
     n_batch, n_pixel = ray_o.shape[:2]
     rets = []
@@ -258,7 +270,8 @@ def render(sd, batch, n_samples=64, voxel_size=(0.005, 0.005, 0.005), training=T
         nb, npx, ns = wpts.shape[:3]
         w = wpts.view(nb, npx * ns, -1)
         v = viewdir[:, :, None].repeat(1, 1, ns, 1).contiguous().view(nb, npx * ns, -1)
-        raw = calculate_density_color(sd, w, v, feature_volume, sp, voxel_size)
+        mm = None if relu_masks is None else {k: m[i * ns:(i + npx) * ns] for k, m in relu_masks["mlp"].items()}
+        raw = calculate_density_color(sd, w, v, feature_volume, sp, voxel_size, relu_masks=mm)
         rgb, disp, acc, wts, depth = raw2outputs(raw.reshape(-1, ns, 4), z_vals.view(-1, ns), rd.reshape(-1, 3),
                                                  white_bkgd)
         rets.append({"rgb_map": rgb.view(nb, npx, -1), "disp_map": disp.view(nb, npx), "acc_map": acc.view(nb, npx),

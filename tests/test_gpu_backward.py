@@ -10,6 +10,9 @@ from tests.golden import scenes
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# gradient agreement with a MASK-CONSISTENT float64 reference (same ReLU pattern on both sides), relative to each tensor's
+# largest entry: what remains is fp32 rounding through 17 batch-statistics BatchNorm layers
+ENC_TOL = 1e-4  # measured 8e-6 (encoder alone) / 1.2e-5 (whole training step, all 69 tensors)
 
 
 def _rel(a, b, tol, name):
@@ -20,6 +23,23 @@ def _rel(a, b, tol, name):
     err = np.abs(a - b).max() / scale
     assert err <= tol, "%s: max |diff| / max |ref| = %.3e > %.1e (ref max %.3e)" % (name, err, tol, scale)
     return err
+
+
+def _encoder_masks(ctx):
+    """ReLU masks of the HIP encoder forward (records of SparseConvNet.forward(save=...)) in the oracle's row order
+    (linear voxel order of the layer's active set)."""
+    masks = []
+    for rec in ctx[1:]:
+        n = int(rec["n_out"])
+        order = torch.argsort(rec["out_lin"][:n].long())
+        masks.append((rec["y"][:n][order] > 0).cpu())
+    return masks
+
+
+def _mlp_masks(tap):
+    from neuralbody_amd.ops import TAP
+
+    return {k: (tap[:, TAP[k][0]:TAP[k][1]] > 0).cpu() for k in ("h1", "h2", "h3", "V")}
 
 
 def test_composite_bwd_matches_autograd():
@@ -160,21 +180,22 @@ def test_encoder_backward_matches_autograd():
     from oracle import neuralbody_oracle as orc
 
     r, sd, body, batch, cam, _ = scenes.build("small")
-    sdg = {}
-    for k, v in orc.tensor_state_dict(sd).items():
-        sdg[k] = v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else v
-    out_sh = batch["out_sh"].max(0).tolist()
-    vols_ref = orc.encode_sparse_voxels(sdg, torch.from_numpy(batch["coord"]), out_sh, training=True)
-    rs = np.random.RandomState(21)
-    cots = [torch.from_numpy(rs.standard_normal(tuple(v.shape)).astype(np.float32)) for v in vols_ref]
-    sum((v * c.double()).sum() for v, c in zip(vols_ref, cots)).backward()
-
     net = H.make_network(sd, DEV, True, "f32")
     bd = H.device_batch(batch, DEV)
     sp = Renderer(net).prepare_sp_input(bd)
     ctx = []
     with torch.no_grad():
         vols = net.encode_sparse_voxels(sp, save=ctx)
+    # the float64 reference differentiates through the SAME ReLU masks as the fp32 kernels took (activations within
+    # rounding of zero otherwise fall on different sides and bound the agreement at ~1e-2)
+    sdg = {}
+    for k, v in orc.tensor_state_dict(sd).items():
+        sdg[k] = v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else v
+    out_sh = batch["out_sh"].max(0).tolist()
+    vols_ref = orc.encode_sparse_voxels(sdg, torch.from_numpy(batch["coord"]), out_sh, training=True, relu_masks=_encoder_masks(ctx))
+    rs = np.random.RandomState(21)
+    cots = [torch.from_numpy(rs.standard_normal(tuple(v.shape)).astype(np.float32)) for v in vols_ref]
+    sum((v * c.double()).sum() for v, c in zip(vols_ref, cots)).backward()
     dense = [rec for rec in ctx[1:] if rec["level"] is not None]
     drows = []
     for rec, c in zip(dense, cots):
@@ -189,11 +210,8 @@ def test_encoder_backward_matches_autograd():
     worst = 0.0
     for name, gr in g.items():
         ref = sdg[name].grad.numpy()
-        # ReLU masks are taken from each side's own forward pass: the handful of activations with y ~ 0 that flip
-        # between the fp32 kernels and the float64 reference bound the agreement (~1e-2 of the largest entry with
-        # O(1) random cotangents); a wrong formula shows up as O(1)
-        worst = max(worst, _rel(gr.cpu().numpy().reshape(ref.shape), ref, 2e-2, "grad " + name))
-    worst = max(worst, _rel(dcodes.cpu().numpy(), sdg["c.weight"].grad.numpy(), 2e-2, "grad c.weight"))
+        worst = max(worst, _rel(gr.cpu().numpy().reshape(ref.shape), ref, ENC_TOL, "grad " + name))
+    worst = max(worst, _rel(dcodes.cpu().numpy(), sdg["c.weight"].grad.numpy(), ENC_TOL, "grad c.weight"))
     assert len(g) == 17 * 3
     print("encoder backward: worst max|diff|/max|ref| = %.2e over 52 tensors" % worst)
 
@@ -211,20 +229,28 @@ def test_full_training_step_gradients_match_autograd():
         b_np[k] = batch[k][:, :n_use]
     g_rgb = torch.from_numpy(np.random.RandomState(9).standard_normal((1, n_use, 3)).astype(np.float32))
 
-    # ---- reference: float64 autograd through the oracle (same fp32 inputs)
+    # ---- HIP (first: its ReLU masks are handed to the reference)
+    from neuralbody_amd import training
+
+    net = H.make_network(sd, DEV, True, "f32")
+    rend = H.make_renderer(net, dict(r, white_bkgd=True))
+    bd = H.device_batch(b_np, DEV)
+    training.DEBUG_CAPTURE = {}
+    try:
+        out = rend.render(bd)
+        cap = training.DEBUG_CAPTURE
+    finally:
+        training.DEBUG_CAPTURE = None
+    assert out["rgb_map"].requires_grad
+    masks = {"encoder": _encoder_masks(cap["enc_ctx"]), "mlp": _mlp_masks(cap["tap"])}
+
+    # ---- reference: float64 autograd through the oracle (same fp32 inputs, same ReLU masks)
     sdg = {}
     for k, v in orc.tensor_state_dict(sd).items():
         sdg[k] = v.double().requires_grad_(True) if v.is_floating_point() and "running" not in k else v
     out_ref = orc.render(sdg, {k: (torch.from_numpy(v).double() if v.dtype == np.float32 else v) for k, v in b_np.items()},
-                         n_samples=64, training=True, white_bkgd=True)
+                         n_samples=64, training=True, white_bkgd=True, relu_masks=masks)
     (out_ref["rgb_map"] * g_rgb.double()).sum().backward()
-
-    # ---- HIP
-    net = H.make_network(sd, DEV, True, "f32")
-    rend = H.make_renderer(net, dict(r, white_bkgd=True))
-    bd = H.device_batch(b_np, DEV)
-    out = rend.render(bd)
-    assert out["rgb_map"].requires_grad
     _rel(out["rgb_map"].detach().cpu().numpy(), out_ref["rgb_map"].detach().numpy(), 1e-4, "forward rgb")
     (out["rgb_map"] * g_rgb.to(DEV)).sum().backward()
     torch.cuda.synchronize()
@@ -241,7 +267,7 @@ def test_full_training_step_gradients_match_autograd():
         # End to end the comparison is only as good as the forward agreement: the fixture's x12 density gain turns the
         # fp32 encoder's ~1e-4 feature noise into flipped ReLUs / shifted alphas for a few samples, so this test checks
         # the plumbing of the whole chain at 2e-2; the component tests carry the tight bounds.
-        tol = 2e-2
+        tol = ENC_TOL
         e = _rel(p.grad.cpu().numpy(), ref.numpy().reshape(p.shape), tol, "grad " + name)
         worst[group] = max(worst.get(group, 0.0), e)
     print("worst relative gradient error per group:", {k: "%.1e" % v for k, v in worst.items()})
@@ -305,10 +331,15 @@ def test_network_wrapper_training_steps_reduce_loss():
     assert int(net.xyzc_net.conv0[1].num_batches_tracked) == 6
 
 
+# the fixture's gradients come from the unmodified reference in fp32 on the CPU, whose ReLU masks are its own: a handful of
+# activations within rounding of zero fall on the other side here (the mask-consistent float64 tests above agree to 1e-5)
+FIXTURE_TOL = 2e-3
+
+
 def test_training_step_matches_reference_fixture():
     """One training step (forward with the fixture's jitter, MSE loss, backward) against the gradients of the UNMODIFIED
-    reference (tests/golden/train_step.npz): loss to 1e-5, per-parameter gradient norms and probe entries to 2e-2 of
-    the tensor's largest gradient entry (fp32 ReLU-mask flips, see the tests above)."""
+    reference (tests/golden/train_step.npz): loss to 1e-5, per-parameter gradient norms and probe entries to FIXTURE_TOL
+    of the tensor's largest gradient entry."""
     g = np.load(H.GOLDEN + "/train_step.npz")
     r, sd, batch, t_rand = scenes.build_train()
     net = H.make_network(sd, DEV, True, "f32")
@@ -329,5 +360,5 @@ def test_training_step_matches_reference_fixture():
         idx = scenes.grad_probe_indices(gr.shape)
         e2 = np.abs(gr.reshape(-1)[idx] - g["probe/" + name]).max() / scale
         worst = max(worst, e1, e2)
-        assert e1 <= 2e-2 and e2 <= 2e-2, (name, e1, e2)
+        assert e1 <= FIXTURE_TOL and e2 <= FIXTURE_TOL, (name, e1, e2)
     print("training step vs reference fixture: worst relative deviation %.2e over %d tensors" % (worst, len(list(net.parameters()))))
