@@ -8,7 +8,7 @@
  *     Nothing throws across the ABI, nothing calls exit().
  *   - all pointers marked "dev" are DEVICE pointers owned by the caller (PyTorch-ROCm
  *     tensors: tensor.data_ptr()).  The library never allocates or frees user-visible
- *     memory and keeps no hidden state between calls.
+ *     memory, links no vendor BLAS and keeps no hidden state between calls.
  *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *     work is enqueued asynchronously, no entry point synchronises the device.
  *   - floats are fp32, indices int32 unless stated.
@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 10
+#define NB_ABI_VERSION 11
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -100,6 +100,14 @@ typedef struct nb_mlp_params { /* all dev, row-major [out,in] / [out] */
 /* replaces: module parameter access in Network.calculate_density_color
  * (lib/networks/latent_xyzc.py:99-121).  `packed` dev, nb_mlp_pack_size() floats. */
 int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream);
+/* The same, writing only the sections a caller is going to use (a training step changes the weights every iteration and
+ * decodes with NB_PREC_F32 only).  The fp32 section (NB_PACK_F32) is always written. */
+#define NB_PACK_F32 1
+#define NB_PACK_BF16X3 2
+#define NB_PACK_BF16X3S 4
+#define NB_PACK_F16F8 8
+#define NB_PACK_ALL 15
+int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, void *stream);
 /* latent_row: dev pointer to latent.weight[latent_index] (128 floats);
  * out: dev, nb_mlp_latent_bias_size() floats. */
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream);
@@ -178,11 +186,18 @@ int nb_composite_bwd(const float *raw, const float *z_vals, const float *ray_d, 
                      int32_t n_samples, int white_bkgd, const float *d_rgb_map, const float *d_acc_map,
                      const float *d_depth_map, float *d_raw, void *stream);
 
-/* Row-major fp32 GEMM C[m,n] = alpha * op(A) op(B) + beta * C on rocBLAS (the MLP backward's plain
- * library GEMMs: backward of the Conv1d(k=1) layers, latent_xyzc.py:99-121).  lda/ldb/ldc are row
- * strides.  The library keeps one lazily created rocBLAS handle. */
+/* Row-major fp32 GEMM C[m,n] = alpha * op(A) op(B) + beta * C on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
+ * fp32): the backward of the Conv1d(k=1) layers (latent_xyzc.py:99-121).  lda/ldb/ldc are row strides.  op(A) = A^T
+ * (trans_a) is the weight-gradient form dW = dY^T X (split over the long row dimension, fp32 atomics, op(B) = B only). */
 int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
              const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream);
+/* The same with the epilogues of the backward chain fused (trans_a = 0 only):
+ *   mask_y (dev [m, >= n], row stride ldy, or NULL): C[r,c] = 0 where mask_y[r,c] <= 0 — the ReLU that followed the
+ *            layer whose input gradient C is (mask_y = that layer's post-activation output);
+ *   colsum (dev [n] or NULL): colsum[c] += sum_r C[r,c] after the mask — the bias gradient of that layer. */
+int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
+                  const float *b, int32_t ldb, float beta, float *c, int32_t ldc, const float *mask_y, int32_t ldy,
+                  float *colsum, void *stream);
 
 /* dy[i] = y[i] > 0 ? dy[i] : 0 (ReLU backward on the post-activation value), in place. */
 int nb_relu_bwd(float *dy, const float *y, int64_t n, void *stream);

@@ -9,8 +9,9 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2, "f16f8": 3}
+PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "bf16x3s": 4, "f16f8": 8}
 
 
 class NbScene(C.Structure):
@@ -53,6 +54,7 @@ SIGNATURES = {
     "nb_mlp_pack_size": (_I64, []),
     "nb_mlp_latent_bias_size": (_I64, []),
     "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
+    "nb_mlp_pack_sections": (C.c_int, [C.POINTER(NbMlpParams), _P, C.c_int, _P]),
     "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),
     "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
     "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.POINTER(NbCull), C.c_int,
@@ -60,6 +62,7 @@ SIGNATURES = {
     "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
     "nb_composite_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P]),
     "nb_sgemm": (C.c_int, [C.c_int, C.c_int, _I32, _I32, _I32, C.c_float, _P, _I32, _P, _I32, C.c_float, _P, _I32, _P]),
+    "nb_gemm_fused": (C.c_int, [C.c_int, C.c_int, _I32, _I32, _I32, C.c_float, _P, _I32, _P, _I32, C.c_float, _P, _I32, _P, _I32, _P, _P]),
     "nb_relu_bwd": (C.c_int, [_P, _P, _I64, _P]),
     "nb_colsum": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
     "nb_trilinear_bwd": (C.c_int, [C.POINTER(NbScene), C.c_void_p * 4, C.c_void_p * 4, _P, _P, _I64, _P]),

@@ -66,7 +66,7 @@ def build(force=False, verbose=True):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB_PATH] + objs + ["-lrocblas"]
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB_PATH] + objs  # no vendor BLAS: every GEMM is ours
     if verbose:
         print("[nb build]", " ".join(cmd))
     subprocess.check_call(cmd)

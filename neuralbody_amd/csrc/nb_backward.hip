@@ -3,13 +3,12 @@
 // PyTorch autograd through raw2outputs, the Conv1d stack, F.grid_sample and spconv).
 //
 //   nb_composite_bwd   d(rgb_map, acc_map, depth_map) -> d raw            (raw2outputs, nerf_net_utils.py:19-49)
-//   nb_sgemm           plain row-major fp32 GEMMs of the MLP backward on rocBLAS (library GEMMs: dX = dY.W,
-//                      dW = dY^T.X over the N = rays x samples rows)
-//   nb_relu_bwd / nb_colsum   elementwise mask and bias-gradient reductions
+//   nb_sgemm / nb_gemm_fused   row-major fp32 GEMMs of the MLP backward on v_mfma_f32_32x32x2_f32 (exact fp32):
+//                      dX = dY.W with the ReLU mask and the bias-gradient column sums in the epilogue (gemm_rows_kernel),
+//                      dW = dY^T.X over the N = rays x samples rows with a split-K kernel (gemm_tn_kernel)
+//   nb_relu_bwd / nb_colsum   elementwise mask and bias-gradient reductions (stand-alone forms)
 //   nb_trilinear_bwd   dF [N,352] -> gradients of the ACTIVE voxel rows of the four feature volumes
 //                      (grid_sample backward restricted to active voxels: inactive sites are constants)
-#include <rocblas/rocblas.h>
-
 #include "nb_march_common.h"
 
 using namespace nbm;
@@ -178,7 +177,182 @@ __global__ void scale_matrix_kernel(float *__restrict__ C, int m, int n, int ldc
     *p = beta == 0.f ? 0.f : *p * beta;
 }
 
-rocblas_handle g_handle = nullptr;
+// ------------------------------------------------------------------ C[R,N] = alpha A[R,K] op(B) + beta C, R large, K and N small
+// (dX = dY.W of the MLP backward: R = rays x samples rows, K, N <= 384).  One wave = 32 rows x up to 4 column tiles of 32;
+// v_mfma_f32_32x32x2_f32 (exact fp32): A operand = one float per lane (row lane % 32, k = 2 c + lane / 32), B operand = the
+// weight element (k, column), C/D in the standard 32x32 layout.  Fused epilogues of the backward chain:
+//   mask_y   : C *= (Y[row, col] > 0)   — the ReLU that followed the layer whose input gradient this is
+//   colsum   : colsum[col] += sum_rows C (after the mask) — the bias gradient of that layer
+__global__ __launch_bounds__(256) void gemm_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                        int trans_b, long long R, int K, int N, float alpha, float beta,
+                                                        float *__restrict__ C, int ldc, const float *__restrict__ mask_y, int ldy,
+                                                        float *__restrict__ colsum) {
+    // column sums: one fp32 atomic per column per WORKGROUP (LDS reduction over the four waves first) — one per wave made
+    // 4096 atomics per address per product and dominated the kernel
+    __shared__ float cs_lds[128];
+    if (threadIdx.x < 128) cs_lds[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 31, kk = lane >> 5;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 32;
+    const int col0 = blockIdx.y * 128;
+    const long long arow = row0 + i;
+    const bool rok = arow < R;
+    const float *ap = A + (rok ? arow : 0) * lda;
+    f32x16_ acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int nt = row0 < R ? min(4, (N - col0 + 31) / 32) : 0;  // wave-uniform
+    for (int k = 0; k < K && nt > 0; k += 2) {
+        const int ke = k + kk;
+        const bool kok = ke < K;
+        const float a = (rok && kok) ? ap[ke] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < nt) {
+                const int col = col0 + 32 * t + i;
+                float b = 0.f;
+                if (kok && col < N) b = trans_b ? B[(size_t)col * ldb + ke] : B[(size_t)ke * ldb + col];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        if (t >= nt) continue;
+        const int col = col0 + 32 * t + i;
+        if (col >= N) continue;
+        float cs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + tn_tile_row(r, kk);
+            if (row >= R) continue;
+            float v = alpha * acc[t][r];
+            float *cp = C + row * ldc + col;
+            if (beta != 0.f) v += beta * *cp;
+            if (mask_y && !(mask_y[row * ldy + col] > 0.f)) v = 0.f;
+            *cp = v;
+            cs += v;
+        }
+        if (colsum) atomicAdd(&cs_lds[32 * t + i], cs);
+    }
+    if (colsum) {
+        __syncthreads();
+        if (threadIdx.x < 128 && col0 + (int)threadIdx.x < N) atomicAdd(&colsum[col0 + threadIdx.x], cs_lds[threadIdx.x]);
+    }
+}
+
+// fast path of gemm_rows_kernel (K a multiple of 16, 16-byte aligned operands): a 128-row x 128-column block per workgroup.
+// The weight panel B[k0 .. k0+15][128 columns] is shared by the four waves through LDS (double buffered, one barrier per
+// 16-wide K chunk); every lane reads ITS row's 16 K values of A as one 64-byte cache line straight into registers.  (The
+// first version loaded 8 K per step per wave with no sharing: 128 half-used cache-line requests per 16 MFMAs per wave — 5x
+// over what the vector L1 can serve; measured 320 us for the 65536 x 256 x 256 product against a 62 us matrix-pipe bound.)
+template <bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm_rows_fast_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                             long long R, int K, int N, float alpha, float beta, float *__restrict__ C,
+                                                             int ldc, const float *__restrict__ mask_y, int ldy,
+                                                             float *__restrict__ colsum) {
+    constexpr int KC = 16, LDB = 132;  // LDS row stride (floats): 128 + 4 keeps the transposed stores conflict-light
+    __shared__ __attribute__((aligned(16))) float bs[2][KC * LDB];
+    __shared__ float cs_lds[128];
+    if (threadIdx.x < 128) cs_lds[threadIdx.x] = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, kk = lane >> 5, wave = tid >> 6;
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    const int col0 = blockIdx.y * 128;
+    const long long arow = min(row0 + i, R - 1);  // rows past the end compute values that are never stored
+    const float *ap = A + arow * lda;
+    f32x16_ acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // cooperative load of one B chunk: 16 x 128 floats = 512 float4, two per thread
+    f32x4 breg[2];
+    auto load_b = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = tid + 256 * h;
+            if (TRANS_B) {  // B[col][k]: thread -> (col = q / 4, four consecutive k)
+                const int col = min(col0 + (q >> 2), N - 1);
+                breg[h] = *reinterpret_cast<const f32x4 *>(B + (size_t)col * ldb + k0 + 4 * (q & 3));
+            } else {  // B[k][col]: thread -> (k = q / 32, four consecutive columns)
+                const int col = col0 + 4 * (q & 31);
+                const float *bp = B + (size_t)(k0 + (q >> 5)) * ldb;
+                if (col + 3 < N) breg[h] = *reinterpret_cast<const f32x4 *>(bp + col);  // ldb % 4 == 0 and col0 % 4 == 0 on this path
+                else breg[h] = f32x4{col < N ? bp[col] : 0.f, col + 1 < N ? bp[col + 1] : 0.f, col + 2 < N ? bp[col + 2] : 0.f, 0.f};
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = tid + 256 * h;
+            if (TRANS_B) {
+                const int c = q >> 2, k4 = 4 * (q & 3);
+                bs[buf][(k4 + 0) * LDB + c] = breg[h].x;
+                bs[buf][(k4 + 1) * LDB + c] = breg[h].y;
+                bs[buf][(k4 + 2) * LDB + c] = breg[h].z;
+                bs[buf][(k4 + 3) * LDB + c] = breg[h].w;
+            } else {
+                *reinterpret_cast<f32x4 *>(&bs[buf][(q >> 5) * LDB + 4 * (q & 31)]) = breg[h];
+            }
+        }
+    };
+    f32x4 a[4];
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = *reinterpret_cast<const f32x4 *>(ap + k0 + 4 * c);
+    };
+    load_b(0);
+    load_a(0);
+    store_b(0);
+    __syncthreads();
+    const int nchunk = K / KC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        f32x4 an[4] = {a[0], a[1], a[2], a[3]};
+        if (ch + 1 < nchunk) {
+            load_b((ch + 1) * KC);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) an[c] = *reinterpret_cast<const f32x4 *>(ap + (ch + 1) * KC + 4 * c);
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {  // k = 2 c + kk
+            const f32x4 q = a[c >> 1];
+            const float av = (c & 1) ? (kk ? q.w : q.z) : (kk ? q.y : q.x);
+            const float *bp = &bs[buf][(2 * c + kk) * LDB + i];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[32 * t], acc[t], 0, 0, 0);
+        }
+        if (ch + 1 < nchunk) store_b(buf ^ 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = an[c];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = col0 + 32 * t + i;
+        if (col >= N || row0 >= R) continue;
+        float cs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + tn_tile_row(r, kk);
+            if (row >= R) continue;
+            float v = alpha * acc[t][r];
+            float *cp = C + row * ldc + col;
+            if (beta != 0.f) v += beta * *cp;
+            if (mask_y && !(mask_y[row * ldy + col] > 0.f)) v = 0.f;
+            *cp = v;
+            cs += v;
+        }
+        if (colsum) atomicAdd(&cs_lds[32 * t + i], cs);
+    }
+    if (colsum) {
+        __syncthreads();
+        if (threadIdx.x < 128 && col0 + (int)threadIdx.x < N) atomicAdd(&colsum[col0 + threadIdx.x], cs_lds[threadIdx.x]);
+    }
+}
 
 }  // namespace
 
@@ -200,9 +374,17 @@ int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float al
              const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream) {
     NB_REQUIRE(a && b && c && m >= 0 && n >= 0 && k >= 0, "nb_sgemm: bad argument");
     if (m == 0 || n == 0) return NB_OK;
-    if (trans_a && !trans_b && k >= 4096 && m <= 512 && n <= 512) {
-        // weight-gradient shape: split the long K (row) dimension across waves (gemm_tn_kernel)
-        hipStream_t st = (hipStream_t)stream;
+    return nb_gemm_fused(trans_a, trans_b, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, nullptr, 0, nullptr, stream);
+}
+
+int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
+                  const float *b, int32_t ldb, float beta, float *c, int32_t ldc, const float *mask_y, int32_t ldy,
+                  float *colsum, void *stream) {
+    NB_REQUIRE(a && b && c && m >= 0 && n >= 0 && k >= 0, "nb_gemm_fused: bad argument");
+    if (m == 0 || n == 0) return NB_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (trans_a) {
+        NB_REQUIRE(!trans_b && !mask_y && !colsum, "nb_gemm_fused: op(A) = A^T is the weight-gradient form (no epilogue, B not transposed)");
         if (beta != 1.f)
             hipLaunchKernelGGL(scale_matrix_kernel, dim3(nb_ceil_div((long long)m * n, 256)), dim3(256), 0, st, c, m, n, ldc, beta);
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(nb_ceil_div(k, 4 * TN_ROWS), nb_ceil_div(m, 32), nb_ceil_div(n, 32)), dim3(256),
@@ -210,22 +392,16 @@ int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float al
         NB_CHECK_LAUNCH("gemm_tn_kernel");
         return NB_OK;
     }
-    if (!g_handle) {
-        if (rocblas_create_handle(&g_handle) != rocblas_status_success) {
-            nb_set_error("nb_sgemm: rocblas_create_handle failed");
-            return NB_ELAUNCH;
-        }
-    }
-    rocblas_set_stream(g_handle, (hipStream_t)stream);
-    rocblas_set_pointer_mode(g_handle, rocblas_pointer_mode_host);
-    // row-major C[m,n] = op(A) op(B)  ==  column-major C^T[n,m] = op(B)^T op(A)^T
-    const rocblas_status st = rocblas_sgemm(g_handle, trans_b ? rocblas_operation_transpose : rocblas_operation_none,
-                                            trans_a ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha,
-                                            b, ldb, a, lda, &beta, c, ldc);
-    if (st != rocblas_status_success) {
-        nb_set_error("nb_sgemm: rocblas_sgemm status %d", (int)st);
-        return NB_ELAUNCH;
-    }
+    const dim3 grid(nb_ceil_div(m, 128), nb_ceil_div(n, 128)), block(256);
+    const bool aligned = k % 16 == 0 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ldb % 4 == 0 && ((uintptr_t)b % 16) == 0;
+    if (aligned && trans_b)
+        hipLaunchKernelGGL((gemm_rows_fast_kernel<true>), grid, block, 0, st, a, lda, b, ldb, (long long)m, k, n, alpha, beta, c, ldc, mask_y, ldy, colsum);
+    else if (aligned)
+        hipLaunchKernelGGL((gemm_rows_fast_kernel<false>), grid, block, 0, st, a, lda, b, ldb, (long long)m, k, n, alpha, beta, c, ldc, mask_y, ldy, colsum);
+    else
+        hipLaunchKernelGGL(gemm_rows_kernel, grid, block, 0, st, a, lda, b, ldb, trans_b, (long long)m, k, n, alpha, beta, c, ldc,
+                           mask_y, ldy, colsum);
+    NB_CHECK_LAUNCH("gemm_rows_kernel");
     return NB_OK;
 }
 

@@ -427,13 +427,23 @@ static int check_params(const nb_mlp_params *p) {
 }
 
 int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream) {
+    return nb_mlp_pack_sections(p, packed, NB_PACK_ALL, stream);
+}
+
+int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, void *stream) {
     if (int rc = check_params(p)) return rc;
     NB_REQUIRE(packed != nullptr, "nb_mlp_pack: packed is NULL");
+    NB_REQUIRE((sections & ~NB_PACK_ALL) == 0, "nb_mlp_pack_sections: unknown section bits %d", sections);
+    // the fp32 section is always written: the other streams read the merged feature/latent layer from it
     hipLaunchKernelGGL(nb_pack_kernel, dim3(nb_ceil_div(PACK_SIZE, 256)), dim3(256), 0, (hipStream_t)stream, *p, packed);
     NB_CHECK_LAUNCH("nb_pack_kernel");
-    if (int rc = nbm::pack_bf16_stream(p, packed, (hipStream_t)stream)) return rc;  // reads the merged layer from the fp32 section
-    if (int rc = nbm::pack_msplit_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream)) return rc;
-    return nbm::pack_f16_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(), (hipStream_t)stream);
+    if (sections & NB_PACK_BF16X3)
+        if (int rc = nbm::pack_bf16_stream(p, packed, (hipStream_t)stream)) return rc;
+    if (sections & NB_PACK_BF16X3S)
+        if (int rc = nbm::pack_msplit_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream)) return rc;
+    if (sections & NB_PACK_F16F8)
+        if (int rc = nbm::pack_f16_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(), (hipStream_t)stream)) return rc;
+    return NB_OK;
 }
 
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream) {

@@ -139,6 +139,7 @@ class Network(nn.Module):
         self.rgb_fc = nn.Conv1d(128, 3, 1)
         self._packed = None
         self._packed_key = None
+        self._packed_have = set()
         self._t_vals = {}
 
     # ------------------------------------------------------------------ packed decoder weights
@@ -155,8 +156,11 @@ class Network(nn.Module):
         'f16f8') decode stand-alone points with the split-bf16 kernels."""
         return "bf16x3" if self.precision in ("bf16x3s", "f16f8") else self.precision
 
-    def packed_weights(self):
-        """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed."""
+    def packed_weights(self, precision=None):
+        """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed; only the sections of the
+        arithmetics asked for since the last change are (re)written — a training step repacks every iteration and only
+        ever decodes with 'f32'."""
+        need = {precision or self.precision, self._point_precision()} if precision is None else {precision}
         d = self._mlp_param_dict()
         # keyed on the parameters' storages, which the entry keeps alive (so an address cannot be recycled under the
         # key), and on their version counters (optimizer steps and load_state_dict write in place)
@@ -165,8 +169,12 @@ class Network(nn.Module):
         same = old is not None and len(old) == len(key) and all(
             a[0]._cdata == b[0]._cdata and a[1:] == b[1:] for a, b in zip(old, key))
         if self._packed is None or not same:
-            self._packed = ops.mlp_pack(d, None)
+            self._packed = ops.mlp_pack(d, self._packed, precisions=need)
             self._packed_key = key
+            self._packed_have = set(need) | {"f32"}
+        elif not need <= self._packed_have:
+            ops.mlp_pack(d, self._packed, precisions=need - self._packed_have)
+            self._packed_have |= need
         return self._packed
 
     def latent_bias(self, latent_index):
@@ -211,7 +219,7 @@ class Network(nn.Module):
         if n_batch != 1:
             raise NotImplementedError("batch size 1 only")
         p = wpts.reshape(-1, 3).float().contiguous()
-        out = ops.decode_points(scene, self.packed_weights(), None, p, None, density_only=True,
+        out = ops.decode_points(scene, self.packed_weights(self._point_precision()), None, p, None, density_only=True,
                                 precision=self._point_precision())
         return out.view(1, -1, 1)
 
@@ -222,7 +230,7 @@ class Network(nn.Module):
         p = wpts.reshape(-1, 3).float().contiguous()
         v = viewdir.reshape(-1, 3).float().contiguous()
         lb = self.latent_bias(sp_input["latent_index"])
-        out = ops.decode_points(scene, self.packed_weights(), lb, p, v, precision=self._point_precision())
+        out = ops.decode_points(scene, self.packed_weights(self._point_precision()), lb, p, v, precision=self._point_precision())
         return out.view(1, -1, 4)
 
     def forward(self, sp_input, grid_coords, viewdir, light_pts):
@@ -244,6 +252,6 @@ class Network(nn.Module):
         if t_vals is None:
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._t_vals[key] = t_vals
-        return ops.march(scene, self.packed_weights(), lb, ray_o, ray_d, near, far, t_vals, t_rand,
+        return ops.march(scene, self.packed_weights(self.precision), lb, ray_o, ray_d, near, far, t_vals, t_rand,
                          white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision, ray_order=ray_order,
                          cull=cull)

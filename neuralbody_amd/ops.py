@@ -110,14 +110,16 @@ def _mlp_params(params):
     return p, keep
 
 
-def mlp_pack(params, out=None):
-    """nb_mlp_pack: re-order the decoder weights into MFMA fragment order -> 1-D fp32 blob."""
+def mlp_pack(params, out=None, precisions=None):
+    """nb_mlp_pack(_sections): re-order the decoder weights into MFMA fragment order -> 1-D fp32 blob.  `precisions`:
+    iterable of arithmetic names whose sections are needed (None: all)."""
     p, keep = _mlp_params(params)
     dev = keep[0].device
     if out is None:
         out = torch.empty(mlp_pack_size(), dtype=torch.float32, device=dev)
     _req(out, torch.float32, (mlp_pack_size(),), "packed")
-    check(_lib.lib().nb_mlp_pack(C.byref(p), ptr(out), _stream()), "nb_mlp_pack")
+    bits = 15 if precisions is None else (1 | sum(_lib.PACK_SECTIONS[q] for q in set(precisions)))
+    check(_lib.lib().nb_mlp_pack_sections(C.byref(p), ptr(out), int(bits), _stream()), "nb_mlp_pack_sections")
     return out
 
 
@@ -389,9 +391,10 @@ def _mat(t, name):
     return t
 
 
-def sgemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0):
-    """nb_sgemm (rocBLAS): out[m,n] = alpha * op(a) @ op(b) + beta * out, row-major; a / b / out may be column
-    slices of wider matrices (row stride = leading dimension)."""
+def sgemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0, relu_mask=None, colsum=None):
+    """nb_gemm_fused (fp32 MFMA kernels of libnb_hip.so): out[m,n] = alpha * op(a) @ op(b) + beta * out, row-major; a / b /
+    out may be column slices of wider matrices (row stride = leading dimension).  Epilogues of the backward chain (not with
+    trans_a): relu_mask [m, n] (slice allowed): out is zeroed where relu_mask <= 0; colsum [n]: += column sums of out."""
     _mat(a, "a")
     _mat(b, "b")
     m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
@@ -404,8 +407,19 @@ def sgemm(a, b, trans_a=False, trans_b=False, out=None, alpha=1.0, beta=0.0):
     _mat(out, "out")
     if tuple(out.shape) != (m, n):
         raise ValueError("sgemm: out is %s, expected %s" % (tuple(out.shape), (m, n)))
-    check(_lib.lib().nb_sgemm(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, float(alpha), ptr(a), a.stride(0), ptr(b),
-                              b.stride(0), float(beta), ptr(out), out.stride(0), _stream()), "nb_sgemm")
+    ldy = 0
+    if relu_mask is not None:
+        _mat(relu_mask, "relu_mask")
+        if tuple(relu_mask.shape) != (m, n):
+            raise ValueError("sgemm: relu_mask is %s, expected %s" % (tuple(relu_mask.shape), (m, n)))
+        ldy = relu_mask.stride(0)
+    if colsum is not None:
+        _req(colsum, torch.float32, (n,), "colsum")
+    if (relu_mask is not None or colsum is not None) and trans_a:
+        raise ValueError("sgemm: epilogues are not available for the weight-gradient form (trans_a)")
+    check(_lib.lib().nb_gemm_fused(1 if trans_a else 0, 1 if trans_b else 0, m, n, k, float(alpha), ptr(a), a.stride(0), ptr(b),
+                                   b.stride(0), float(beta), ptr(out), out.stride(0), ptr(relu_mask), ldy, ptr(colsum),
+                                   _stream()), "nb_gemm_fused")
     return out
 
 

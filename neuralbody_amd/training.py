@@ -3,7 +3,7 @@
 Forward in training mode decodes the sample points with the activation tap on (`nb_decode_points(dbg=...)`:
 F | h1 | h2 | h3 | G | V | PE per point) and composites with `nb_composite`; the backward below consumes the tap:
 
-    d rgb_map --nb_composite_bwd--> d raw --MLP backward (rocBLAS GEMMs via nb_sgemm, nb_relu_bwd, nb_colsum)-->
+    d rgb_map --nb_composite_bwd--> d raw --MLP backward (fp32 MFMA GEMMs with fused ReLU-mask / bias-sum epilogues)-->
     parameter gradients + dF --nb_trilinear_bwd--> gradients of the active rows of the four feature volumes
 
 All arithmetic is fp32.  The merged feature_fc/latent_fc layer of the inference kernels is NOT used here: gradients are
@@ -24,52 +24,62 @@ def decoder_backward(net, tap, d_raw, latent_index):
     """Gradients of the MLP parameters and of the gathered features.
 
     tap [N,1600] activation tap, d_raw [N,4] = d(rgb logits, sigma).  Returns (grads, dF) where grads maps the
-    reference's parameter names to gradient tensors and dF is [N,352]."""
+    reference's parameter names to gradient tensors and dF is [N,352].  Every product is an fp32 MFMA kernel of
+    libnb_hip.so (ops.sgemm); the input-gradient products carry the ReLU mask of the layer below and that layer's bias
+    gradient (column sums) in their epilogue."""
     N = tap.shape[0]
+    dev = tap.device
     sl = lambda k: tap[:, TAP[k][0]:TAP[k][1]]  # noqa: E731  column slices (row stride 1600)
     F, h1, h2, h3, G, V, PE = (sl(k) for k in ("F", "h1", "h2", "h3", "G", "V", "PE"))
     d_rgb, d_sig = d_raw[:, 0:3], d_raw[:, 3:4]
     W0, W1, W2 = _w2(net.fc_0), _w2(net.fc_1), _w2(net.fc_2)
     Wa, Wf, Wl, Wv, Wr = _w2(net.alpha_fc), _w2(net.feature_fc), _w2(net.latent_fc), _w2(net.view_fc), _w2(net.rgb_fc)
+    zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
     g = {}
     # rgb_fc (latent_xyzc.py:121)
     g["rgb_fc.weight"] = ops.sgemm(d_rgb, V, trans_a=True)
     g["rgb_fc.bias"] = ops.colsum(d_rgb)
-    dV = ops.sgemm(d_rgb, Wr)
-    ops.relu_bwd_(dV, V.contiguous())
+    g["alpha_fc.bias"] = ops.colsum(d_sig)
+    # dV = (d_rgb . W_rgb) * [V > 0]; its column sums are view_fc's bias gradient
+    g["view_fc.bias"] = zeros(128)
+    dV = ops.sgemm(d_rgb, Wr, relu_mask=V, colsum=g["view_fc.bias"])
     # view_fc on [latent_fc out | PE(viewdir) | PE(xyz)] (:113-120)
     gWv = torch.empty_like(Wv)
     ops.sgemm(dV, G, trans_a=True, out=gWv[:, 0:256])
     ops.sgemm(dV, PE, trans_a=True, out=gWv[:, 256:346])
     g["view_fc.weight"] = gWv
-    g["view_fc.bias"] = ops.colsum(dV)
-    dG = ops.sgemm(dV, Wv[:, 0:256])
-    # latent_fc on [feature_fc out | latent] (:106-111)
+    # dG = dV . W_view[:, :256]; column sums = latent_fc's bias gradient
+    sum_dG = zeros(256)
+    dG = ops.sgemm(dV, Wv[:, 0:256], colsum=sum_dG)
+    # latent_fc on [feature_fc out | latent] (:106-111): feature_fc's output is recomputed from h3 (not in the tap)
     latent = net.latent.weight.detach().index_select(0, latent_index.reshape(-1)[:1].long())  # [1,128]
     feat = net.feature_fc.bias.detach()[None].expand(N, 256).contiguous()
     ops.sgemm(h3, Wf, trans_b=True, out=feat, beta=1.0)
-    sum_dG = ops.colsum(dG)
     gWl = torch.empty_like(Wl)
     ops.sgemm(dG, feat, trans_a=True, out=gWl[:, 0:256])
     ops.sgemm(sum_dG[:, None], latent, out=gWl[:, 256:384])  # outer product: every sample sees the same latent
     g["latent_fc.weight"] = gWl
     g["latent_fc.bias"] = sum_dG
     g["latent.row"] = ops.sgemm(sum_dG[None], Wl[:, 256:384])[0]  # gradient of latent.weight[latent_index]
-    dfeat = ops.sgemm(dG, Wl[:, 0:256])
-    # feature_fc, alpha_fc (:103, :106)
+    # dfeat = dG . W_latent[:, :256]; column sums = feature_fc's bias gradient
+    g["feature_fc.bias"] = zeros(256)
+    dfeat = ops.sgemm(dG, Wl[:, 0:256], colsum=g["feature_fc.bias"])
     g["feature_fc.weight"] = ops.sgemm(dfeat, h3, trans_a=True)
-    g["feature_fc.bias"] = ops.colsum(dfeat)
     g["alpha_fc.weight"] = ops.sgemm(d_sig, h3, trans_a=True)
-    g["alpha_fc.bias"] = ops.colsum(d_sig)
+    # dh3 = (dfeat . W_feature + d_sigma . W_alpha) * [h3 > 0]; column sums = fc_2's bias gradient
     dh = ops.sgemm(dfeat, Wf)
-    ops.sgemm(d_sig, Wa, out=dh, beta=1.0)
-    # trunk (:99-101)
-    for name, W, h_out, h_in in (("fc_2", W2, h3, h2), ("fc_1", W1, h2, h1), ("fc_0", W0, h1, F)):
-        ops.relu_bwd_(dh, h_out.contiguous())
-        g[name + ".weight"] = ops.sgemm(dh, h_in, trans_a=True)
-        g[name + ".bias"] = ops.colsum(dh)
-        dh = ops.sgemm(dh, W)
-    return g, dh  # dh is now dF [N,352]
+    g["fc_2.bias"] = zeros(256)
+    ops.sgemm(d_sig, Wa, out=dh, beta=1.0, relu_mask=h3, colsum=g["fc_2.bias"])
+    # trunk (:99-101): each input-gradient product applies the mask of the layer below and sums its bias gradient
+    g["fc_2.weight"] = ops.sgemm(dh, h2, trans_a=True)
+    g["fc_1.bias"] = zeros(256)
+    dh = ops.sgemm(dh, W2, relu_mask=h2, colsum=g["fc_1.bias"])
+    g["fc_1.weight"] = ops.sgemm(dh, h1, trans_a=True)
+    g["fc_0.bias"] = zeros(256)
+    dh = ops.sgemm(dh, W1, relu_mask=h1, colsum=g["fc_0.bias"])
+    g["fc_0.weight"] = ops.sgemm(dh, F, trans_a=True)
+    dF = ops.sgemm(dh, W0)
+    return g, dF
 
 
 def encoder_backward(xyzc_net, ctx, drows_dense):
@@ -138,7 +148,7 @@ class RenderFunction(torch.autograd.Function):
             v = viewdir[:, :, None].expand(n_batch, n_pixel, S, 3).reshape(-1, 3).float().contiguous()
             scene = net.make_scene(vols, sp_input)
             lb = net.latent_bias(sp_input["latent_index"])
-            raw, tap = ops.decode_points(scene, net.packed_weights(), lb, w, v, debug=True, precision="f32")
+            raw, tap = ops.decode_points(scene, net.packed_weights("f32"), lb, w, v, debug=True, precision="f32")
             z = z_vals.reshape(-1, S).float().contiguous()
             rd = ray_d.reshape(-1, 3).float().contiguous()
             rgb, disp, acc, weights, depth = ops.composite(raw.view(-1, S, 4), z, rd, cfg.white_bkgd)

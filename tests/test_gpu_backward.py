@@ -92,6 +92,20 @@ def test_sgemm_relu_colsum():
     ops.sgemm(big_a[:, 3:68], big_b[:, 2:43], trans_a=True, out=acc[:, 4:45], alpha=2.0, beta=1.0)
     np.testing.assert_allclose(acc[:, 4:45].cpu().numpy(), (0.5 + 2.0 * ref).cpu().numpy(), rtol=2e-4, atol=4e-3)
     assert float(acc[:, :4].min()) == 0.5 and float(acc[:, 45:].max()) == 0.5
+    # fused epilogues of the backward chain: ReLU mask of the layer below + its bias gradient (column sums), accumulate form,
+    # ragged sizes (rows not a multiple of 32, K odd, N not a multiple of 32) and strided operands
+    for (m, k, n) in ((257, 3, 128), (1000, 129, 45), (64, 256, 352)):
+        A = torch.from_numpy(rs.standard_normal((m, k + 5)).astype(np.float32)).to(DEV)
+        Bm = torch.from_numpy(rs.standard_normal((k, n + 3)).astype(np.float32)).to(DEV)
+        Y = torch.from_numpy(rs.standard_normal((m, n + 7)).astype(np.float32)).to(DEV)
+        C0 = torch.from_numpy(rs.standard_normal((m, n + 2)).astype(np.float32)).to(DEV)
+        ref = (C0[:, 1:n + 1].double() + A[:, 2:k + 2].double() @ Bm[:, 1:n + 1].double()) * (Y[:, 4:n + 4] > 0)
+        out = C0.clone()
+        cs = torch.full((n,), 0.25, device=DEV)
+        ops.sgemm(A[:, 2:k + 2], Bm[:, 1:n + 1], out=out[:, 1:n + 1], beta=1.0, relu_mask=Y[:, 4:n + 4], colsum=cs)
+        np.testing.assert_allclose(out[:, 1:n + 1].cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(cs.cpu().numpy(), 0.25 + ref.sum(0).float().cpu().numpy(), rtol=1e-4, atol=2e-3)
+        assert torch.equal(out[:, 0], C0[:, 0]) and torch.equal(out[:, n + 1], C0[:, n + 1])
     y = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
     dy = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
     ref = torch.where(y > 0, dy, torch.zeros_like(dy))
