@@ -397,6 +397,16 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
         if constexpr (i < NREC) load_rec<REC0 + i>(rg, buf[i]);
     });
     f32x16 c0, c1;
+    // -DF_SPLIT_X: the 8-bit cross terms accumulate in their own tiles (added at the end of the pair) so that no
+    // accumulator chain alternates between the 8-pass fp16 and the 16-pass 8-bit MFMA
+#ifdef F_SPLIT_X
+    f32x16 cx0, cx1;
+#define X0 cx0
+#define X1 cx1
+#else
+#define X0 c0
+#define X1 c1
+#endif
     auto slice = [&](auto tc, auto sc) {  // slice sc (0..SPT-1) of tile tc: 16 / SPT values
         constexpr int t = decltype(tc)::value, sl = decltype(sc)::value;
         static_for<8 / SPT>([&](auto qc) {
@@ -410,9 +420,12 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
     static_for<NREC>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         constexpr int tp = k / RPP, j0 = k % RPP;
-        constexpr int b = j0 / BR < NBLK - 1 ? j0 / BR : NBLK - 1;  // every block before the last has 4 (+ 4) records
-        constexpr int j = j0 - BR * b;
-        constexpr int nch = b == NBLK - 1 ? NCH_LAST : 4;
+        // a pair's records: ALL main records first (chunk m = j0), then the cross records block by block.  (Alternating them
+        // block by block put an 8-pass fp16 and a 16-pass 8-bit MFMA back to back on the same accumulator eight times per
+        // pair, and every such hand-over stalled the chain for hundreds of cycles: profiles/r02_march_f16_phases.md)
+        constexpr bool is_main = j0 < NMAIN;
+        constexpr int b = is_main ? (j0 / 4 < NBLK ? j0 / 4 : NBLK - 1) : (j0 - NMAIN) / 4;
+        constexpr int xw = is_main ? 0 : (j0 - NMAIN) % 4;  // which cross record: X8h(t0), X8h(t1), X8l(t0), X8l(t1)
         if (j0 == 0) {
             if (INIT) {
                 c0 = f_bias_tile(bp, 2 * tp, hi);
@@ -421,6 +434,13 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
                 c0 = acc[2 * tp];
                 c1 = acc[2 * tp + 1];
             }
+#ifdef F_SPLIT_X
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                cx0[r] = 0.f;
+                cx1[r] = 0.f;
+            }
+#endif
         }
         Rec &cur = buf[k % (F_PF + 1)];
         if constexpr (k + F_PF < NREC) {
@@ -430,10 +450,7 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             wait_rec<2 * (NREC - 1 - k)>(cur);
         }
         // slice index carried by this record (-1: none): main record m -> slice m; overflow slices behind cross records
-        constexpr int m = 4 * b + (j < nch ? j : 0);
-        constexpr bool is_main = j < nch;
-        constexpr int n_cross_before = 4 * b + (j >= nch ? j - nch : 0);
-        constexpr int sl_idx = is_main ? (m < NSL ? m : -1) : (NMAIN + n_cross_before < NSL ? NMAIN + n_cross_before : -1);
+        constexpr int sl_idx = is_main ? (j0 < NSL ? j0 : -1) : (j0 < NSL ? j0 : -1);
         auto run_slice = [&]() {
             if constexpr (CV != 0 && tp > 0 && sl_idx >= 0) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -441,17 +458,17 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
-        if constexpr (j < nch) {
-            c0 = mfma_main(cur.p0, xh[4 * b + j], c0);
+        if constexpr (is_main) {
+            c0 = mfma_main(cur.p0, xh[j0], c0);
             run_slice();
-            c1 = mfma_main(cur.p1, xh[4 * b + j], c1);
-        } else if constexpr (j == nch) {
+            c1 = mfma_main(cur.p1, xh[j0], c1);
+        } else if constexpr (xw == 0) {
             c0 = mfma_cross(cur, xl[b], c0, sc_h, SC_XL);
             run_slice();
-        } else if constexpr (j == nch + 1) {
+        } else if constexpr (xw == 1) {
             c1 = mfma_cross(cur, xl[b], c1, sc_h, SC_XL);
             run_slice();
-        } else if constexpr (j == nch + 2) {
+        } else if constexpr (xw == 2) {
             c0 = mfma_cross(cur, xx[b], c0, sc_l, SC_ONE);
             run_slice();
         } else {
@@ -469,11 +486,19 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             // pin the end of the pair's accumulator chains here: the MFMAs are pure, and code sinking otherwise moves the
             // tail of every chain into the block that first reads the tile (past the next level's gather), keeping the
             // records they read alive in registers
+#ifdef F_SPLIT_X
+            if (XT) {
+                c0 += cx0;
+                c1 += cx1;
+            }
+#endif
             asm volatile("" : "+a"(c0), "+a"(c1));
             acc[2 * tp] = c0;
             acc[2 * tp + 1] = c1;
         }
     });
+#undef X0
+#undef X1
     if constexpr (CV != 0) {  // the last pair: exposed
         static_for<2 * SPT>([&](auto sc) {
             constexpr int sl = decltype(sc)::value;
@@ -535,11 +560,7 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         F_STAMP(13);
     }
     ops_from<8>(nx, xh, xl, xx);
-#ifdef F_TIMING
-    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx, NoExtra(), tbuf ? tbuf + 8192 + 96 * ((tbuf - tbuf0) / 32) : nullptr);
-#else
     layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx);
-#endif
     F_STAMP(14);
     ops_from<8>(nx, xh, xl, xx);
     // fc_2.  alpha_fc (fp32, VALU) is NOT folded into the conversion slices: its weights come from LDS, and a
@@ -568,7 +589,11 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings; rgb_fc (fp32,
     // VALU) rides on the finished tiles of the second phase
     f32x16 v[4];
+#ifdef F_TIMING
+    layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, scl[8], scl[9], nullptr, NoExtra(), tbuf ? tbuf + 8192 + 96 * ((tbuf - tbuf0) / 32) : nullptr);
+#else
     layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, scl[8], scl[9]);
+#endif
     F_STAMP(17);
     float s_rgb[3] = {0.f, 0.f, 0.f};
     {
@@ -842,10 +867,13 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
     const PhaseGeom g = phase_geom(ph);
     const int rpp = recs_per_pair(g.nblk, g.nch_last, g.x), br = 4 + 4 * g.x;
     const int rel = rec - g.rec0, tp = rel / rpp, j0 = rel % rpp;
-    const int b = j0 / br < g.nblk - 1 ? j0 / br : g.nblk - 1, j = j0 - br * b, nch = b == g.nblk - 1 ? g.nch_last : 4;
+    const int nmain = (g.nblk - 1) * 4 + g.nch_last;
+    const bool is_main = j0 < nmain;
+    const int b = is_main ? j0 / 4 : (j0 - nmain) / 4;  // main record j0 = chunk j0 of the phase; then 4 cross records per block
+    (void)br;
     unsigned w32[8];
-    if (j < nch) {  // main record: A16(c, t0) | A16(c, t1)
-        const int c = 4 * b + j;
+    if (is_main) {  // main record: A16(c, t0) | A16(c, t1)
+        const int c = j0;
         for (int half = 0; half < 2; ++half) {
             const int row = 32 * (2 * tp + half) + i;
             for (int r = 0; r < 8; r += 2) {
@@ -855,7 +883,7 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
             }
         }
     } else {  // X8h(t0), X8h(t1), X8l(t0), X8l(t1): 32 fp8 values of K-block b
-        const int which = j - nch, row = 32 * (2 * tp + (which & 1)) + i, lo = which >> 1;
+        const int which = (j0 - nmain) % 4, row = 32 * (2 * tp + (which & 1)) + i, lo = which >> 1;
         const int e8 = scales[2 * phase_layer(ph) + lo];  // 127 - exponent
         const float mul = ldexpf(1.f, 127 - e8);
         for (int e = 0; e < 32; e += 4) {

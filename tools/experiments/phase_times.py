@@ -38,6 +38,6 @@ print("| one depth step | %.0f | |" % tot)
 tr = out["raw"].view(torch.int32).reshape(-1)[8192:8192 + 64 * 128].cpu().numpy().astype(np.int64).reshape(64, 128)
 dr = (np.diff(tr, axis=1) & 0xffffffff)[2:-1]
 m = dr.mean(0)
-print("fc_1 record-to-record cycles (records 1..127; a pair = 32 records: 4 x [4 main, 4 cross]; page turns every 12):")
-for i in range(0, 127, 16):
+print("view_fc-over-g record-to-record cycles (records 1..63; a pair = 32 records: 4 x [4 main, 4 cross]; page turns every 12):")
+for i in range(0, 63, 16):
     print(" ".join("%4d" % v for v in m[i:i + 16]))
