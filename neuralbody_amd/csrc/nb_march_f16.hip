@@ -52,12 +52,11 @@ __host__ __device__ constexpr int recs_phase(int nt, int nblk, int nch_last, int
 #ifndef F_MERGED_X
 #define F_MERGED_X 0
 #endif
-// fc_0 is consumed level by level (levels 0..3 = 32, 64, 128, 128 channels = 16, 32, 64, 64 values per lane)
+// fc_0 is ONE phase over the 176 gathered values of a lane in the order [level 1 (32) | level 2 (64) | level 3 (64) |
+// level 0 (16) | 16 zeros] = 6 K-blocks, the last with 2 chunks (all four pyramid levels are gathered before the layer
+// starts: their tile fetches are in flight together, and the 184 records run without a gather in between)
 constexpr int FR_F0 = 0;
-constexpr int FR_F1 = FR_F0 + recs_phase(8, 1, 2);
-constexpr int FR_F2 = FR_F1 + recs_phase(8, 1, 4);
-constexpr int FR_F3 = FR_F2 + recs_phase(8, 2, 4);
-constexpr int FR_L1 = FR_F3 + recs_phase(8, 2, 4);
+constexpr int FR_L1 = FR_F0 + recs_phase(8, 6, 2);
 constexpr int FR_L2 = FR_L1 + recs_phase(8, 4, 4);
 constexpr int FR_L4 = FR_L2 + recs_phase(8, 4, 4);
 constexpr int FR_VG = FR_L4 + recs_phase(8, 4, 4, F_MERGED_X);   // view_fc over the merged layer's 256 outputs
@@ -514,25 +513,8 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
 #else
 #define F_STAMP(i) do { } while (0)
 #endif
-template <int L, int NG, int CV>
-__device__ __forceinline__ void level_phase(const SceneDev &sc, const FRing &rg, const GridCoord &g, const WaveBox &wb, const float *bp,
-                                            f32x16 (&acc)[8], int sc_h, int sc_l, NextOps *out, unsigned *tbuf, int stamp0) {
-    constexpr int REC0 = L == 0 ? FR_F0 : (L == 1 ? FR_F1 : (L == 2 ? FR_F2 : FR_F3));
-    const int hi = rg.lane >> 5;
-    float f[16 * NG];
-#ifdef F_ABL_NOGATHER
-#pragma unroll
-    for (int i = 0; i < 16 * NG; ++i) f[i] = g.gw * (float)(i + 1) + g.gh;
-#else
-    gather_level_coop<L, TILE_BYTES>(sc, g, wb, hi, rg.lane, rg.tile, f);
-#endif
-    F_STAMP(stamp0);
-    f16x8 fh[2 * NG];
-    i32x8 fl[(NG + 1) / 2], fx[(NG + 1) / 2];
-    make_operands<NG, false>([&](int i) { return f[i]; }, fh, fl, fx);
-    F_STAMP(stamp0 + 1);
-    layer_phase<REC0, 8, (NG + 1) / 2, NG == 1 ? 2 : 4, L == 0, CV>(rg, bp, acc, fh, fl, fx, sc_h, sc_l, out);
-}
+// fc_0 operand slot (0..175) of the q-th gathered value of pyramid level L (see the stream geometry above)
+__host__ __device__ constexpr int f0_slot(int L, int q) { return L == 1 ? q : (L == 2 ? 32 + q : (L == 3 ? 96 + q : 160 + q)); }
 
 __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, float px, float py, float pz, float vx, float vy, float vz,
                                            float (&pe)[N_PE], float (&out)[4], unsigned *tbuf, unsigned *tbuf0 = nullptr) {
@@ -544,19 +526,81 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     i32x8 xl[4], xx[4];
     NextOps nx;
     {
-        // fc_0 level by level: gather one pyramid level (fp32), convert it, accumulate its K range into all 8 tiles;
-        // the last level's phase converts the finished tiles (relu) into fc_1's operands on the fly
+        // gather: the tile fetches of all four pyramid levels are issued first (32 coalesced 16-byte loads per lane in
+        // flight together), then level after level goes registers -> LDS tile -> trilinear blend -> operands
         const GridCoord g = grid_coords(sc, px, py, pz);
         const WaveBox wb = wave_box(g);
-        const int sh = scl[0], sl = scl[1];
         F_STAMP(1);
-        level_phase<0, 1, 0>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, nullptr, tbuf, 2);
+        f16x8 fh[24];
+        i32x8 fl[6], fx[6];
+#ifdef F_ABL_NOGATHER
+        float f[192];
+#pragma unroll
+        for (int i = 0; i < 192; ++i) f[i] = i < 176 ? g.gw * (float)(i + 1) + g.gh : 0.f;
+        make_operands<12, false>([&](int i) { return f[i]; }, fh, fl, fx);
+#else
+        CoopFetch<TILE_BYTES> c0f, c1f, c2f, c3f;
+        coop_issue<0, TILE_BYTES>(sc, wb, rg.lane, c0f);
+        coop_issue<1, TILE_BYTES>(sc, wb, rg.lane, c1f);
+        coop_issue<2, TILE_BYTES>(sc, wb, rg.lane, c2f);
+        coop_issue<3, TILE_BYTES>(sc, wb, rg.lane, c3f);
+        F_STAMP(2);
+        {
+            float f0[16];
+            coop_finish<0, TILE_BYTES>(sc, g, c0f, hi, rg.lane, rg.tile, f0);
+            // level 0 fills the first half of the last block (slots 160..175), the second half is zero
+            f16x8 h2[2];
+            i32x8 l1[1], x1[1];
+            make_operands<1, false>([&](int i) { return f0[i]; }, h2, l1, x1);
+            fh[20] = h2[0];
+            fh[21] = h2[1];
+            fl[5] = l1[0];
+            fx[5] = x1[0];
+        }
+        F_STAMP(3);
+        {
+            float f1[32];
+            coop_finish<1, TILE_BYTES>(sc, g, c1f, hi, rg.lane, rg.tile, f1);
+            f16x8 h4[4];
+            i32x8 l1[1], x1[1];
+            make_operands<2, false>([&](int i) { return f1[i]; }, h4, l1, x1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) fh[c] = h4[c];
+            fl[0] = l1[0];
+            fx[0] = x1[0];
+        }
         F_STAMP(4);
-        level_phase<1, 2, 0>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, nullptr, tbuf, 5);
-        F_STAMP(7);
-        level_phase<2, 4, 0>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, nullptr, tbuf, 8);
-        F_STAMP(10);
-        level_phase<3, 4, 1>(sc, rg, g, wb, prm + P_B0, acc, sh, sl, &nx, tbuf, 11);
+        {
+            float f2[64];
+            coop_finish<2, TILE_BYTES>(sc, g, c2f, hi, rg.lane, rg.tile, f2);
+            f16x8 h8[8];
+            i32x8 l2[2], x2[2];
+            make_operands<4, false>([&](int i) { return f2[i]; }, h8, l2, x2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) fh[4 + c] = h8[c];
+            fl[1] = l2[0];
+            fl[2] = l2[1];
+            fx[1] = x2[0];
+            fx[2] = x2[1];
+        }
+        F_STAMP(5);
+        {
+            float f3[64];
+            coop_finish<3, TILE_BYTES>(sc, g, c3f, hi, rg.lane, rg.tile, f3);
+            f16x8 h8[8];
+            i32x8 l2[2], x2[2];
+            make_operands<4, false>([&](int i) { return f3[i]; }, h8, l2, x2);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) fh[12 + c] = h8[c];
+            fl[3] = l2[0];
+            fl[4] = l2[1];
+            fx[3] = x2[0];
+            fx[4] = x2[1];
+        }
+#endif
+        F_STAMP(6);
+        // fc_0: 6 K-blocks (22 chunks), finished tiles converted (relu) into fc_1's operands on the fly
+        layer_phase<FR_F0, 8, 6, 2, true, 1>(rg, prm + P_B0, acc, fh, fl, fx, scl[0], scl[1], &nx);
         F_STAMP(13);
     }
     ops_from<8>(nx, xh, xl, xx);
@@ -765,39 +809,42 @@ __global__ __launch_bounds__(256) void nb_march_f16_kernel(MarchArgs a, const ch
 
 // ---------------------------------------------------------------- weight stream packing
 // weight of layer phase `ph` at (output row, operand element q of a lane with half index kg); 0 for padding
+// phases: 0 fc_0, 1 fc_1, 2 fc_2, 3 merged feature/latent layer, 4 view_fc over the merged outputs, 5 view_fc over the encodings
 __device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const float *f32_blob, int ph, int row, int q, int kg) {
-    if (ph < 4) {  // fc_0, pyramid level ph: q-th gathered value of the level
-        const int half = lvl_c(ph) / 2;
-        if (q >= half) return 0.f;
-        return p.fc0_w[row * 352 + col_feat(lvl_reg_base(ph) + q, kg)];
+    if (ph == 0) {  // fc_0: slots [level 1 | level 2 | level 3 | level 0 | zeros]
+        int L, idx;
+        if (q < 32) { L = 1; idx = q; }
+        else if (q < 96) { L = 2; idx = q - 32; }
+        else if (q < 160) { L = 3; idx = q - 96; }
+        else if (q < 176) { L = 0; idx = q - 160; }
+        else return 0.f;
+        return p.fc0_w[row * 352 + col_feat(lvl_reg_base(L) + idx, kg)];
     }
-    if (ph == 4) return p.fc1_w[row * 256 + col_hidden(q, kg)];
-    if (ph == 5) return p.fc2_w[row * 256 + col_hidden(q, kg)];
-    if (ph == 6) {
+    if (ph == 1) return p.fc1_w[row * 256 + col_hidden(q, kg)];
+    if (ph == 2) return p.fc2_w[row * 256 + col_hidden(q, kg)];
+    if (ph == 3) {
         // merged latent_fc[:, :256] @ feature_fc from the fp32 section (computed in fp64 there): invert col_hidden
         const int col = col_hidden(q, kg);
         const int tt = col >> 5, rr = col & 31, hi2 = (rr >> 2) & 1, r2 = (rr & 3) + 4 * (rr >> 3), q2 = 16 * tt + r2;
         return f32_blob[F_OFF_L4 + (((row >> 5) * 32 + (q2 >> 2)) * 64 + (hi2 * 32 + (row & 31))) * 4 + (q2 & 3)];
     }
-    if (ph == 7) return p.view_w[row * 346 + col_hidden(q, kg)];
+    if (ph == 4) return p.view_w[row * 346 + col_hidden(q, kg)];
     const int col = col_pe(q, kg);  // q >= 45 -> -1
     return col < 0 ? 0.f : p.view_w[row * 346 + col];
 }
-__device__ __forceinline__ int phase_layer(int ph) { return ph < 4 ? 0 : (ph < 7 ? ph - 3 : 4); }
+__device__ __forceinline__ int phase_layer(int ph) { return ph < 4 ? ph : 4; }
+constexpr int N_PHASES = 6;
 
 struct PhaseGeom {
     int rec0, nt, nblk, nch_last, x;
 };
 __device__ __forceinline__ PhaseGeom phase_geom(int ph) {
     switch (ph) {
-        case 0: return {FR_F0, 8, 1, 2, 1};
-        case 1: return {FR_F1, 8, 1, 4, 1};
-        case 2: return {FR_F2, 8, 2, 4, 1};
-        case 3: return {FR_F3, 8, 2, 4, 1};
-        case 4: return {FR_L1, 8, 4, 4, 1};
-        case 5: return {FR_L2, 8, 4, 4, 1};
-        case 6: return {FR_L4, 8, 4, 4, F_MERGED_X};
-        case 7: return {FR_VG, 4, 4, 4, 1};
+        case 0: return {FR_F0, 8, 6, 2, 1};
+        case 1: return {FR_L1, 8, 4, 4, 1};
+        case 2: return {FR_L2, 8, 4, 4, 1};
+        case 3: return {FR_L4, 8, 4, 4, F_MERGED_X};
+        case 4: return {FR_VG, 4, 4, 4, 1};
         default: return {FR_VP, 4, 2, 2, 1};
     }
 }
@@ -808,7 +855,7 @@ __global__ void nb_f16_scales_kernel(nb_mlp_params p, const float *__restrict__ 
     const int layer = blockIdx.x;  // fc_0, fc_1, fc_2, merged, view_fc
     __shared__ float mh[256], ml[256];
     float a = 0.f, b = 0.f;
-    const int ph0 = layer == 0 ? 0 : (layer < 4 ? layer + 3 : 7), ph1 = layer == 0 ? 4 : (layer < 4 ? layer + 4 : 9);
+    const int ph0 = layer, ph1 = layer < 4 ? layer + 1 : N_PHASES;  // view_fc = phases 4 and 5
     for (int ph = ph0; ph < ph1; ++ph) {
         const PhaseGeom g = phase_geom(ph);
         const int rows = 32 * g.nt, nq = 32 * g.nblk;
@@ -858,8 +905,8 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
         for (int k = 0; k < 4; ++k) padp[lane * 4 + k] = padp[256 + lane * 4 + k] = 0u;
         return;
     }
-    int ph = 8;
-    for (int q = 0; q < 8; ++q)
+    int ph = N_PHASES - 1;
+    for (int q = 0; q + 1 < N_PHASES; ++q)
         if (rec < phase_geom(q + 1).rec0) {
             ph = q;
             break;
