@@ -317,40 +317,66 @@ struct NextOps {  // operands of the next layer being assembled word by word
     unsigned h[64];
     int l[32], x[32];
 };
-// values 2 * p, 2 * p + 1 (p = 0..7) of `tile` -> their share of tile t's operand words
-template <bool RELU, int P, bool HEAD_ONLY = false, class Extra>
-__device__ __forceinline__ void cv_slice(const f32x16 &tile, int t, NextOps &o, Extra &&extra) {
-    float v0 = tile[2 * P], v1 = tile[2 * P + 1];
-    if (RELU) {
-        v0 = relu_asm(v0);
-        v1 = relu_asm(v1);
-    }
+// Conversion of values 2 P, 2 P + 1 (P = 0..7) of a finished accumulator tile into their share of tile t's operand words,
+// as TWO hand-written half-slices.  Each is one asm block: between separate asm statements and conversion builtins hipcc
+// inserts a conservative `s_nop 0` per statement (it cannot see what the asm wrote), ~1000 issue slots per depth step.
+//   half A: AGPR -> VGPR, relu, fp16 head pair            (5 instructions, 3 without relu)
+//   half B: bf8 of the values, remainders, bf8 of the remainders * 2^12   (4 instructions)
+// Hazards inside: the partial-register conversions (op_sel word writes) are not read within the next instruction; the
+// accumulators read here were last written at least two MFMAs earlier (see layer_phase).
+struct SliceRegs {
+    float v0, v1;
+    unsigned h;
+};
+template <bool RELU>
+__device__ __forceinline__ void cv_half_a(float a0, float a1, SliceRegs &r) {
 #ifdef F_ABL_NOCONV
-    o.h[8 * t + P] = __float_as_uint(v0);
-    o.l[4 * t + (P >> 1)] = __float_as_int(v1);
-    o.x[4 * t + (P >> 1)] = __float_as_int(v0);
-    extra(t, P, v0, v1);
+    asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=&v"(r.v0), "=&v"(r.v1) : "a"(a0), "a"(a1));
+    r.h = __float_as_uint(r.v0);
     return;
 #endif
-    const unsigned h = cvt_pk_f16(v0, v1);
-    o.h[8 * t + P] = h;
-    if constexpr (HEAD_ONLY) {
-        extra(t, P, v0, v1);
-        return;
-    }
-    constexpr float inv = 1.0f / (float)(1 << LO_SHIFT);
-    constexpr int w = P >> 1;
-    if (P & 1) {
-        const i16x2 lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(__builtin_bit_cast(i16x2, o.l[4 * t + w]), rem16<0>(v0, h), rem16<1>(v1, h), inv, true);
-        o.l[4 * t + w] = __builtin_bit_cast(int, lp);
-        o.x[4 * t + w] = __builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, o.x[4 * t + w], true);
-    } else {
-        const i16x2 zero = {0, 0};
-        const i16x2 lp = __builtin_amdgcn_cvt_scalef32_pk_bf8_f32(zero, rem16<0>(v0, h), rem16<1>(v1, h), inv, false);
-        o.l[4 * t + w] = __builtin_bit_cast(int, lp);
-        o.x[4 * t + w] = __builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false);
-    }
-    extra(t, P, v0, v1);
+    if (RELU)
+        asm volatile(
+            "v_accvgpr_read_b32 %0, %3\n\t"
+            "v_accvgpr_read_b32 %1, %4\n\t"
+            "v_max_f32 %0, 0, %0\n\t"
+            "v_max_f32 %1, 0, %1\n\t"
+            "v_cvt_pk_f16_f32 %2, %0, %1"
+            : "=&v"(r.v0), "=&v"(r.v1), "=&v"(r.h)
+            : "a"(a0), "a"(a1));
+    else
+        asm volatile(
+            "v_accvgpr_read_b32 %0, %3\n\t"
+            "v_accvgpr_read_b32 %1, %4\n\t"
+            "v_cvt_pk_f16_f32 %2, %0, %1"
+            : "=&v"(r.v0), "=&v"(r.v1), "=&v"(r.h)
+            : "a"(a0), "a"(a1));
+}
+// W = 0: low word of the two 8-bit operand registers (their high word is written later by the W = 1 half-slice)
+template <int W>
+__device__ __forceinline__ void cv_half_b(SliceRegs &r, int &l, int &x) {
+#ifdef F_ABL_NOCONV
+    l = __float_as_int(r.v1);
+    x = __float_as_int(r.v0);
+    return;
+#endif
+    const float inv = 1.0f / (float)(1 << LO_SHIFT);  // the scaled conversion DIVIDES by its scale operand
+    if (W == 0)
+        asm volatile(
+            "v_cvt_pk_bf8_f32 %1, %2, %3\n\t"
+            "v_fma_mix_f32 %2, %4, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %3, %4, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_cvt_scalef32_pk_bf8_f32 %0, %2, %3, %5"
+            : "=&v"(l), "=&v"(x), "+v"(r.v0), "+v"(r.v1)
+            : "v"(r.h), "s"(inv));
+    else
+        asm volatile(
+            "v_cvt_pk_bf8_f32 %1, %2, %3 op_sel:[0,0,1]\n\t"
+            "v_fma_mix_f32 %2, %4, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mix_f32 %3, %4, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_cvt_scalef32_pk_bf8_f32 %0, %2, %3, %5 op_sel:[0,0,0,1]"
+            : "+v"(l), "+v"(x), "+v"(r.v0), "+v"(r.v1)
+            : "v"(r.h), "s"(inv));
 }
 template <int NT8>
 __device__ __forceinline__ void ops_from(const NextOps &o, f16x8 (&xh)[2 * NT8], i32x8 (&xl)[NT8 / 2], i32x8 (&xx)[NT8 / 2]) {
@@ -377,18 +403,18 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
     constexpr int BR = 4 + 4 * XT;  // records per full block
     constexpr int NREC = (NT / 2) * RPP;
     constexpr int SC_XL = 127 - LO_SHIFT, SC_ONE = 127;
-    // Conversion slices sit BETWEEN the two MFMAs of a main record (measured, tools/experiments/probe_filler2.hip: a
-    // 9-instruction slice costs +6 % there and +26 % after the pair, in front of the next record's fragment reads and
-    // counted wait).  A pair has NMAIN main records; slices of 2 values when that gives one slice per main record, else of
-    // 4 values with the overflow placed behind the first cross-term MFMAs.
+    // In-flight conversion: the 32 values a lane holds of the PREVIOUS pair are converted in 32 half-slices (16 when only the
+    // fp16 heads are needed) spread over ALL records of this pair, main and cross: the wave is issue-bound (about one
+    // issue slot per 4 cycles: a 32-cycle fp16 MFMA hides ~5 other instructions, a 51-cycle 8-bit one ~10), and whole
+    // slices behind the main records only (9 VALU + 2 fragment reads + wait + half a DMA piece per 2 MFMAs) overran that.
     constexpr int NMAIN = (NBLK - 1) * 4 + NCH_LAST;
-    constexpr int SPT = NMAIN >= 16 ? 8 : 4;  // slices per tile
-    constexpr int NSL = 2 * SPT;              // slices per pair
-    static_assert(CV == 0 || RPP >= NSL, "the next pair must have one record per slice of the previous pair");
+    constexpr int NH = CV == 4 ? 16 : 32;        // half-slices per pair
+    constexpr int HPR = (NH + RPP - 1) / RPP;    // per record
+    SliceRegs sr;
     // fragment reads run TWO records ahead of the MFMAs (one record = 64-100 matrix-pipe cycles, less than the LDS
     // latency under load)
 #ifndef F_PF
-#define F_PF 2  // records of lookahead
+#define F_PF 3  // records of lookahead (measured: 2 -> 21.4 ms, 3 -> 21.0, 4 -> 21.3, 5 -> 21.8)
 #endif
     Rec buf[F_PF + 1];
     static_for<F_PF>([&](auto ic) {
@@ -406,15 +432,16 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
 #define X0 c0
 #define X1 c1
 #endif
-    auto slice = [&](auto tc, auto sc) {  // slice sc (0..SPT-1) of tile tc: 16 / SPT values
-        constexpr int t = decltype(tc)::value, sl = decltype(sc)::value;
-        static_for<8 / SPT>([&](auto qc) {
-            constexpr int p = sl * (8 / SPT) + decltype(qc)::value;  // value pair 0..7 of the tile
-            if constexpr (CV == 1) cv_slice<true, p>(acc[t], t, *out, extra);
-            else if constexpr (CV == 2) cv_slice<false, p>(acc[t], t, *out, extra);
-            else if constexpr (CV == 4) cv_slice<true, p, true>(acc[t], t, *out, extra);  // relu, fp16 heads only
-            else if constexpr (CV == 3) extra(t, p, relu_asm(acc[t][2 * p]), relu_asm(acc[t][2 * p + 1]));
-        });
+    auto half_slice = [&](auto tpc, auto qc) {  // half-slice q of the pair tpp
+        constexpr int tpp = decltype(tpc)::value, q = decltype(qc)::value;
+        constexpr int sl = CV == 4 ? q : q / 2, half = CV == 4 ? 0 : q % 2;
+        constexpr int t = 2 * tpp + sl / 8, P = sl % 8;
+        if constexpr (half == 0) {
+            cv_half_a<CV != 2>(acc[t][2 * P], acc[t][2 * P + 1], sr);
+            out->h[8 * t + P] = sr.h;
+        } else {
+            cv_half_b<(P & 1)>(sr, out->l[4 * t + P / 2], out->x[4 * t + P / 2]);
+        }
     };
     static_for<NREC>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -448,12 +475,13 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
         } else {
             wait_rec<2 * (NREC - 1 - k)>(cur);
         }
-        // slice index carried by this record (-1: none): main record m -> slice m; overflow slices behind cross records
-        constexpr int sl_idx = is_main ? (j0 < NSL ? j0 : -1) : (j0 < NSL ? j0 : -1);
         auto run_slice = [&]() {
-            if constexpr (CV != 0 && tp > 0 && sl_idx >= 0) {
+            if constexpr (CV != 0 && tp > 0 && j0 * HPR < NH) {
                 __builtin_amdgcn_sched_barrier(0);
-                slice(std::integral_constant<int, 2 * (tp - 1) + sl_idx / SPT>{}, std::integral_constant<int, sl_idx % SPT>{});
+                static_for<HPR>([&](auto ic) {
+                    constexpr int q = j0 * HPR + decltype(ic)::value;
+                    if constexpr (q < NH) half_slice(std::integral_constant<int, tp - 1>{}, std::integral_constant<int, q>{});
+                });
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -499,10 +527,10 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
 #undef X0
 #undef X1
     if constexpr (CV != 0) {  // the last pair: exposed
-        static_for<2 * SPT>([&](auto sc) {
-            constexpr int sl = decltype(sc)::value;
-            slice(std::integral_constant<int, NT - 2 + sl / SPT>{}, std::integral_constant<int, sl % SPT>{});
-        });
+        // its first tile was last written by the second-last MFMA, 16 passes + the issue of the last one ago: the asm reads
+        // below are invisible to hipcc's hazard recognizer (the XDL write -> VALU read distance is 19 wait states)
+        asm volatile("s_nop 7" ::: "memory");
+        static_for<NH>([&](auto qc) { half_slice(std::integral_constant<int, NT / 2 - 1>{}, qc); });
     }
 }
 
@@ -604,7 +632,11 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         F_STAMP(13);
     }
     ops_from<8>(nx, xh, xl, xx);
+#ifdef F_TIMING  // per-record trace of fc_1
+    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx, NoExtra(), tbuf ? tbuf0 + 8192 + 128 * ((tbuf - tbuf0) / 32) : nullptr);
+#else
     layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx);
+#endif
     F_STAMP(14);
     ops_from<8>(nx, xh, xl, xx);
     // fc_2.  alpha_fc (fp32, VALU) is NOT folded into the conversion slices: its weights come from LDS, and a
@@ -633,11 +665,7 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings; rgb_fc (fp32,
     // VALU) rides on the finished tiles of the second phase
     f32x16 v[4];
-#ifdef F_TIMING
-    layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, scl[8], scl[9], nullptr, NoExtra(), tbuf ? tbuf + 8192 + 96 * ((tbuf - tbuf0) / 32) : nullptr);
-#else
     layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, scl[8], scl[9]);
-#endif
     F_STAMP(17);
     float s_rgb[3] = {0.f, 0.f, 0.f};
     {

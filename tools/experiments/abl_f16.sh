@@ -3,7 +3,7 @@
 #   tools/experiments/abl_f16.sh build      (here)   then on the GPU box:   tools/experiments/abl_f16.sh run
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
-  for v in "" NOGATHER NOCONV NOPE NOX NOM "NOX -DF_ABL_NOM" NOLDS NODMA NOBAR "NOGATHER -DF_ABL_NOCONV -DF_ABL_NOPE"; do
+  for v in ${ABL_SET:-"" NOGATHER NOCONV NOPE NOX NOM "NOX -DF_ABL_NOM" NOLDS NODMA NOBAR "NOGATHER -DF_ABL_NOCONV -DF_ABL_NOPE"}; do
     tag=$(echo "$v" | sed 's/ -DF_ABL_/_/g'); tag=${tag:-base}
     flags=""; [ -n "$v" ] && flags="-DF_ABL_$v"
     NB_EXTRA_FLAGS="$flags" NB_LIB_SUFFIX=_f16$tag python -m neuralbody_amd.build > /dev/null 2>&1 &

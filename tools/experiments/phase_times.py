@@ -10,11 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-NAMES = {1: "grid coords + wave box", 2: "gather L0", 3: "convert L0", 4: "fc_0 phase L0 (24 rec)", 5: "gather L1", 6: "convert L1",
-         7: "fc_0 phase L1 (32 rec)", 8: "gather L2", 9: "convert L2", 10: "fc_0 phase L2 (64 rec)", 11: "gather L3", 12: "convert L3",
-         13: "fc_0 phase L3 (64 rec) + tail conversion", 14: "fc_1 (128 rec) + tail conversion", 15: "fc_2 (128 rec) + alpha + tail",
-         16: "merged layer (128 rec) + tail", 17: "view_fc over g (64 rec)", 18: "xyz encodings + conversion",
-         19: "view_fc over PE (28 rec) + rgb", 20: "composite, weight store, loop"}
+NAMES = {1: "grid coords + wave box", 2: "issue the tile fetches of 4 levels", 3: "level 0: tile, blend, convert", 4: "level 1",
+         5: "level 2", 6: "level 3", 13: "fc_0 (184 rec) + tail conversion", 14: "fc_1 (128 rec) + tail conversion",
+         15: "fc_2 (128 rec) + alpha + tail", 16: "merged layer (64 rec) + tail", 17: "view_fc over g (64 rec)",
+         18: "xyz encodings + conversion", 19: "view_fc over PE (28 rec) + rgb", 20: "composite, weight store, loop"}
+STAMPS = sorted(NAMES)
 
 dev = torch.device("cuda:0")
 sd, body, net, rend, bd, n = bench.build_scene(dev, 512, 512, 64, "f16f8")
@@ -26,18 +26,19 @@ with torch.no_grad():
         out = net.render_rays(bd["ray_o"][0], bd["ray_d"][0], bd["near"][0], bd["far"][0], vols, sp, 64, want_raw=True, ray_order=order)
 torch.cuda.synchronize()
 t = out["raw"].view(torch.int32).reshape(-1)[:64 * 32].cpu().numpy().astype(np.int64).reshape(64, 32)[:, :21]
+t = t[:, [0] + STAMPS]
 d = np.diff(t, axis=1) & 0xffffffff
 d = d[2:-1]  # skip the first steps (cold caches) and the last
 print("| phase | mean cycles | share |\n|---|---|---|")
 tot = d.sum(1).mean()
-for i in range(1, 21):
-    print("| %s | %.0f | %.1f %% |" % (NAMES[i], d[:, i - 1].mean(), 100 * d[:, i - 1].mean() / tot))
+for i, st in enumerate(STAMPS):
+    print("| %s | %.0f | %.1f %% |" % (NAMES[st], d[:, i].mean(), 100 * d[:, i].mean() / tot))
 print("| one depth step | %.0f | |" % tot)
 
 # per-record trace of fc_1 (F_TIMING): cycles between consecutive records, averaged over the steps
 tr = out["raw"].view(torch.int32).reshape(-1)[8192:8192 + 64 * 128].cpu().numpy().astype(np.int64).reshape(64, 128)
 dr = (np.diff(tr, axis=1) & 0xffffffff)[2:-1]
 m = dr.mean(0)
-print("view_fc-over-g record-to-record cycles (records 1..63; a pair = 32 records: 4 x [4 main, 4 cross]; page turns every 12):")
-for i in range(0, 63, 16):
+print("fc_1 record-to-record cycles (records 1..127; a pair = 32 records: 16 main, then 16 cross; page turns every 12 stream records):")
+for i in range(0, 127, 16):
     print(" ".join("%4d" % v for v in m[i:i + 16]))

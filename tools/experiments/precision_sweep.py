@@ -15,6 +15,11 @@ Schemes (per layer):
     f16c8    fp16 main product + the two cross terms with BOTH operands rounded to fp8 e4m3 after an exact 2^k block
              scale (what a scaled f8f6f4 MFMA would compute)
 
+    f16c6    fp16 main product + the two cross terms in SIX bits on the scaled f8f6f4 MFMA (which then runs at the rate of
+             ONE fp16 K=16 MFMA per K=64, tools/experiments/probe_mxrate.hip): weights fp6 e2m3 with a pack-time E8M0 scale
+             per (row, 32 K), activations bf6 e3m2 with a run-time E8M0 scale per (sample, 32 K) from the block's maximum;
+             the remainder block reuses the head block's scale - 11
+
 Run:  python tools/experiments/precision_sweep.py [--wide]      (CPU, ~1 min)
 The same table measured on the HIP kernels is produced by tools/experiments/precision_gpu.py.
 """
@@ -73,6 +78,49 @@ def _bf8_static(x, log2_scale):
     return q / sc
 
 
+def _minifloat(x, mbits, emin, vmax):
+    """round-to-nearest-even onto a sign/exponent/mantissa grid with subnormals below 2^emin, saturating at vmax"""
+    a = x.abs()
+    e = torch.floor(torch.log2(a.clamp_min(1e-38))).clamp_min(emin)
+    step = torch.exp2(e - mbits)
+    q = (torch.round(a / step) * step).clamp_max(vmax)
+    return torch.sign(x) * q
+
+
+def _blocks(x, dim):
+    xm = x.movedim(dim, -1)
+    sh = xm.shape
+    pad = (-sh[-1]) % 32
+    if pad:
+        xm = torch.nn.functional.pad(xm, (0, pad))
+    return xm.reshape(*xm.shape[:-1], -1, 32), sh, xm.shape
+
+
+def _unblocks(q, dim, sh, shp):
+    return q.reshape(*shp)[..., :sh[-1]].movedim(-1, dim)
+
+
+def _fp6_weights(W):
+    """fp6 e2m3 (max 7.5), pack-time scale per (row, 32 K): the smallest power of two with max|block| / scale <= 7.5"""
+    blk, sh, shp = _blocks(W, 1)
+    amax = blk.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 7.5)))
+    return _unblocks(_minifloat(blk / scale, 3, 0, 7.5) * scale, 1, sh, shp)
+
+
+def _bf6_acts(Xh, Xl):
+    """bf6 e3m2 (max 28) of the head and the remainder; run-time scale per (sample, 32 K) = 2^(exponent of the head
+    block's maximum - 3) (block max lands in [8, 16)); the remainder block uses that scale * 2^-11"""
+    bh, sh, shp = _blocks(Xh, 0)
+    bl, _, _ = _blocks(Xl, 0)
+    amax = bh.abs().amax(-1, keepdim=True).clamp_min(2.0 ** -100)
+    scale = torch.exp2(torch.floor(torch.log2(amax)) - 3.0)
+    qh = _minifloat(bh / scale, 2, -2, 28.0) * scale
+    sl = scale * 2.0 ** -11
+    ql = _minifloat(bl / sl, 2, -2, 28.0) * sl
+    return _unblocks(qh, 0, sh, shp), _unblocks(ql, 0, sh, shp)
+
+
 def _w_scale(W):
     """per-layer static weight scale chosen at pack time: the largest power of two keeping max|W| <= 448"""
     m = float(W.abs().max())
@@ -87,7 +135,7 @@ def mm(W, X, scheme):
         return _bf16(W) @ _bf16(X)
     if scheme == "f16x1":
         return _f16(W) @ _f16(X)
-    if scheme in ("bf16x3", "f16x3", "f16x2w", "f16x2x", "f16c8", "f16c8s", "f16c8b"):
+    if scheme in ("bf16x3", "f16x3", "f16x2w", "f16x2x", "f16c8", "f16c8s", "f16c8b", "f16c6", "f16c6w", "f16c6x"):
         r = _bf16 if scheme == "bf16x3" else _f16
         Wh, Xh = r(W), r(X)
         Wl, Xl = r(W - Wh), r(X - Xh)
@@ -99,6 +147,14 @@ def mm(W, X, scheme):
             return Wh @ Xh + _f8_scaled(Wh, 1) @ _f8_scaled(Xl, 0) + _f8_scaled(Wl, 1) @ _f8_scaled(Xh, 0)
         if scheme == "f16c8s":  # static scales: activations 2^-2 (hi) / 2^8 (lo), weights per layer from max|W|
             return Wh @ Xh + _f8_static(Wh, _w_scale(Wh)) @ _f8_static(Xl, 8) + _f8_static(Wl, _w_scale(Wl)) @ _f8_static(Xh, -2)
+        if scheme == "f16c6":
+            q_xh, q_xl = _bf6_acts(Xh, Xl)
+            return Wh @ Xh + _fp6_weights(Wh) @ q_xl + _fp6_weights(Wl) @ q_xh
+        if scheme == "f16c6w":  # only the weights in six bits (activations bf8 as shipped)
+            return Wh @ Xh + _fp6_weights(Wh) @ _bf8_static(Xl, 12) + _fp6_weights(Wl) @ _bf8_static(Xh, 0)
+        if scheme == "f16c6x":  # only the activations in six bits
+            q_xh, q_xl = _bf6_acts(Xh, Xl)
+            return Wh @ Xh + _f8_static(Wh, _w_scale(Wh)) @ q_xl + _f8_static(Wl, _w_scale(Wl)) @ q_xh
         if scheme == "f16c8b":  # activations in bf8 e5m2 (no range worries), weights in fp8 e4m3 with pack-time scales
             return Wh @ Xh + _f8_static(Wh, _w_scale(Wh)) @ _bf8_static(Xl, 12) + _f8_static(Wl, _w_scale(Wl)) @ _bf8_static(Xh, 0)
         return Wh @ Xh + Wh @ Xl + Wl @ Xh
@@ -213,6 +269,11 @@ def main():
         mix = {l: "f16c8b" for l in LAYERS}
         mix["merged"] = "f16x1"
         report("f16c8b, merged f16x1", mix)
+        for sc in ("f16c6", "f16c6w", "f16c6x"):
+            report("all " + sc, {l: sc for l in LAYERS})
+            mix = {l: sc for l in LAYERS}
+            mix["merged"] = "f16x1"
+            report(sc + ", merged f16x1", mix)
         return
     for s in ("f32", "bf16x3", "f16x3", "f16c8", "f16x2w", "f16x2x", "f16x1", "bf16x1"):
         report("all " + s, {l: s for l in LAYERS})
