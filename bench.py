@@ -47,9 +47,13 @@ PRECISION_INFO = {
     "bf16x3": ("bf16", "nb_march16_kernel", 1944 * 32768 / 32.0, 2500.0),
     # M-split organisation of the same arithmetic: 4 waves x 984 MFMAs per 64 samples (encoding K padded to 128)
     "bf16x3s": ("bf16", "nb_march16s_kernel", 4 * 984 * 32768 / 64.0, 2500.0),
-    # fp16 main product (648 K=16 MFMAs per 32 samples) + 336 K=64 scaled 8-bit MFMAs for the two cross terms; the 8-bit
-    # flops are counted at half weight (their dense peak is 2x the fp16 peak), i.e. in fp16-equivalent matrix-pipe time
-    "f16f8": ("f16+f8", "nb_march_f16_kernel", (648 * 32768 + 336 * 131072 / 2.0) / 32.0, 2500.0),
+    # fp16 main product (648 K=16 MFMAs per 32 samples) + 272 K=64 scaled 8-bit MFMAs for the two cross terms (the merged
+    # feature_fc.latent_fc layer runs without them); the 8-bit flops are counted at half weight (their dense peak is 2x the
+    # fp16 peak), i.e. in fp16-equivalent matrix-pipe time
+    "f16f8": ("f16+f8", "nb_march_f16_kernel", (648 * 32768 + 272 * 131072 / 2.0) / 32.0, 2500.0),
+    # the same with the cross terms in 6 bits: a K=64 fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA
+    # (profiles/r02_probe_mxrate.log), so it is counted as one (a quarter of its flops)
+    "f16f6": ("f16+f6", "nb_march_f6_kernel", (648 + 272) * 32768 / 32.0, 2500.0),
 }
 
 
@@ -262,7 +266,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--precision", default=None, choices=[None, "f32", "bf16x3", "bf16x3s", "f16f8"])
+    ap.add_argument("--precision", default=None, choices=[None, "auto", "f32", "bf16x3", "bf16x3s", "f16f8", "f16f6"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one view per GPU per step (views shard with no collective but the tile all-gather); "
                          "strong: one view per step, its rays split over the GPUs")
@@ -348,15 +352,16 @@ def main():
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_march_f16_traffic.json" if net.precision == "f16f8" else "r01_march16_traffic.json")
-    if net.precision in ("bf16x3", "f16f8") and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
+    tpath = os.path.join(ROOT, "profiles", "r02_march_%s_traffic.json" % {"f16f8": "f16", "f16f6": "f6"}[net.march_precision()]
+                         if net.march_precision() in ("f16f8", "f16f6") else "r01_march16_traffic.json")
+    if net.march_precision() in ("bf16x3", "f16f8", "f16f6") and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]
     views_per_step = world if args.scaling == "weak" else 1
     rays_per_launch = n_rays if args.scaling == "weak" else (n_rays + world - 1) // world
     total_rays = n_rays * views_per_step * args.steps
     samples_per_s = total_rays * S / elapsed
-    dtype, kernel_name, exec_flop, peak = PRECISION_INFO[net.precision]
+    dtype, kernel_name, exec_flop, peak = PRECISION_INFO[net.march_precision()]
     achieved_tflops = FLOP_PER_SAMPLE * rays_per_launch * S / (march_ms * 1e-3) / 1e12
     result = {
         "metric": "ray_samples_per_sec", "value": samples_per_s, "unit": "ray-samples/s", "n_gpus": world,
@@ -375,7 +380,10 @@ def main():
                                              "v_mfma_f32_32x32x16_bf16, fp32 accumulate (M-split workgroups)",
                                   "f16f8": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
                                            "terms in 8 bits (fp8 e4m3 weights, bf8 e5m2 activations) on "
-                                           "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate"}[net.precision],
+                                           "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate",
+                                  "f16f6": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
+                                           "terms in 6 bits (fp6 e2m3 weights, bf6 e3m2 activations, E8M0 scales per 32 K) on "
+                                           "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate"}[net.march_precision()],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
@@ -387,7 +395,7 @@ def main():
                              "the kernel issues %.0f MFMA flop/sample (merged feature_fc.latent_fc layer%s), so "
                              "executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~219 MB/launch "
                              "(<0.1%% of the launch time at 8 TB/s)"
-                             % (rays_per_launch * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.precision.startswith("bf16") else "")},
+                             % (rays_per_launch * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.march_precision().startswith("bf16") else "")},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         err, n_chk = parity_linf(sd, net, rend, poses[1], S)

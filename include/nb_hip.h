@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 11
+#define NB_ABI_VERSION 12
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -41,6 +41,11 @@ extern "C" {
                              fp16 head/remainder split in 8 bits (weights fp8 e4m3, activations bf8 e5m2) on
                              v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate: ~2^-15 relative error per term at 1.8
                              instead of 3 matrix-pipe units */
+#define NB_PREC_F16F6 4   /* nb_march only: the same split with the cross terms in 6 bits (weights fp6 e2m3 with a pack-time
+                             E8M0 scale per row and 32 K, activations bf6 e3m2 with a run-time E8M0 scale per sample and
+                             32 K): the K=64 scaled MFMA then issues at the rate of one K=16 fp16 MFMA (8-bit: 1.9x).
+                             Weight blocks whose elements span more than ~2^5 lose their small elements: see
+                             nb_mlp_six_bit_loss() */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */
@@ -85,6 +90,12 @@ typedef struct nb_scene {
  * ------------------------------------------------------------------------------- */
 int64_t nb_mlp_pack_size(void);        /* floats in the packed blob */
 int64_t nb_mlp_latent_bias_size(void); /* floats in the per-frame bias (256) */
+/* Float offset inside the packed blob of 10 int32 counters written with the NB_PACK_F16F6 section: for each of the five
+ * layers (fc_0, fc_1, fc_2, merged, view_fc) {small, nonzero} = how many non-zero weights lie below 1/8 of the maximum of
+ * their (row, 32 K) block — where fp6 e2m3 keeps fewer than 3 significant bits — and how many are non-zero at all.
+ * small / nonzero is ~0.2 for normally distributed weights; a caller that cannot rule out weight blocks with a wide
+ * dynamic range (> ~2^5) uses it to fall back to NB_PREC_F16F8 (the Python Network does, precision "auto"). */
+int64_t nb_mlp_six_bit_stats_offset(void);
 
 typedef struct nb_mlp_params { /* all dev, row-major [out,in] / [out] */
     const float *fc0_w, *fc0_b;         /* [256,352] */
@@ -106,7 +117,8 @@ int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream);
 #define NB_PACK_BF16X3 2
 #define NB_PACK_BF16X3S 4
 #define NB_PACK_F16F8 8
-#define NB_PACK_ALL 15
+#define NB_PACK_F16F6 16
+#define NB_PACK_ALL 31
 int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, void *stream);
 /* latent_row: dev pointer to latent.weight[latent_index] (128 floats);
  * out: dev, nb_mlp_latent_bias_size() floats. */

@@ -9,9 +9,9 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 11
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2, "f16f8": 3}
-PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "bf16x3s": 4, "f16f8": 8}
+ABI_VERSION = 12
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2, "f16f8": 3, "f16f6": 4}
+PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "bf16x3s": 4, "f16f8": 8, "f16f6": 16}
 
 
 class NbScene(C.Structure):
@@ -53,6 +53,7 @@ SIGNATURES = {
     "nb_device_count": (C.c_int, []),
     "nb_mlp_pack_size": (_I64, []),
     "nb_mlp_latent_bias_size": (_I64, []),
+    "nb_mlp_six_bit_stats_offset": (_I64, []),
     "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
     "nb_mlp_pack_sections": (C.c_int, [C.POINTER(NbMlpParams), _P, C.c_int, _P]),
     "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),

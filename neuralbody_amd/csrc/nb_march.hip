@@ -415,8 +415,11 @@ __global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__
 
 extern "C" {
 
-int64_t nb_mlp_pack_size(void) { return PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats() + nbm::f16_stream_floats(); }
+static long long f16_stream_off() { return PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(); }
+static long long f6_stream_off() { return f16_stream_off() + nbm::f16_stream_floats(); }
+int64_t nb_mlp_pack_size(void) { return f6_stream_off() + nbm::f6_stream_floats(); }
 int64_t nb_mlp_latent_bias_size(void) { return 256; }
+int64_t nb_mlp_six_bit_stats_offset(void) { return f6_stream_off() + nbm::f6_stream_floats() - 16; }
 
 static int check_params(const nb_mlp_params *p) {
     NB_REQUIRE(p != nullptr, "nb_mlp_params is NULL");
@@ -442,7 +445,9 @@ int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, vo
     if (sections & NB_PACK_BF16X3S)
         if (int rc = nbm::pack_msplit_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream)) return rc;
     if (sections & NB_PACK_F16F8)
-        if (int rc = nbm::pack_f16_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(), (hipStream_t)stream)) return rc;
+        if (int rc = nbm::pack_f16_stream(p, packed, f16_stream_off(), (hipStream_t)stream)) return rc;
+    if (sections & NB_PACK_F16F6)
+        if (int rc = nbm::pack_f6_stream(p, packed, f6_stream_off(), (hipStream_t)stream)) return rc;
     return NB_OK;
 }
 
@@ -501,10 +506,11 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, ray_order,
                     white_bkgd,
                     rgb_map, disp_map, acc_map, weights, depth_map, raw);
-    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_BF16X3S || precision == NB_PREC_F16F8,
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_BF16X3S || precision == NB_PREC_F16F8 ||
+                   precision == NB_PREC_F16F6,
                "nb_march: precision %d", precision);
-    if (precision == NB_PREC_F16F8)
-        return nbm::launch_march_f16(a, PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(), (hipStream_t)stream);
+    if (precision == NB_PREC_F16F8) return nbm::launch_march_f16(a, f16_stream_off(), (hipStream_t)stream);
+    if (precision == NB_PREC_F16F6) return nbm::launch_march_f6(a, f6_stream_off(), (hipStream_t)stream);
     // the M-split kernel has no sample culling: culled marches take the ring kernel (same arithmetic)
     if (precision == NB_PREC_BF16X3S && !cull)
         return nbm::launch_march_msplit(a, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream);

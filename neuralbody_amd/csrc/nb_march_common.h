@@ -671,5 +671,9 @@ int launch_march_msplit(MarchArgs a, long long stream_off, hipStream_t st);
 long long f16_stream_floats();
 int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
 int launch_march_f16(const MarchArgs &a, long long stream_off, hipStream_t st);
+// fp16 + scaled-6-bit march (nb_march_f6.hip = nb_march_f16.hip with -DF_SIX)
+long long f6_stream_floats();
+int pack_f6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
+int launch_march_f6(const MarchArgs &a, long long stream_off, hipStream_t st);
 
 }  // namespace nbm

@@ -17,6 +17,12 @@
 // that row/column and K half.
 //
 // Measured RGB error against the reference renderer over all fixtures: profiles/r02_precision_sweep.md.
+//
+// -DF_SIX=1 (nb_march_f6.hip compiles this file a second time) builds the "f16f6" variant: the cross terms in SIX bits —
+// weights fp6 e2m3 with a pack-time E8M0 scale per (row, 32 K), activations bf6 e3m2 with a run-time E8M0 scale per
+// (sample, 32 K) taken from the exponent of the block's largest |value|.  With both operands in six bits the K=64 scaled
+// MFMA issues at the rate of ONE K=16 fp16 MFMA (8-bit operands: 1.9x; profiles/r02_probe_mxrate.log), and one
+// v_cvt_scalef32_pk32_bf6_f16 / v_cvt_scalef32_2xpk16_bf6_f32 converts 32 values (profiles/r02_probe_cvt6.log).
 #include <type_traits>
 #include <utility>
 
@@ -24,11 +30,22 @@
 
 using namespace nbm;
 
+#ifndef F_SIX
+#define F_SIX 0
+#endif
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef int i32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
+constexpr bool SIX = F_SIX != 0;
+// one K=64 block of an 8-bit / 6-bit activation operand
+using XB = std::conditional_t<SIX, i32x6, i32x8>;
 
 namespace nbm {
 
@@ -211,6 +228,24 @@ __device__ __forceinline__ f32x16 mfma_cross(const Rec &a, const i32x8 b, const 
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, b, c, 0, 1, 0, scale_a, 0, scale_b);
 }
 
+// six-bit cross term: A fp6 e2m3 (cbsz 2) in the first 24 bytes of the lane's record share, its E8M0 scale in byte 24;
+// B bf6 e3m2 (blgp 3), E8M0 scale = byte BSEL of `sb` (one register carries the scales of four K blocks)
+template <int BSEL>
+__device__ __forceinline__ f32x16 mfma_cross6(const Rec &a, const i32x6 b, const f32x16 c, int sb) {
+#ifdef F_ABL_NOX
+    return c;
+#endif
+    // the full 8-register record share (only the first six are read): the pair of 4-register fragment reads then forms
+    // the operand in place, and the scale is register 6 of the same tuple
+    i32x8 av = {a.p0.x, a.p0.y, a.p0.z, a.p0.w, a.p1.x, a.p1.y, a.p1.z, a.p1.w};
+    asm volatile("" : "+v"(av));  // an 8-register tuple the two reads coalesce into (a 6-of-8 use costs two copies per record)
+    const i32x8 bv = {b[0], b[1], b[2], b[3], b[4], b[5], 0, 0};
+#ifdef F_NO_OPSEL
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2, 3, 0, av[6], 0, sb >> (8 * BSEL));
+#endif
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2, 3, 0, av[6], BSEL, sb);
+}
+
 __device__ __forceinline__ f32x16 f_bias_tile(const float *bp, int t, int hi) {
     const f32x4 *b4 = reinterpret_cast<const f32x4 *>(bp + (t * 2 + hi) * 16);
     const f32x4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
@@ -304,6 +339,84 @@ __device__ __forceinline__ void make_operands(Get get, f16x8 (&xh)[2 * NG], i32x
     for (int b = 0; b < (NG + 1) / 2; ++b) asm volatile("" : "+v"(xl[b]), "+v"(xx[b]));
 }
 
+// Six-bit variant.  One K block = 32 consecutive values of a lane: fp16 heads (4 chunks), bf6 of the heads, bf6 of the
+// remainders, and the block's E8M0 exponent t: the head block is stored / 2^(t - 127) with t = exponent(max |v|) - 3 (the
+// largest value lands in [8, 16) of bf6's +-28), the remainder block / 2^(t - 11 - 127) (|remainder| <= 2^-11 |value|).
+// Element order inside the bf6 registers: heads natural (v_cvt_scalef32_pk32_bf6_f16), remainders interleaved
+// [v0, v16, v1, v17, ...] (v_cvt_scalef32_2xpk16_bf6_f32) — the weight records of the two cross terms are packed to match.
+__device__ __forceinline__ int block_exponent(float m) {
+    return max(__float_as_int(m) >> 23, 15) - 3;  // m >= 0; t - 11 >= 1 stays a valid E8M0 / float exponent
+}
+__device__ __forceinline__ void cvt_block6(const u32x16 hv, const f32x16 ra, const f32x16 rb, int t, i32x6 &x, i32x6 &l) {
+    const float sf = __int_as_float(t << 23), sfl = __int_as_float((t - 11) << 23);  // the conversions DIVIDE by the scale
+    // Inline asm with EARLY-CLOBBER results, not the builtins: these are multi-pass instructions that write their six result
+    // registers while still reading the scale operand, and hipcc (ROCm 7.2) is free to allocate the result over the scale
+    // register — every element converted after the first pass then sees a clobbered scale and saturates
+    // (tools/experiments/probe_cross6.hip: `v_cvt_scalef32_2xpk16_bf6_f32 v[6:11], v[32:47], v[48:63], v7`).
+    asm volatile("v_cvt_scalef32_pk32_bf6_f16 %0, %1, %2" : "=&v"(x) : "v"(hv), "v"(sf));
+    asm volatile("v_cvt_scalef32_2xpk16_bf6_f32 %0, %1, %2, %3" : "=&v"(l) : "v"(ra), "v"(rb), "v"(sfl));
+}
+// NG groups of 16 values -> 2 NG chunks, ceil(NG / 2) blocks and their exponents packed four to a register (byte b % 4 of
+// sh[b / 4]: head block, of sl[b / 4]: remainder block)
+template <int NG, bool RELU, class Get>
+__device__ __forceinline__ void make_operands6(Get get, f16x8 (&xh)[2 * NG], i32x6 (&xl)[(NG + 1) / 2], i32x6 (&xx)[(NG + 1) / 2],
+                                               int (&eb)[(NG + 1) / 2]) {
+    constexpr int NB = (NG + 1) / 2;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        u32x16 hv;
+        f32x16 ra, rb;
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {  // value pair i of the block: group 2 b (i < 8) or 2 b + 1
+            const int g = 2 * b + (i >> 3);
+            float v0 = 0.f, v1 = 0.f;
+            if (g < NG) {
+                v0 = get(16 * g + 2 * (i & 7));
+                v1 = get(16 * g + 2 * (i & 7) + 1);
+                if (RELU) {
+                    v0 = relu1(v0);
+                    v1 = relu1(v1);
+                }
+            }
+            const unsigned h = cvt_pk_f16(v0, v1);
+            hv[i] = h;
+            m = fmaxf(m, fmaxf(fabsf(v0), fabsf(v1)));
+            const float r0 = rem16<0>(v0, h), r1 = rem16<1>(v1, h);
+            if (i < 8) {
+                ra[2 * i] = r0;
+                ra[2 * i + 1] = r1;
+            } else {
+                rb[2 * (i - 8)] = r0;
+                rb[2 * (i - 8) + 1] = r1;
+            }
+        }
+        eb[b] = block_exponent(m);
+        cvt_block6(hv, ra, rb, eb[b], xx[b], xl[b]);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (4 * b + c < 2 * NG) xh[4 * b + c] = __builtin_bit_cast(f16x8, u32x4{hv[4 * c], hv[4 * c + 1], hv[4 * c + 2], hv[4 * c + 3]});
+    }
+#pragma unroll
+    for (int c = 0; c < 2 * NG; ++c) asm volatile("" : "+v"(xh[c]));
+#pragma unroll
+    for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(xl[b]), "+v"(xx[b]));
+}
+// block exponents four to a register: byte b % 4 of sh[b / 4] for the head block, of sl[b / 4] (= - 11) for the remainder
+// block; unused bytes hold 12 so that the bytewise subtraction never borrows
+template <int NB>
+__device__ __forceinline__ void pack_exps(const int (&eb)[NB], int (&sh)[(NB + 3) / 4], int (&sl)[(NB + 3) / 4]) {
+#pragma unroll
+    for (int i = 0; i < (NB + 3) / 4; ++i) {
+        int w = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w |= (4 * i + k < NB ? eb[4 * i + k < NB ? 4 * i + k : 0] : 12) << (8 * k);
+        sh[i] = w;
+        sl[i] = w - 0x0b0b0b0b;
+    }
+}
+
 // ---------------------------------------------------------------- one layer phase
 // A finished accumulator tile pair is converted into the next layer's operands IN THE SHADOW of the following pair's
 // MFMAs: 8 slices of 4 values (relu, fp16 head, remainder, two 8-bit packs: ~14 VALU) per tile, one slice behind each of
@@ -313,10 +426,16 @@ __device__ __forceinline__ void make_operands(Get get, f16x8 (&xh)[2 * NG], i32x
 struct NoExtra {
     __device__ __forceinline__ void operator()(int, int, float, float) const {}
 };
-struct NextOps {  // operands of the next layer being assembled word by word
+struct NextOps8 {  // operands of the next layer being assembled word by word
     unsigned h[64];
     int l[32], x[32];
 };
+struct NextOps6 {  // ... block by block: heads of pair b = K block b, its two bf6 forms, the exponents (byte b)
+    u32x16 hv[4];
+    i32x6 l6[4], x6[4];
+    int sh, sl;
+};
+using NextOps = std::conditional_t<SIX, NextOps6, NextOps8>;
 // Conversion of values 2 P, 2 P + 1 (P = 0..7) of a finished accumulator tile into their share of tile t's operand words,
 // as TWO hand-written half-slices.  Each is one asm block: between separate asm statements and conversion builtins hipcc
 // inserts a conservative `s_nop 0` per statement (it cannot see what the asm wrote), ~1000 issue slots per depth step.
@@ -378,8 +497,54 @@ __device__ __forceinline__ void cv_half_b(SliceRegs &r, int &l, int &x) {
             : "+v"(l), "+v"(x), "+v"(r.v0), "+v"(r.v1)
             : "v"(r.h), "s"(inv));
 }
+// six-bit variant of the second half-slice: fp16 head pair, running block maximum, the two remainders (4 instructions)
+__device__ __forceinline__ void cv6_half_b(SliceRegs &r, float &m, float &r0, float &r1) {
+#ifdef F_ABL_NOCONV
+    r0 = r.v0;
+    r1 = r.v1;
+    return;
+#endif
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %4, %5\n\t"
+        "v_max3_f32 %1, %1, |%4|, |%5|\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %3, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(r.h), "+v"(m), "=&v"(r0), "=&v"(r1)
+        : "v"(r.v0), "v"(r.v1));
+}
+// first half-slice without the head conversion (it moves to the second half in the six-bit variant)
+template <bool RELU>
+__device__ __forceinline__ void cv6_half_a(float a0, float a1, SliceRegs &r) {
+    if (RELU)
+        asm volatile(
+            "v_accvgpr_read_b32 %0, %2\n\t"
+            "v_accvgpr_read_b32 %1, %3\n\t"
+            "v_max_f32 %0, 0, %0\n\t"
+            "v_max_f32 %1, 0, %1"
+            : "=&v"(r.v0), "=&v"(r.v1)
+            : "a"(a0), "a"(a1));
+    else
+        asm volatile("v_accvgpr_read_b32 %0, %2\n\tv_accvgpr_read_b32 %1, %3" : "=&v"(r.v0), "=&v"(r.v1) : "a"(a0), "a"(a1));
+}
+
 template <int NT8>
-__device__ __forceinline__ void ops_from(const NextOps &o, f16x8 (&xh)[2 * NT8], i32x8 (&xl)[NT8 / 2], i32x8 (&xx)[NT8 / 2]) {
+__device__ __forceinline__ void ops_from(const NextOps6 &o, f16x8 (&xh)[2 * NT8], i32x6 (&xl)[NT8 / 2], i32x6 (&xx)[NT8 / 2], int (&sh)[1],
+                                         int (&sl)[1]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int c = 0; c < 2 * NT8; ++c)
+        xh[c] = __builtin_bit_cast(f16x8, u32x4{o.hv[c / 4][4 * (c % 4)], o.hv[c / 4][4 * (c % 4) + 1], o.hv[c / 4][4 * (c % 4) + 2],
+                                                o.hv[c / 4][4 * (c % 4) + 3]});
+#pragma unroll
+    for (int b = 0; b < NT8 / 2; ++b) {
+        xl[b] = o.l6[b];
+        xx[b] = o.x6[b];
+    }
+    sh[0] = o.sh;
+    sl[0] = o.sl;
+}
+template <int NT8>
+__device__ __forceinline__ void ops_from(const NextOps8 &o, f16x8 (&xh)[2 * NT8], i32x8 (&xl)[NT8 / 2], i32x8 (&xx)[NT8 / 2], int (&)[1], int (&)[1]) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int c = 0; c < 2 * NT8; ++c) xh[c] = __builtin_bit_cast(f16x8, u32x4{o.h[4 * c], o.h[4 * c + 1], o.h[4 * c + 2], o.h[4 * c + 3]});
@@ -395,9 +560,9 @@ __device__ __forceinline__ void ops_from(const NextOps &o, f16x8 (&xh)[2 * NT8],
 // CV: 0 = leave the result in acc; 1 / 2 = convert finished tiles into `out` with / without relu (in-flight, see above);
 // 3 = no conversion, but `extra` still sees the relu'd values of every finished tile (rgb_fc over view_fc's output).
 template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT, int CV = 0, class Extra = NoExtra, int XT = 1>
-__device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f32x16 (&acc)[NT], const f16x8 *xh, const i32x8 *xl,
-                                            const i32x8 *xx, int sc_h, int sc_l, NextOps *out = nullptr, Extra &&extra = Extra(),
-                                            unsigned *trace = nullptr) {
+__device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f32x16 (&acc)[NT], const f16x8 *xh, const XB *xl,
+                                            const XB *xx, const int *xsh, const int *xsl, int sc_h, int sc_l, NextOps *out = nullptr,
+                                            Extra &&extra = Extra(), unsigned *trace = nullptr) {
     const int hi = rg.lane >> 5;
     constexpr int RPP = recs_per_pair(NBLK, NCH_LAST, XT);
     constexpr int BR = 4 + 4 * XT;  // records per full block
@@ -422,26 +587,48 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
         if constexpr (i < NREC) load_rec<REC0 + i>(rg, buf[i]);
     });
     f32x16 c0, c1;
-    // -DF_SPLIT_X: the 8-bit cross terms accumulate in their own tiles (added at the end of the pair) so that no
-    // accumulator chain alternates between the 8-pass fp16 and the 16-pass 8-bit MFMA
-#ifdef F_SPLIT_X
-    f32x16 cx0, cx1;
-#define X0 cx0
-#define X1 cx1
-#else
-#define X0 c0
-#define X1 c1
+#if F_SIX
+    f32x16 ra, rb;  // remainders of the pair being converted (even / odd tile)
+    float mx = 0.f;  // its running max |value|
 #endif
     auto half_slice = [&](auto tpc, auto qc) {  // half-slice q of the pair tpp
         constexpr int tpp = decltype(tpc)::value, q = decltype(qc)::value;
         constexpr int sl = CV == 4 ? q : q / 2, half = CV == 4 ? 0 : q % 2;
-        constexpr int t = 2 * tpp + sl / 8, P = sl % 8;
+        constexpr int tt = sl / 8, t = 2 * tpp + tt, P = sl % 8;
+#if F_SIX
+        if constexpr (CV == 4) {  // heads only
+            cv_half_a<true>(acc[t][2 * P], acc[t][2 * P + 1], sr);
+            out->hv[tpp][8 * tt + P] = sr.h;
+        } else if constexpr (half == 0) {
+            cv6_half_a<CV != 2>(acc[t][2 * P], acc[t][2 * P + 1], sr);
+        } else {
+            float r0, r1;
+            cv6_half_b(sr, mx, r0, r1);
+            out->hv[tpp][8 * tt + P] = sr.h;
+            if constexpr (tt == 0) {
+                ra[2 * P] = r0;
+                ra[2 * P + 1] = r1;
+            } else {
+                rb[2 * P] = r0;
+                rb[2 * P + 1] = r1;
+            }
+            if constexpr (q == NH - 1) {  // the pair = K block tpp of the next layer is complete: its two bf6 forms
+                const int te = block_exponent(mx);
+                cvt_block6(out->hv[tpp], ra, rb, te, out->x6[tpp], out->l6[tpp]);
+                asm volatile("" : "+v"(out->x6[tpp]), "+v"(out->l6[tpp]));  // keep the (pure) conversions here
+                out->sh = tpp == 0 ? te : (out->sh | (te << (8 * tpp)));
+                if constexpr (tpp == NT / 2 - 1) out->sl = out->sh - 0x0b0b0b0b;  // every byte >= 12: no borrow
+                mx = 0.f;
+            }
+        }
+#else
         if constexpr (half == 0) {
             cv_half_a<CV != 2>(acc[t][2 * P], acc[t][2 * P + 1], sr);
             out->h[8 * t + P] = sr.h;
         } else {
             cv_half_b<(P & 1)>(sr, out->l[4 * t + P / 2], out->x[4 * t + P / 2]);
         }
+#endif
     };
     static_for<NREC>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
@@ -460,13 +647,6 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
                 c0 = acc[2 * tp];
                 c1 = acc[2 * tp + 1];
             }
-#ifdef F_SPLIT_X
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                cx0[r] = 0.f;
-                cx1[r] = 0.f;
-            }
-#endif
         }
         Rec &cur = buf[k % (F_PF + 1)];
         if constexpr (k + F_PF < NREC) {
@@ -489,17 +669,22 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             c0 = mfma_main(cur.p0, xh[j0], c0);
             run_slice();
             c1 = mfma_main(cur.p1, xh[j0], c1);
-        } else if constexpr (xw == 0) {
-            c0 = mfma_cross(cur, xl[b], c0, sc_h, SC_XL);
-            run_slice();
-        } else if constexpr (xw == 1) {
-            c1 = mfma_cross(cur, xl[b], c1, sc_h, SC_XL);
-            run_slice();
-        } else if constexpr (xw == 2) {
-            c0 = mfma_cross(cur, xx[b], c0, sc_l, SC_ONE);
-            run_slice();
         } else {
-            c1 = mfma_cross(cur, xx[b], c1, sc_l, SC_ONE);
+#if F_SIX
+#ifndef F_ABL_NOXL
+            if constexpr (xw == 0) c0 = mfma_cross6<b % 4>(cur, xl[b], c0, xsl[b / 4]);
+            else if constexpr (xw == 1) c1 = mfma_cross6<b % 4>(cur, xl[b], c1, xsl[b / 4]);
+#endif
+#ifndef F_ABL_NOXH
+            if constexpr (xw == 2) c0 = mfma_cross6<b % 4>(cur, xx[b], c0, xsh[b / 4]);
+            else if constexpr (xw == 3) c1 = mfma_cross6<b % 4>(cur, xx[b], c1, xsh[b / 4]);
+#endif
+#else
+            if constexpr (xw == 0) c0 = mfma_cross(cur, xl[b], c0, sc_h, SC_XL);
+            else if constexpr (xw == 1) c1 = mfma_cross(cur, xl[b], c1, sc_h, SC_XL);
+            else if constexpr (xw == 2) c0 = mfma_cross(cur, xx[b], c0, sc_l, SC_ONE);
+            else c1 = mfma_cross(cur, xx[b], c1, sc_l, SC_ONE);
+#endif
             run_slice();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -513,19 +698,11 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             // pin the end of the pair's accumulator chains here: the MFMAs are pure, and code sinking otherwise moves the
             // tail of every chain into the block that first reads the tile (past the next level's gather), keeping the
             // records they read alive in registers
-#ifdef F_SPLIT_X
-            if (XT) {
-                c0 += cx0;
-                c1 += cx1;
-            }
-#endif
             asm volatile("" : "+a"(c0), "+a"(c1));
             acc[2 * tp] = c0;
             acc[2 * tp + 1] = c1;
         }
     });
-#undef X0
-#undef X1
     if constexpr (CV != 0) {  // the last pair: exposed
         // its first tile was last written by the second-last MFMA, 16 passes + the issue of the last one ago: the asm reads
         // below are invisible to hipcc's hazard recognizer (the XDL write -> VALU read distance is 19 wait states)
@@ -551,7 +728,8 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     const int *scl = reinterpret_cast<const int *>(prm + P_SC);
     f32x16 acc[8];
     f16x8 xh[16];
-    i32x8 xl[4], xx[4];
+    XB xl[4], xx[4];
+    int xsh[1] = {0}, xsl[1] = {0};  // block exponents of the activation operands (six-bit variant)
     NextOps nx;
     {
         // gather: the tile fetches of all four pyramid levels are issued first (32 coalesced 16-byte loads per lane in
@@ -560,12 +738,40 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         const WaveBox wb = wave_box(g);
         F_STAMP(1);
         f16x8 fh[24];
-        i32x8 fl[6], fx[6];
-#ifdef F_ABL_NOGATHER
-        float f[192];
+        XB fl[6], fx[6];
+        int fsh[2] = {0, 0}, fsl[2] = {0, 0};
+#if F_SIX
+        int fe[6];
+#endif
+        // NG groups of 16 gathered values -> chunks C0.. and K blocks B0.. of fc_0's operand
+        auto emit = [&](auto ngc, const float *f, auto c0c, auto b0c) {
+            constexpr int NG = decltype(ngc)::value, C0 = decltype(c0c)::value, B0 = decltype(b0c)::value, NB = (NG + 1) / 2;
+            f16x8 h[2 * NG];
+            XB l[NB], x[NB];
+#if F_SIX
+            int eb[NB];
+            make_operands6<NG, false>([&](int i) { return f[i]; }, h, l, x, eb);
 #pragma unroll
-        for (int i = 0; i < 192; ++i) f[i] = i < 176 ? g.gw * (float)(i + 1) + g.gh : 0.f;
-        make_operands<12, false>([&](int i) { return f[i]; }, fh, fl, fx);
+            for (int q = 0; q < NB; ++q) fe[B0 + q] = eb[q];
+#else
+            make_operands<NG, false>([&](int i) { return f[i]; }, h, l, x);
+#endif
+#pragma unroll
+            for (int c = 0; c < 2 * NG; ++c) fh[C0 + c] = h[c];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                fl[B0 + q] = l[q];
+                fx[B0 + q] = x[q];
+            }
+        };
+        using std::integral_constant;
+#ifdef F_ABL_NOGATHER
+        {
+            float f[192];
+#pragma unroll
+            for (int i = 0; i < 192; ++i) f[i] = i < 176 ? g.gw * (float)(i + 1) + g.gh : 0.f;
+            emit(integral_constant<int, 12>{}, f, integral_constant<int, 0>{}, integral_constant<int, 0>{});
+        }
 #else
         CoopFetch<TILE_BYTES> c0f, c1f, c2f, c3f;
         coop_issue<0, TILE_BYTES>(sc, wb, rg.lane, c0f);
@@ -574,76 +780,51 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         coop_issue<3, TILE_BYTES>(sc, wb, rg.lane, c3f);
         F_STAMP(2);
         {
+            // level 0 fills the first half of the last block (slots 160..175), the second half is zero
             float f0[16];
             coop_finish<0, TILE_BYTES>(sc, g, c0f, hi, rg.lane, rg.tile, f0);
-            // level 0 fills the first half of the last block (slots 160..175), the second half is zero
-            f16x8 h2[2];
-            i32x8 l1[1], x1[1];
-            make_operands<1, false>([&](int i) { return f0[i]; }, h2, l1, x1);
-            fh[20] = h2[0];
-            fh[21] = h2[1];
-            fl[5] = l1[0];
-            fx[5] = x1[0];
+            emit(integral_constant<int, 1>{}, f0, integral_constant<int, 20>{}, integral_constant<int, 5>{});
         }
         F_STAMP(3);
         {
             float f1[32];
             coop_finish<1, TILE_BYTES>(sc, g, c1f, hi, rg.lane, rg.tile, f1);
-            f16x8 h4[4];
-            i32x8 l1[1], x1[1];
-            make_operands<2, false>([&](int i) { return f1[i]; }, h4, l1, x1);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) fh[c] = h4[c];
-            fl[0] = l1[0];
-            fx[0] = x1[0];
+            emit(integral_constant<int, 2>{}, f1, integral_constant<int, 0>{}, integral_constant<int, 0>{});
         }
         F_STAMP(4);
         {
             float f2[64];
             coop_finish<2, TILE_BYTES>(sc, g, c2f, hi, rg.lane, rg.tile, f2);
-            f16x8 h8[8];
-            i32x8 l2[2], x2[2];
-            make_operands<4, false>([&](int i) { return f2[i]; }, h8, l2, x2);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) fh[4 + c] = h8[c];
-            fl[1] = l2[0];
-            fl[2] = l2[1];
-            fx[1] = x2[0];
-            fx[2] = x2[1];
+            emit(integral_constant<int, 4>{}, f2, integral_constant<int, 4>{}, integral_constant<int, 1>{});
         }
         F_STAMP(5);
         {
             float f3[64];
             coop_finish<3, TILE_BYTES>(sc, g, c3f, hi, rg.lane, rg.tile, f3);
-            f16x8 h8[8];
-            i32x8 l2[2], x2[2];
-            make_operands<4, false>([&](int i) { return f3[i]; }, h8, l2, x2);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) fh[12 + c] = h8[c];
-            fl[3] = l2[0];
-            fl[4] = l2[1];
-            fx[3] = x2[0];
-            fx[4] = x2[1];
+            emit(integral_constant<int, 4>{}, f3, integral_constant<int, 12>{}, integral_constant<int, 3>{});
         }
+#endif
+#if F_SIX
+        pack_exps<6>(fe, fsh, fsl);
 #endif
         F_STAMP(6);
         // fc_0: 6 K-blocks (22 chunks), finished tiles converted (relu) into fc_1's operands on the fly
-        layer_phase<FR_F0, 8, 6, 2, true, 1>(rg, prm + P_B0, acc, fh, fl, fx, scl[0], scl[1], &nx);
+        layer_phase<FR_F0, 8, 6, 2, true, 1>(rg, prm + P_B0, acc, fh, fl, fx, fsh, fsl, scl[0], scl[1], &nx);
         F_STAMP(13);
     }
-    ops_from<8>(nx, xh, xl, xx);
+    ops_from<8>(nx, xh, xl, xx, xsh, xsl);
 #ifdef F_TIMING  // per-record trace of fc_1
-    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx, NoExtra(), tbuf ? tbuf0 + 8192 + 128 * ((tbuf - tbuf0) / 32) : nullptr);
+    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, xsh, xsl, scl[2], scl[3], &nx, NoExtra(), tbuf ? tbuf0 + 8192 + 128 * ((tbuf - tbuf0) / 32) : nullptr);
 #else
-    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, scl[2], scl[3], &nx);
+    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, xsh, xsl, scl[2], scl[3], &nx);
 #endif
     F_STAMP(14);
-    ops_from<8>(nx, xh, xl, xx);
+    ops_from<8>(nx, xh, xl, xx, xsh, xsl);
     // fc_2.  alpha_fc (fp32, VALU) is NOT folded into the conversion slices: its weights come from LDS, and a
     // compiler-visible LDS read inside the record loop makes hipcc wait lgkmcnt(0), which drains the fragment prefetch
     // at every slice (measured with F_TIMING: fc_2 took 22.5k cycles against 13.3k for the identical fc_1).  It runs on
     // the finished accumulators before the tail conversion overwrites nothing it needs (acc stays intact).
-    layer_phase<FR_L2, 8, 4, 4, true, F_MERGED_X ? 1 : 4>(rg, prm + P_B2, acc, xh, xl, xx, scl[4], scl[5], &nx);
+    layer_phase<FR_L2, 8, 4, 4, true, F_MERGED_X ? 1 : 4>(rg, prm + P_B2, acc, xh, xl, xx, xsh, xsl, scl[4], scl[5], &nx);
     float s_alpha = 0.f;
     {
         const f32x4 *aw = reinterpret_cast<const f32x4 *>(prm + P_AW + hi * 128);
@@ -658,14 +839,14 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     }
     out[3] = add_halves(s_alpha) + prm[P_AB];
     F_STAMP(15);
-    ops_from<8>(nx, xh, xl, xx);
-    layer_phase<FR_L4, 8, 4, 4, true, 2, NoExtra, F_MERGED_X>(rg, prm + P_LB, acc, xh, xl, xx, scl[6], scl[7], &nx);
+    ops_from<8>(nx, xh, xl, xx, xsh, xsl);
+    layer_phase<FR_L4, 8, 4, 4, true, 2, NoExtra, F_MERGED_X>(rg, prm + P_LB, acc, xh, xl, xx, xsh, xsl, scl[6], scl[7], &nx);
     F_STAMP(16);
-    ops_from<8>(nx, xh, xl, xx);
+    ops_from<8>(nx, xh, xl, xx, xsh, xsl);
     // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings; rgb_fc (fp32,
     // VALU) rides on the finished tiles of the second phase
     f32x16 v[4];
-    layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, scl[8], scl[9]);
+    layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, xsh, xsl, scl[8], scl[9]);
     F_STAMP(17);
     float s_rgb[3] = {0.f, 0.f, 0.f};
     {
@@ -676,10 +857,17 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         pe_xyz(pe, px, py, pz, vx, vy, vz, hi);
 #endif
         f16x8 ph[6];
-        i32x8 pl[2], pxx[2];
+        XB pl[2], pxx[2];
+        int psh[1] = {0}, psl[1] = {0};
+#if F_SIX
+        int pee[2];
+        make_operands6<3, false>([&](int i) { return i < N_PE ? pe[i < N_PE ? i : 0] : 0.f; }, ph, pl, pxx, pee);
+        pack_exps<2>(pee, psh, psl);
+#else
         make_operands<3, false>([&](int i) { return i < N_PE ? pe[i < N_PE ? i : 0] : 0.f; }, ph, pl, pxx);
+#endif
         F_STAMP(18);
-        layer_phase<FR_VP, 4, 2, 2, false>(rg, prm + P_BV, v, ph, pl, pxx, scl[8], scl[9]);
+        layer_phase<FR_VP, 4, 2, 2, false>(rg, prm + P_BV, v, ph, pl, pxx, psh, psl, scl[8], scl[9]);
     }
     // rgb_fc in fp32 on the VALU (outside the record loop for the same reason as alpha_fc)
 #pragma unroll
@@ -745,7 +933,14 @@ __device__ __forceinline__ FRing f_ring_begin(const float *pk, const float *lb, 
 }
 
 // ---------------------------------------------------------------- ray mode
-__global__ __launch_bounds__(256) void nb_march_f16_kernel(MarchArgs a, const char *stream) {
+#if F_SIX
+#define F_KERNEL nb_march_f6_kernel
+#define F_KERNEL_NAME "nb_march_f6_kernel"
+#else
+#define F_KERNEL nb_march_f16_kernel
+#define F_KERNEL_NAME "nb_march_f16_kernel"
+#endif
+__global__ __launch_bounds__(256) void F_KERNEL(MarchArgs a, const char *stream) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const FRing rg = f_ring_begin(a.pk, a.lb, stream, lds);
     const int lane = rg.lane, j = lane & 31, hi = lane >> 5;
@@ -922,9 +1117,29 @@ __device__ __forceinline__ unsigned fp8_e4m3_bits(float v) {
     return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(v, v, 0, false) & 0xffu;
 }
 
+// fp6 e2m3 (sign, 2 exponent bits of bias 1, 3 mantissa bits; subnormal step 1/8, largest 7.5), round to nearest even
+__device__ __forceinline__ unsigned fp6_e2m3_bits(float v) {
+    const unsigned sgn = v < 0.f ? 32u : 0u;
+    const float a = fminf(fabsf(v), 7.5f);
+    unsigned code;
+    if (a < 1.f) {
+        code = (unsigned)rintf(a * 8.f);  // 8 = 1.0, the first normal
+    } else {
+        int e = a >= 4.f ? 2 : (a >= 2.f ? 1 : 0);
+        int m = (int)rintf((ldexpf(a, -e) - 1.f) * 8.f);
+        if (m == 8) {
+            m = 0;
+            ++e;
+        }
+        code = (unsigned)(((e + 1) << 3) | m);
+        if (code > 31u) code = 31u;
+    }
+    return sgn | code;
+}
+
 // one thread per (record, lane): the lane's 32 bytes of the record
 __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, const int *__restrict__ scales,
-                                   unsigned *__restrict__ out) {
+                                   int *__restrict__ stats, unsigned *__restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= FN_RECS_PAD * 64) return;
     const int rec = t >> 6, lane = t & 63, i = lane & 31, kg = lane >> 5;
@@ -957,8 +1172,45 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
                 w32[half * 4 + r / 2] = __builtin_bit_cast(unsigned, hp);
             }
         }
-    } else {  // X8h(t0), X8h(t1), X8l(t0), X8l(t1): 32 fp8 values of K-block b
+    } else {  // X8h(t0), X8h(t1), X8l(t0), X8l(t1): 32 8-bit (6-bit) values of K-block b
         const int which = (j0 - nmain) % 4, row = 32 * (2 * tp + (which & 1)) + i, lo = which >> 1;
+#if F_SIX
+        // fp6 e2m3 with the lane's own E8M0 scale (row, K half).  The W_h record multiplies the REMAINDER operand, whose
+        // elements are interleaved [v0, v16, v1, v17, ...] (v_cvt_scalef32_2xpk16_bf6_f32); the W_l record the head operand
+        float wv[32], amax = 0.f;
+        for (int e = 0; e < 32; ++e) {
+            const int n = lo ? e : 16 * (e & 1) + (e >> 1);
+            const float w = phase_weight(p, f32_blob, ph, row, 32 * b + n, kg);
+            const float h = (float)(_Float16)w;
+            wv[e] = lo ? w - h : h;
+            amax = fmaxf(amax, fabsf(wv[e]));
+        }
+        int ex = 0;
+        if (amax > 0.f && amax < 3.0e38f) {
+            ex = ilogbf(amax / 7.5f);
+            if (ldexpf(7.5f, ex) < amax) ++ex;  // the smallest power of two with max / 2^ex <= 7.5
+            ex = min(max(ex, -120), 120);
+        }
+        for (int k = 0; k < 8; ++k) w32[k] = 0u;
+        for (int e = 0; e < 32; ++e) {
+            const unsigned code = fp6_e2m3_bits(ldexpf(wv[e], -ex));
+            const int bit = 6 * e;
+            w32[bit >> 5] |= code << (bit & 31);
+            if ((bit & 31) > 26) w32[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+        }
+        w32[6] = (unsigned)(127 + ex);
+        // statistic behind nb_mlp_six_bit_stats_offset(): how many non-zero head weights sit below 1/8 of their block's
+        // maximum, i.e. in e2m3's subnormal range where they keep fewer than 3 bits (per layer: small, non-zero)
+        if (!lo) {
+            int small = 0, nz = 0;
+            for (int e = 0; e < 32; ++e) {
+                nz += wv[e] != 0.f;
+                small += wv[e] != 0.f && fabsf(wv[e]) < 0.125f * amax;
+            }
+            atomicAdd(&stats[2 * phase_layer(ph)], small);
+            atomicAdd(&stats[2 * phase_layer(ph) + 1], nz);
+        }
+#else
         const int e8 = scales[2 * phase_layer(ph) + lo];  // 127 - exponent
         const float mul = ldexpf(1.f, 127 - e8);
         for (int e = 0; e < 32; e += 4) {
@@ -970,6 +1222,7 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
             }
             w32[e / 4] = word;
         }
+#endif
     }
     // piece 0 (bytes 0..15 of the lane) at lane * 16, piece 1 at 1024 + lane * 16
     unsigned *recp = out + (size_t)rec * (FREC_BYTES / 4);
@@ -983,23 +1236,40 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
 
 namespace nbm {
 
+#if F_SIX
+long long f6_stream_floats() { return ((long long)FN_RECS_PAD * FREC_BYTES + F_N_SCALES * 4) / 4; }
+#else
 long long f16_stream_floats() { return ((long long)FN_RECS_PAD * FREC_BYTES + F_N_SCALES * 4) / 4; }
+#endif
 
-// `packed` = [fp32 section][bf16 ring stream][M-split stream][f16f8 stream | scales]; stream_off = float offset of the last
+// `packed` = [fp32 section][bf16 ring stream][M-split stream][f16f8 stream | scales][f16f6 stream | unused scales]
+#if F_SIX
+int pack_f6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st) {
+#else
 int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st) {
+#endif
     unsigned *stream = reinterpret_cast<unsigned *>(packed + stream_off);
     int *scales = reinterpret_cast<int *>(stream + (size_t)FN_RECS_PAD * FREC_BYTES / 4);
+#if F_SIX
+    // the 16 words behind the stream carry no layer scales in this variant (every lane of a record has its own) but the
+    // small-element statistic the pack kernel accumulates
+    NB_REQUIRE(hipMemsetAsync(scales, 0, F_N_SCALES * sizeof(int), st) == hipSuccess, "pack_f6_stream: hipMemsetAsync failed");
+#else
     hipLaunchKernelGGL(nb_f16_scales_kernel, dim3(5), dim3(256), 0, st, *p, packed, scales);
     NB_CHECK_LAUNCH("nb_f16_scales_kernel");
-    hipLaunchKernelGGL(nb_pack_f16_kernel, dim3(nb_ceil_div((long long)FN_RECS_PAD * 64, 256)), dim3(256), 0, st, *p, packed, scales, stream);
+#endif
+    hipLaunchKernelGGL(nb_pack_f16_kernel, dim3(nb_ceil_div((long long)FN_RECS_PAD * 64, 256)), dim3(256), 0, st, *p, packed, scales, scales, stream);
     NB_CHECK_LAUNCH("nb_pack_f16_kernel");
     return NB_OK;
 }
 
+#if F_SIX
+int launch_march_f6(const MarchArgs &a, long long stream_off, hipStream_t st) {
+#else
 int launch_march_f16(const MarchArgs &a, long long stream_off, hipStream_t st) {
-    hipLaunchKernelGGL(nb_march_f16_kernel, dim3(a.n_wave_groups), dim3(256), 0, st, a,
-                       reinterpret_cast<const char *>(a.pk + stream_off));
-    NB_CHECK_LAUNCH("nb_march_f16_kernel");
+#endif
+    hipLaunchKernelGGL(F_KERNEL, dim3(a.n_wave_groups), dim3(256), 0, st, a, reinterpret_cast<const char *>(a.pk + stream_off));
+    NB_CHECK_LAUNCH(F_KERNEL_NAME);
     return NB_OK;
 }
 

@@ -31,7 +31,8 @@ ENCODER_BLOCKS = [
 ]
 DENSE_AFTER = ("conv1", "conv2", "conv3", "conv4")  # latent_xyzc.py:188-201
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
-DEFAULT_PRECISION = "f16f8"
+DEFAULT_PRECISION = "auto"
+SIX_BIT_MAX_SMALL = 0.5
 
 
 class SparseConv3dParam(nn.Module):
@@ -120,8 +121,9 @@ class Network(nn.Module):
         # decoder GEMM arithmetic: "bf16x3" (split-bf16 MFMA, 3 products, fp32 accumulate) or "f32" (exact
         # fp32 MFMA); both stay inside the 1e-4 RGB parity budget, see DESIGN.md
         self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
-        if self.precision not in ("f32", "bf16x3", "bf16x3s", "f16f8"):
-            raise ValueError("precision must be 'f32', 'bf16x3', 'bf16x3s' or 'f16f8'")
+        if self.precision not in ("auto", "f32", "bf16x3", "bf16x3s", "f16f8", "f16f6"):
+            raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'bf16x3s', 'f16f8' or 'f16f6'")
+        self._auto = None  # (weight key, chosen arithmetic) of precision 'auto'
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -154,13 +156,27 @@ class Network(nn.Module):
     def _point_precision(self):
         """nb_decode_points has two kernel families (exact fp32, split bf16); the march-only arithmetics ('bf16x3s',
         'f16f8') decode stand-alone points with the split-bf16 kernels."""
-        return "bf16x3" if self.precision in ("bf16x3s", "f16f8") else self.precision
+        return "bf16x3" if self.precision in ("auto", "bf16x3s", "f16f8", "f16f6") else self.precision
+
+    def march_precision(self):
+        """Arithmetic of the fused march.  'auto' = 'f16f6' (cross terms in six bits, the fastest) unless the weights have
+        blocks fp6 cannot hold: more than SIX_BIT_MAX_SMALL of a layer's non-zero weights below 1/8 of their block maximum
+        (normally distributed weights: ~0.2; the wide-dynamic-range stress case of tools/experiments/precision_sweep.py:
+        ~0.75, where six-bit weights triple the error) — then 'f16f8'.  Decided once per weight version (one 5-float
+        read-back after packing)."""
+        if self.precision != "auto":
+            return self.precision
+        packed = self.packed_weights("f16f6")
+        if self._auto is None or self._auto[0] is not self._packed_key:
+            worst = float(ops.six_bit_small_fraction(packed).max())
+            self._auto = (self._packed_key, "f16f6" if worst <= SIX_BIT_MAX_SMALL else "f16f8", worst)
+        return self._auto[1]
 
     def packed_weights(self, precision=None):
         """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed; only the sections of the
         arithmetics asked for since the last change are (re)written — a training step repacks every iteration and only
         ever decodes with 'f32'."""
-        need = {precision or self.precision, self._point_precision()} if precision is None else {precision}
+        need = {self.march_precision(), self._point_precision()} if precision is None else {precision}
         d = self._mlp_param_dict()
         # keyed on the parameters' storages, which the entry keeps alive (so an address cannot be recycled under the
         # key), and on their version counters (optimizer steps and load_state_dict write in place)
@@ -252,6 +268,7 @@ class Network(nn.Module):
         if t_vals is None:
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._t_vals[key] = t_vals
-        return ops.march(scene, self.packed_weights(self.precision), lb, ray_o, ray_d, near, far, t_vals, t_rand,
-                         white_bkgd=white_bkgd, want_raw=want_raw, precision=self.precision, ray_order=ray_order,
+        prec = self.march_precision()
+        return ops.march(scene, self.packed_weights(prec), lb, ray_o, ray_d, near, far, t_vals, t_rand,
+                         white_bkgd=white_bkgd, want_raw=want_raw, precision=prec, ray_order=ray_order,
                          cull=cull)

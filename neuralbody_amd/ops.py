@@ -118,9 +118,17 @@ def mlp_pack(params, out=None, precisions=None):
     if out is None:
         out = torch.empty(mlp_pack_size(), dtype=torch.float32, device=dev)
     _req(out, torch.float32, (mlp_pack_size(),), "packed")
-    bits = 15 if precisions is None else (1 | sum(_lib.PACK_SECTIONS[q] for q in set(precisions)))
+    bits = 31 if precisions is None else (1 | sum(_lib.PACK_SECTIONS[q] for q in set(precisions)))
     check(_lib.lib().nb_mlp_pack_sections(C.byref(p), ptr(out), int(bits), _stream()), "nb_mlp_pack_sections")
     return out
+
+
+def six_bit_small_fraction(packed):
+    """Per layer (fc_0, fc_1, fc_2, merged, view_fc): the share of non-zero weights below 1/8 of their (row, 32 K)
+    block's maximum, counted while the 'f16f6' section was packed (nb_mlp_six_bit_stats_offset).  Device tensor [5]."""
+    off = int(_lib.lib().nb_mlp_six_bit_stats_offset())
+    c = packed[off:off + 10].view(torch.int32).reshape(5, 2).to(torch.float32)
+    return c[:, 0] / c[:, 1].clamp_min(1.0)
 
 
 def mlp_latent_bias(params, latent_row, out=None):
