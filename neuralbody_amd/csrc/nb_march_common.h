@@ -354,7 +354,7 @@ __device__ __forceinline__ void gather_level_coop(const SceneDev &sc, const Grid
     }
     // ---- fill the tile: piece p = (voxel v, 16-byte quad q) -> buf[p * 16]
     {
-        const float rcp_xy = 1.f / (float)(nx * ny), rcp_x = 1.f / (float)nx;
+        const float rcp_xy = __builtin_amdgcn_rcpf((float)(nx * ny)), rcp_x = __builtin_amdgcn_rcpf((float)nx);  // v + 0.5 absorbs 1 ulp
         f32x4 t[MAX_IT];
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it) {
@@ -438,7 +438,7 @@ __device__ __forceinline__ void coop_issue(const SceneDev &sc, const WaveBox &wb
     const int nx = cf.xhi - cf.xlo + 1, ny = cf.yhi - cf.ylo + 1, nz = cf.zhi - cf.zlo + 1;
     cf.pieces = nx * ny * nz * PC;
     if (cf.pieces > BUF_BYTES / 16) return;  // wave-uniform: coop_finish takes the per-lane path
-    const float rcp_xy = 1.f / (float)(nx * ny), rcp_x = 1.f / (float)nx;
+    const float rcp_xy = __builtin_amdgcn_rcpf((float)(nx * ny)), rcp_x = __builtin_amdgcn_rcpf((float)nx);  // v + 0.5 absorbs 1 ulp
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
         if (it * 64 < cf.pieces) {  // wave-uniform
@@ -575,15 +575,28 @@ struct RayAccum {
 };
 
 // `weights` [n_rays, S] is written one value per ray per depth step; a 4-byte store per lane at a 4*S-byte
-// stride turns into one partial HBM sector write each (measured: WRITE_SIZE 739 MB per 512x512x64 launch
-// for 67 MB of payload).  Each lane therefore keeps four consecutive steps in registers — the hi = 0 half
-// of a sample column steps 8m..8m+3, the hi = 1 half steps 8m+4..8m+7 — and stores them as one aligned
-// 16-byte vector, so a ray's two halves fill a 32-byte sector together.
+// stride turns into one partial HBM write each (measured: WRITE_SIZE 739 MB per 512x512x64 launch for 67 MB of
+// payload), and two 16-byte halves per 8 steps still cost 2x the payload (151 MB: HBM writes are 64-byte lines).
+// Each lane therefore keeps EIGHT consecutive steps in registers — the hi = 0 half of a sample column steps
+// 16m..16m+7, the hi = 1 half steps 16m+8..16m+15 — and stores them as two aligned 16-byte vectors, so a ray's
+// two halves fill one 64-byte line with a single store instruction (S % 16 == 0; S % 8 == 0: 32-byte sectors as before).
 struct WeightStore {
-    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    float q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     __device__ __forceinline__ void push(const MarchArgs &a, long long ray, int s, int S, int hi, bool valid, float w) {
         if ((S & 7) != 0) {  // wave-uniform: odd sample counts take the simple path
             if (valid && hi == 0) a.weights[ray * S + s] = w;
+            return;
+        }
+        if ((S & 15) == 0) {
+            const int slot = s & 15;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (slot == hi * 8 + i) q[i] = w;
+            if (slot == 15 && valid) {
+                f32x4 *dst = reinterpret_cast<f32x4 *>(a.weights + ray * S + (s - 15) + hi * 8);
+                dst[0] = f32x4{q[0], q[1], q[2], q[3]};
+                dst[1] = f32x4{q[4], q[5], q[6], q[7]};
+            }
             return;
         }
         const int slot = s & 7;

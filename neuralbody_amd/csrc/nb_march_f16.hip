@@ -655,6 +655,9 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
         } else {
             wait_rec<2 * (NREC - 1 - k)>(cur);
         }
+        // half-slices [j0 * HPR, (j0 + 1) * HPR) of the previous pair ride on this record.  (Measured for the six-bit variant,
+        // whose cross MFMAs are as short as one fp16 MFMA: slices on the main records only, one behind each of their two
+        // MFMAs, is 0.2 ms SLOWER than this even spread, A/B on one box.)
         auto run_slice = [&]() {
             if constexpr (CV != 0 && tp > 0 && j0 * HPR < NH) {
                 __builtin_amdgcn_sched_barrier(0);

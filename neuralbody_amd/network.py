@@ -177,6 +177,8 @@ class Network(nn.Module):
         arithmetics asked for since the last change are (re)written — a training step repacks every iteration and only
         ever decodes with 'f32'."""
         need = {self.march_precision(), self._point_precision()} if precision is None else {precision}
+        if "bf16x3s" in need:
+            need.add("bf16x3")  # a culled march (nb_cull) runs the ring kernel, which reads the 'bf16x3' stream
         d = self._mlp_param_dict()
         # keyed on the parameters' storages, which the entry keeps alive (so an address cannot be recycled under the
         # key), and on their version counters (optimizer steps and load_state_dict write in place)

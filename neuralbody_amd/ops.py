@@ -116,7 +116,7 @@ def mlp_pack(params, out=None, precisions=None):
     p, keep = _mlp_params(params)
     dev = keep[0].device
     if out is None:
-        out = torch.empty(mlp_pack_size(), dtype=torch.float32, device=dev)
+        out = torch.zeros(mlp_pack_size(), dtype=torch.float32, device=dev)  # sections not asked for stay zero, never stale
     _req(out, torch.float32, (mlp_pack_size(),), "packed")
     bits = 31 if precisions is None else (1 | sum(_lib.PACK_SECTIONS[q] for q in set(precisions)))
     check(_lib.lib().nb_mlp_pack_sections(C.byref(p), ptr(out), int(bits), _stream()), "nb_mlp_pack_sections")
