@@ -275,13 +275,17 @@ def main():
             mix["merged"] = "f16x1"
             report(sc + ", merged f16x1", mix)
         return
-    for s in ("f32", "bf16x3", "f16x3", "f16c8", "f16x2w", "f16x2x", "f16x1", "bf16x1"):
+    for s in ("f32", "bf16x3", "f16x3", "f16c8", "f16c8b", "f16c6", "f16c6w", "f16c6x", "f16x2w", "f16x2x", "f16x1", "bf16x1"):
         report("all " + s, {l: s for l in LAYERS})
     for s in ("f16x1", "f16c8", "bf16x1"):
         for l in LAYERS:
             mix = {k: "bf16x3" for k in LAYERS}
             mix[l] = s
             report("bf16x3 except %s=%s" % (l, s), mix)
+    for sc in ("f16c8b", "f16c6"):  # the two shipped arithmetics: merged layer as a single fp16 product
+        mix = {k: sc for k in LAYERS}
+        mix["merged"] = "f16x1"
+        report("SHIPPED %s: %s, merged f16x1" % ("f16f8" if sc == "f16c8b" else "f16f6", sc), mix)
     for trunk, head in itertools.product(("bf16x3", "f16c8", "f16x1"), ("f16x1", "bf16x1")):
         mix = {"fc_0": trunk, "fc_1": trunk, "fc_2": trunk, "merged": head, "view_fc": head}
         report("trunk %s / colour head %s" % (trunk, head), mix)
