@@ -147,15 +147,29 @@ __device__ __forceinline__ void f_issue_page(const FRing &rg, int page) {
     });
 }
 
-// one 1-KiB piece of a page (the lane's 16 bytes): pieces 4, 5 take a second M0 / base (13-bit instruction offset)
+// one 1-KiB piece of a page (the lane's 16 bytes): pieces 4, 5 take a second M0 / base (13-bit instruction offset).
+// Issued from inline asm in the `v_off, s[base]` form: left to the compiler the depth loop uses a 64-bit per-lane address
+// (one v_lshl_add_u64 + copies per piece, all VALU issue slots, which in this kernel are as expensive as MFMA slots)
 template <int I>
 __device__ __forceinline__ void f_issue_piece(const FRing &rg, int page) {
     const int slot = page % FN_SLOTS;
+    constexpr int grp = I / 4, off = (I % 4) * 1024;
+#ifdef F_DMA_BUILTIN
     const char *base = rg.stream + (size_t)page * FPAGE_BYTES;
     const unsigned voff = (unsigned)rg.lane * 16u;
     char *dst = rg.lds + slot * FPAGE_BYTES + rg.wave_off;
-    constexpr int grp = I / 4, off = (I % 4) * 1024;
     __builtin_amdgcn_global_load_lds((gptr_t)(base + grp * 4096 + voff), (lptr_t)(dst + grp * 4096), 16, off, 0);
+#else
+    const char *base = rg.stream + (size_t)page * FPAGE_BYTES + grp * 4096;  // wave-uniform
+    const unsigned ldsoff = (unsigned)(unsigned long long)(lptr_t)(rg.lds + slot * FPAGE_BYTES + rg.wave_off + grp * 4096);
+    asm volatile(
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %0, %1 offset:%3"
+        :
+        : "v"(rg.base[0]), "s"(base), "s"(ldsoff), "n"(off)
+        : "memory", "m0");
+#endif
 }
 
 // before the first record of `page` is read: everything but the DMAs of the FAHEAD-1 younger pages has landed, and every
@@ -190,16 +204,35 @@ __device__ __forceinline__ void load_rec(const FRing &rg, Rec &f) {
     asm volatile("" : "=v"(f.p0), "=v"(f.p1) : "v"(rg.base[slot]));
     return;
 #endif
+#if !defined(F_DMA_BURST) && !defined(F_ABL_NODMA) && !defined(F_DMA_BUILTIN)
+    // the six DMA pieces of the page FAHEAD pages ahead ride on the odd records of this page instead of forming a burst
+    // behind the page's barrier (where the matrix pipe has nothing to do); same issue order as the burst, so the counted
+    // vmcnt of f_turn_page is unchanged.  One asm block with the record's fragment reads: M0 (the LDS destination) is
+    // written first, the two reads give it the wait state the LDS-DMA instruction needs (no s_nop), and the uniform 64-bit
+    // source address stays in SGPRs (`v_off, s[base]` form: no per-lane 64-bit VALU add)
+    if constexpr ((REC % FPAGE_RECS) % 2 == 1 && (REC % FPAGE_RECS) / 2 < FDMA_PER_WAVE) {
+        constexpr int I = (REC % FPAGE_RECS) / 2, grp = I / 4, poff = (I % 4) * 1024;
+        constexpr int page = (REC / FPAGE_RECS + FAHEAD) % FN_PAGES, pslot = page % FN_SLOTS;
+        const char *base = rg.stream + (size_t)page * FPAGE_BYTES + grp * 4096;  // wave-uniform
+        const unsigned ldsoff = (unsigned)(unsigned long long)(lptr_t)(rg.lds + pslot * FPAGE_BYTES + rg.wave_off + grp * 4096);
+        asm volatile(
+            "s_mov_b32 m0, %6\n\t"
+            "ds_read_b128 %0, %2 offset:%3\n\t"
+            "ds_read_b128 %1, %2 offset:%4\n\t"
+            "global_load_lds_dwordx4 %7, %5 offset:%8"
+            : "=&v"(f.p0), "=&v"(f.p1)
+            : "v"(rg.base[slot]), "n"(off), "n"(off + 1024), "s"(base), "s"(ldsoff), "v"(rg.base[0]), "n"(poff)
+            : "memory", "m0");
+        return;
+    }
+#endif
     asm volatile(
         "ds_read_b128 %0, %2 offset:%3\n\t"
         "ds_read_b128 %1, %2 offset:%4"
         : "=&v"(f.p0), "=&v"(f.p1)
         : "v"(rg.base[slot]), "n"(off), "n"(off + 1024)
         : "memory");
-#if !defined(F_DMA_BURST) && !defined(F_ABL_NODMA)
-    // the six DMA pieces of the page FAHEAD pages ahead ride on the odd records of this page instead of forming a burst
-    // behind the page's barrier (where the matrix pipe has nothing to do); same issue order as the burst, so the
-    // counted vmcnt of f_turn_page is unchanged
+#if !defined(F_DMA_BURST) && !defined(F_ABL_NODMA) && defined(F_DMA_BUILTIN)
     if constexpr ((REC % FPAGE_RECS) % 2 == 1 && (REC % FPAGE_RECS) / 2 < FDMA_PER_WAVE)
         f_issue_piece<(REC % FPAGE_RECS) / 2>(rg, (REC / FPAGE_RECS + FAHEAD) % FN_PAGES);
 #endif
@@ -207,7 +240,17 @@ __device__ __forceinline__ void load_rec(const FRing &rg, Rec &f) {
 // LDS operations retire in order: "at most NEWER outstanding" = everything older than the NEWER reads issued last has landed
 template <int NEWER>
 __device__ __forceinline__ void wait_rec(Rec &f) {
+#ifdef F_WAIT_ASM
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.p0), "+v"(f.p1) : "n"(NEWER));
+#else
+    // the builtin, fenced: as inline asm with the fragment registers tied to it (so that the MFMA cannot move above the wait)
+    // hipcc treats the statement as a writer of those registers and puts an `s_nop 0` in front of every MFMA
+    static_assert(NEWER < 16, "lgkmcnt field");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_waitcnt(0xC07F | (NEWER << 8));  // vmcnt 63, expcnt 7, lgkmcnt NEWER
+    __builtin_amdgcn_sched_barrier(0);
+    (void)f;
+#endif
 }
 
 __device__ __forceinline__ f32x16 mfma_main(const i32x4 a, const f16x8 b, const f32x16 c) {
@@ -581,6 +624,15 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
 #ifndef F_PF
 #define F_PF 3  // records of lookahead (measured: 2 -> 21.4 ms, 3 -> 21.0, 4 -> 21.3, 5 -> 21.8)
 #endif
+#ifdef F_DUMMY_FILL
+    float rg_dummy[8];
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t rg_dummy2[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rg_dummy[i] = (float)(rg.lane + i);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rg_dummy2[i] = f32x2_t{(float)(rg.lane + i), 1.f};
+#endif
     Rec buf[F_PF + 1];
     static_for<F_PF>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -668,10 +720,30 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
+#ifdef F_DUMMY_FILL  // experiment: F_DUMMY_FILL independent VALU instructions behind every MFMA of fc_0 (kind F_DUMMY_KIND)
+        auto dummy = [&rg_dummy, &rg_dummy2]() {
+            if constexpr (REC0 == FR_F0) {
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<F_DUMMY_FILL>([&rg_dummy, &rg_dummy2](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+#if F_DUMMY_KIND == 0
+                    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(rg_dummy[i % 8]) : "v"(rg_dummy[(i + 3) % 8]));
+#else
+                    asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(rg_dummy2[i % 4]) : "v"(rg_dummy2[(i + 1) % 4]));
+#endif
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+#else
+        auto dummy = [&]() {};
+#endif
         if constexpr (is_main) {
             c0 = mfma_main(cur.p0, xh[j0], c0);
             run_slice();
+            dummy();
             c1 = mfma_main(cur.p1, xh[j0], c1);
+            dummy();
         } else {
 #if F_SIX
 #ifndef F_ABL_NOXL
@@ -689,6 +761,7 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             else c1 = mfma_cross(cur, xx[b], c1, sc_l, SC_ONE);
 #endif
             run_slice();
+            dummy();
         }
         __builtin_amdgcn_sched_barrier(0);
 #ifdef F_TIMING
