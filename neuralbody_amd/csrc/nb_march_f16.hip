@@ -273,15 +273,19 @@ __device__ __forceinline__ f32x16 mfma_cross(const Rec &a, const i32x8 b, const 
 
 // six-bit cross term: A fp6 e2m3 (cbsz 2) in the first 24 bytes of the lane's record share, its E8M0 scale in byte 24;
 // B bf6 e3m2 (blgp 3), E8M0 scale = byte BSEL of `sb` (one register carries the scales of four K blocks)
+// the record share as ONE 8-register tuple (only the first six are the operand; register 6 is the scale): the two 4-register
+// fragment reads coalesce into it in place — a 6-of-8 use of two separate reads costs two copies per record.  Pinned BEFORE the
+// counted wait of the record: an (empty) asm directly in front of the MFMA makes hipcc put an `s_nop 0` between them.
+__device__ __forceinline__ i32x8 cross6_operand(const Rec &a) {
+    i32x8 av = {a.p0.x, a.p0.y, a.p0.z, a.p0.w, a.p1.x, a.p1.y, a.p1.z, a.p1.w};
+    asm volatile("" : "+v"(av));
+    return av;
+}
 template <int BSEL>
-__device__ __forceinline__ f32x16 mfma_cross6(const Rec &a, const i32x6 b, const f32x16 c, int sb) {
+__device__ __forceinline__ f32x16 mfma_cross6(const i32x8 av, const i32x6 b, const f32x16 c, int sb) {
 #ifdef F_ABL_NOX
     return c;
 #endif
-    // the full 8-register record share (only the first six are read): the pair of 4-register fragment reads then forms
-    // the operand in place, and the scale is register 6 of the same tuple
-    i32x8 av = {a.p0.x, a.p0.y, a.p0.z, a.p0.w, a.p1.x, a.p1.y, a.p1.z, a.p1.w};
-    asm volatile("" : "+v"(av));  // an 8-register tuple the two reads coalesce into (a 6-of-8 use costs two copies per record)
     const i32x8 bv = {b[0], b[1], b[2], b[3], b[4], b[5], 0, 0};
 #ifdef F_NO_OPSEL
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, c, 2, 3, 0, av[6], 0, sb >> (8 * BSEL));
@@ -305,6 +309,17 @@ __device__ __forceinline__ float relu_asm(float x) {
     float r;
     asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
     return r;
+}
+// acc += w * relu(x) as one asm block (separate statements get an `s_nop 0` between the asm v_max and the compiler's v_fmac)
+__device__ __forceinline__ void relu_fma(float &acc, float w, float x) {
+    float t;
+    asm("v_max_f32 %1, 0, %2\n\tv_fmac_f32 %0, %3, %1" : "+v"(acc), "=&v"(t) : "v"(x), "v"(w));
+}
+__device__ __forceinline__ void relu_fma3(float &a0, float &a1, float &a2, float w0, float w1, float w2, float x) {
+    float t;
+    asm("v_max_f32 %3, 0, %4\n\tv_fmac_f32 %0, %5, %3\n\tv_fmac_f32 %1, %6, %3\n\tv_fmac_f32 %2, %7, %3"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "=&v"(t)
+        : "v"(x), "v"(w0), "v"(w1), "v"(w2));
 }
 // fp16 head of two values (round to nearest even) and the exact fp32 remainder x - fp16(x) as ONE v_fma_mix_f32 each
 // (hipcc's own lowering of `x - (float)(_Float16)x` converts every value twice: 9 instead of 5 instructions per pair)
@@ -701,12 +716,13 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
             }
         }
         Rec &cur = buf[k % (F_PF + 1)];
-        if constexpr (k + F_PF < NREC) {
-            load_rec<REC0 + k + F_PF>(rg, buf[(k + F_PF) % (F_PF + 1)]);
-            wait_rec<2 * F_PF>(cur);
-        } else {
-            wait_rec<2 * (NREC - 1 - k)>(cur);
-        }
+        if constexpr (k + F_PF < NREC) load_rec<REC0 + k + F_PF>(rg, buf[(k + F_PF) % (F_PF + 1)]);
+#if F_SIX
+        i32x8 cur8;
+        if constexpr (!is_main) cur8 = cross6_operand(cur);
+#endif
+        if constexpr (k + F_PF < NREC) wait_rec<2 * F_PF>(cur);
+        else wait_rec<2 * (NREC - 1 - k)>(cur);
         // half-slices [j0 * HPR, (j0 + 1) * HPR) of the previous pair ride on this record.  (Measured for the six-bit variant,
         // whose cross MFMAs are as short as one fp16 MFMA: slices on the main records only, one behind each of their two
         // MFMAs, is 0.2 ms SLOWER than this even spread, A/B on one box.)
@@ -747,12 +763,12 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
         } else {
 #if F_SIX
 #ifndef F_ABL_NOXL
-            if constexpr (xw == 0) c0 = mfma_cross6<b % 4>(cur, xl[b], c0, xsl[b / 4]);
-            else if constexpr (xw == 1) c1 = mfma_cross6<b % 4>(cur, xl[b], c1, xsl[b / 4]);
+            if constexpr (xw == 0) c0 = mfma_cross6<b % 4>(cur8, xl[b], c0, xsl[b / 4]);
+            else if constexpr (xw == 1) c1 = mfma_cross6<b % 4>(cur8, xl[b], c1, xsl[b / 4]);
 #endif
 #ifndef F_ABL_NOXH
-            if constexpr (xw == 2) c0 = mfma_cross6<b % 4>(cur, xx[b], c0, xsh[b / 4]);
-            else if constexpr (xw == 3) c1 = mfma_cross6<b % 4>(cur, xx[b], c1, xsh[b / 4]);
+            if constexpr (xw == 2) c0 = mfma_cross6<b % 4>(cur8, xx[b], c0, xsh[b / 4]);
+            else if constexpr (xw == 3) c1 = mfma_cross6<b % 4>(cur8, xx[b], c1, xsh[b / 4]);
 #endif
 #else
             if constexpr (xw == 0) c0 = mfma_cross(cur, xl[b], c0, sc_h, SC_XL);
@@ -907,10 +923,10 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
 #pragma unroll
         for (int q4 = 0; q4 < 32; ++q4) {
             const f32x4 w = aw[q4];
-            s_alpha = fmaf(w.x, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 0]), s_alpha);
-            s_alpha = fmaf(w.y, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 1]), s_alpha);
-            s_alpha = fmaf(w.z, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 2]), s_alpha);
-            s_alpha = fmaf(w.w, relu_asm(acc[q4 >> 2][(q4 & 3) * 4 + 3]), s_alpha);
+            relu_fma(s_alpha, w.x, acc[q4 >> 2][(q4 & 3) * 4 + 0]);
+            relu_fma(s_alpha, w.y, acc[q4 >> 2][(q4 & 3) * 4 + 1]);
+            relu_fma(s_alpha, w.z, acc[q4 >> 2][(q4 & 3) * 4 + 2]);
+            relu_fma(s_alpha, w.w, acc[q4 >> 2][(q4 & 3) * 4 + 3]);
         }
     }
     out[3] = add_halves(s_alpha) + prm[P_AB];
@@ -946,16 +962,15 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         layer_phase<FR_VP, 4, 2, 2, false>(rg, prm + P_BV, v, ph, pl, pxx, psh, psl, scl[8], scl[9]);
     }
     // rgb_fc in fp32 on the VALU (outside the record loop for the same reason as alpha_fc)
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const f32x4 *rw = reinterpret_cast<const f32x4 *>(prm + P_RW + (ch * 2 + hi) * 64);
+    {
+        const f32x4 *rw0 = reinterpret_cast<const f32x4 *>(prm + P_RW + (0 * 2 + hi) * 64);
+        const f32x4 *rw1 = reinterpret_cast<const f32x4 *>(prm + P_RW + (1 * 2 + hi) * 64);
+        const f32x4 *rw2 = reinterpret_cast<const f32x4 *>(prm + P_RW + (2 * 2 + hi) * 64);
 #pragma unroll
         for (int q4 = 0; q4 < 16; ++q4) {
-            const f32x4 w = rw[q4];
-            s_rgb[ch] = fmaf(w.x, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 0]), s_rgb[ch]);
-            s_rgb[ch] = fmaf(w.y, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 1]), s_rgb[ch]);
-            s_rgb[ch] = fmaf(w.z, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 2]), s_rgb[ch]);
-            s_rgb[ch] = fmaf(w.w, relu_asm(v[q4 >> 2][(q4 & 3) * 4 + 3]), s_rgb[ch]);
+            const f32x4 w0 = rw0[q4], w1 = rw1[q4], w2 = rw2[q4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) relu_fma3(s_rgb[0], s_rgb[1], s_rgb[2], w0[e], w1[e], w2[e], v[q4 >> 2][(q4 & 3) * 4 + e]);
         }
     }
 #pragma unroll
