@@ -47,13 +47,13 @@ PRECISION_INFO = {
     "bf16x3": ("bf16", "nb_march16_kernel", 1944 * 32768 / 32.0, 2500.0),
     # M-split organisation of the same arithmetic: 4 waves x 984 MFMAs per 64 samples (encoding K padded to 128)
     "bf16x3s": ("bf16", "nb_march16s_kernel", 4 * 984 * 32768 / 64.0, 2500.0),
-    # fp16 main product (648 K=16 MFMAs per 32 samples) + 272 K=64 scaled 8-bit MFMAs for the two cross terms (the merged
-    # feature_fc.latent_fc layer runs without them); the 8-bit flops are counted at half weight (their dense peak is 2x the
-    # fp16 peak), i.e. in fp16-equivalent matrix-pipe time
-    "f16f8": ("f16+f8", "nb_march_f16_kernel", (648 * 32768 + 272 * 131072 / 2.0) / 32.0, 2500.0),
+    # fp16 main product (520 K=16 MFMAs per 32 samples: fc_0 176, fc_1 128, fc_2 128, the folded feature_fc/latent_fc/view_fc
+    # layer 64, view_fc over the encodings 24) + 272 K=64 scaled 8-bit MFMAs for the two cross terms; the 8-bit flops are
+    # counted at half weight (their dense peak is 2x the fp16 peak), i.e. in fp16-equivalent matrix-pipe time
+    "f16f8": ("f16+f8", "nb_march_f16_kernel", (520 * 32768 + 272 * 131072 / 2.0) / 32.0, 2500.0),
     # the same with the cross terms in 6 bits: a K=64 fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA
     # (profiles/r02_probe_mxrate.log), so it is counted as one (a quarter of its flops)
-    "f16f6": ("f16+f6", "nb_march_f6_kernel", (648 + 272) * 32768 / 32.0, 2500.0),
+    "f16f6": ("f16+f6", "nb_march_f6_kernel", (520 + 272) * 32768 / 32.0, 2500.0),
 }
 
 

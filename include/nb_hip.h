@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 12
+#define NB_ABI_VERSION 13
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -89,9 +89,9 @@ typedef struct nb_scene {
  * latent_index or the parameters change.
  * ------------------------------------------------------------------------------- */
 int64_t nb_mlp_pack_size(void);        /* floats in the packed blob */
-int64_t nb_mlp_latent_bias_size(void); /* floats in the per-frame bias (256) */
-/* Float offset inside the packed blob of 10 int32 counters written with the NB_PACK_F16F6 section: for each of the five
- * layers (fc_0, fc_1, fc_2, merged, view_fc) {small, nonzero} = how many non-zero weights lie below 1/8 of the maximum of
+int64_t nb_mlp_latent_bias_size(void); /* floats in the per-frame bias block (384: see nb_mlp_latent_bias) */
+/* Float offset inside the packed blob of 8 int32 counters written with the NB_PACK_F16F6 section: for each of the four
+ * layers of that kernel (fc_0, fc_1, fc_2, the folded feature_fc / latent_fc / view_fc layer) {small, nonzero} = how many non-zero weights lie below 1/8 of the maximum of
  * their (row, 32 K) block — where fp6 e2m3 keeps fewer than 3 significant bits — and how many are non-zero at all.
  * small / nonzero is ~0.2 for normally distributed weights; a caller that cannot rule out weight blocks with a wide
  * dynamic range (> ~2^5) uses it to fall back to NB_PREC_F16F8 (the Python Network does, precision "auto"). */
@@ -121,7 +121,9 @@ int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream);
 #define NB_PACK_ALL 31
 int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, void *stream);
 /* latent_row: dev pointer to latent.weight[latent_index] (128 floats);
- * out: dev, nb_mlp_latent_bias_size() floats. */
+ * out: dev, nb_mlp_latent_bias_size() floats = [256: bias of the merged feature_fc / latent_fc layer with the latent code
+ * folded in | 128: bias of view_fc with that layer folded in as well (feature_fc, latent_fc and view_fc have no activation
+ * between them, latent_xyzc.py:105-119; NB_PREC_F16F8 / NB_PREC_F16F6 run them as one layer)], MFMA fragment order. */
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------

@@ -400,15 +400,28 @@ __global__ void nb_pack_kernel(nb_mlp_params p, float *__restrict__ out) {
     out[e] = v;
 }
 
+// out[0..255]: bias of the merged feature_fc / latent_fc layer, MFMA fragment order [tile][hi][16];
+// out[256..383]: bias of view_fc with that whole (activation-free) layer pair folded in, i.e. view_b + view_w[:, :256] . (the
+// former), same order — for the kernels that run feature_fc, latent_fc and view_fc as ONE linear layer (nb_march_f16.hip)
 __global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__ latent_row, float *__restrict__ out) {
-    const int rel = blockIdx.x * blockDim.x + threadIdx.x;  // [t][hi][16]
-    if (rel >= 256) return;
+    __shared__ double lbn[256];  // natural order
+    const int rel = threadIdx.x;  // [t][hi][16]
+    {
+        const int row = rel;
+        double s = (double)p.latent_b[row];
+        for (int m = 0; m < 256; ++m) s += (double)p.latent_w[row * 384 + m] * (double)p.feature_b[m];
+        for (int m = 0; m < 128; ++m) s += (double)p.latent_w[row * 384 + 256 + m] * (double)latent_row[m];
+        lbn[row] = s;
+    }
+    __syncthreads();
     const int r = rel & 15, hi = (rel >> 4) & 1, t = rel >> 5;
     const int row = 32 * t + tile_row(r, hi);
-    double s = (double)p.latent_b[row];
-    for (int m = 0; m < 256; ++m) s += (double)p.latent_w[row * 384 + m] * (double)p.feature_b[m];
-    for (int m = 0; m < 128; ++m) s += (double)p.latent_w[row * 384 + 256 + m] * (double)latent_row[m];
-    out[rel] = (float)s;
+    out[rel] = (float)lbn[row];
+    if (rel < 128) {  // t < 4: the 128 outputs of view_fc
+        double s = (double)p.view_b[row];
+        for (int m = 0; m < 256; ++m) s += (double)p.view_w[row * 346 + m] * lbn[m];
+        out[256 + rel] = (float)s;
+    }
 }
 
 }  // namespace
@@ -418,7 +431,7 @@ extern "C" {
 static long long f16_stream_off() { return PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(); }
 static long long f6_stream_off() { return f16_stream_off() + nbm::f16_stream_floats(); }
 int64_t nb_mlp_pack_size(void) { return f6_stream_off() + nbm::f6_stream_floats(); }
-int64_t nb_mlp_latent_bias_size(void) { return 256; }
+int64_t nb_mlp_latent_bias_size(void) { return 384; }
 int64_t nb_mlp_six_bit_stats_offset(void) { return f6_stream_off() + nbm::f6_stream_floats() - 16; }
 
 static int check_params(const nb_mlp_params *p) {

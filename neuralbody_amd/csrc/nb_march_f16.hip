@@ -63,27 +63,25 @@ constexpr int FDMA_PER_WAVE = FPAGE_BYTES / 1024 / 4;  // 6
 // x = 0: a phase WITHOUT cross-term records (single fp16 product)
 __host__ __device__ constexpr int recs_per_pair(int nblk, int nch_last, int x = 1) { return (nblk - 1) * (4 + 4 * x) + nch_last + 4 * x; }
 __host__ __device__ constexpr int recs_phase(int nt, int nblk, int nch_last, int x = 1) { return (nt / 2) * recs_per_pair(nblk, nch_last, x); }
-// The merged feature_fc / latent_fc layer runs as a single fp16 product: its output only feeds the colour head, and the
-// measured sensitivity (profiles/r02_precision_sweep.md) leaves room for it (worst fixture 4.2e-5 of the 1e-4 budget
-// against 9e-6 with the cross terms); -DF_MERGED_X=1 restores the cross terms.
-#ifndef F_MERGED_X
-#define F_MERGED_X 0
-#endif
 // fc_0 is ONE phase over the 176 gathered values of a lane in the order [level 1 (32) | level 2 (64) | level 3 (64) |
 // level 0 (16) | 16 zeros] = 6 K-blocks, the last with 2 chunks (all four pyramid levels are gathered before the layer
-// starts: their tile fetches are in flight together, and the 184 records run without a gather in between)
+// starts: their tile fetches are in flight together, and the 184 records run without a gather in between).
+// feature_fc, latent_fc and view_fc have NO activation between them (latent_xyzc.py:105-119): they run as ONE linear layer
+// view_w[:, :256] . latent_w[:, :256] . feature_w (128 x 256, product formed in fp64 at pack time) over fc_2's output, plus
+// view_w[:, 256:] over the encodings; the per-frame latent code and all three biases are in nb_mlp_latent_bias()'s second
+// block.  (Rounds 1-2a ran feature_fc . latent_fc as a 256 x 256 layer of its own: 128 MFMAs, 64 records and one operand
+// conversion per depth step for nothing.)
 constexpr int FR_F0 = 0;
 constexpr int FR_L1 = FR_F0 + recs_phase(8, 6, 2);
 constexpr int FR_L2 = FR_L1 + recs_phase(8, 4, 4);
-constexpr int FR_L4 = FR_L2 + recs_phase(8, 4, 4);
-constexpr int FR_VG = FR_L4 + recs_phase(8, 4, 4, F_MERGED_X);   // view_fc over the merged layer's 256 outputs
+constexpr int FR_VG = FR_L2 + recs_phase(8, 4, 4);   // folded colour-head layer over fc_2's 256 outputs
 constexpr int FR_VP = FR_VG + recs_phase(4, 4, 4);   // view_fc over the 45 (x2 halves) positional-encoding slots, padded to 64
 constexpr int FN_RECS = FR_VP + recs_phase(4, 2, 2);
 constexpr int FN_RECS_PAD = (FN_RECS + 5 * FPAGE_RECS - 1) / (5 * FPAGE_RECS) * (5 * FPAGE_RECS);  // zero records up to a multiple of FN_SLOTS pages
-static_assert(FN_RECS == 596 + 64 * F_MERGED_X, "record count");
+static_assert(FN_RECS == 532, "record count");
 constexpr int FN_PAGES = FN_RECS_PAD / FPAGE_RECS;
 static_assert(FN_PAGES % FN_SLOTS == 0, "page p must always land in slot p % FN_SLOTS, also across the step wrap-around");
-constexpr int F_N_SCALES = 16;  // ints behind the stream: E8M0 scale operands (W_h, W_l) of fc_0, fc_1, fc_2, merged, view_fc
+constexpr int F_N_SCALES = 16;  // ints behind the stream: E8M0 scale operands (W_h, W_l) of fc_0, fc_1, fc_2, the folded view layer
 
 }  // namespace nbm
 
@@ -916,7 +914,7 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     // compiler-visible LDS read inside the record loop makes hipcc wait lgkmcnt(0), which drains the fragment prefetch
     // at every slice (measured with F_TIMING: fc_2 took 22.5k cycles against 13.3k for the identical fc_1).  It runs on
     // the finished accumulators before the tail conversion overwrites nothing it needs (acc stays intact).
-    layer_phase<FR_L2, 8, 4, 4, true, F_MERGED_X ? 1 : 4>(rg, prm + P_B2, acc, xh, xl, xx, xsh, xsl, scl[4], scl[5], &nx);
+    layer_phase<FR_L2, 8, 4, 4, true, 1>(rg, prm + P_B2, acc, xh, xl, xx, xsh, xsl, scl[4], scl[5], &nx);
     float s_alpha = 0.f;
     {
         const f32x4 *aw = reinterpret_cast<const f32x4 *>(prm + P_AW + hi * 128);
@@ -932,13 +930,12 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     out[3] = add_halves(s_alpha) + prm[P_AB];
     F_STAMP(15);
     ops_from<8>(nx, xh, xl, xx, xsh, xsl);
-    layer_phase<FR_L4, 8, 4, 4, true, 2, NoExtra, F_MERGED_X>(rg, prm + P_LB, acc, xh, xl, xx, xsh, xsl, scl[6], scl[7], &nx);
     F_STAMP(16);
-    ops_from<8>(nx, xh, xl, xx, xsh, xsl);
-    // view_fc in two K phases: the 256 outputs of the merged latent layer, then the positional encodings; rgb_fc (fp32,
-    // VALU) rides on the finished tiles of the second phase
+    // the colour head's linear part as ONE layer in two K phases: the folded feature_fc / latent_fc / view_fc product over
+    // fc_2's 256 outputs (bias: the second block of nb_mlp_latent_bias), then view_fc over the positional encodings; rgb_fc
+    // (fp32, VALU) follows on the finished tiles
     f32x16 v[4];
-    layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_BV, v, xh, xl, xx, xsh, xsl, scl[8], scl[9]);
+    layer_phase<FR_VG, 4, 4, 4, true>(rg, prm + P_LB, v, xh, xl, xx, xsh, xsl, scl[6], scl[7]);
     F_STAMP(17);
     float s_rgb[3] = {0.f, 0.f, 0.f};
     {
@@ -959,7 +956,7 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
         make_operands<3, false>([&](int i) { return i < N_PE ? pe[i < N_PE ? i : 0] : 0.f; }, ph, pl, pxx);
 #endif
         F_STAMP(18);
-        layer_phase<FR_VP, 4, 2, 2, false>(rg, prm + P_BV, v, ph, pl, pxx, psh, psl, scl[8], scl[9]);
+        layer_phase<FR_VP, 4, 2, 2, false>(rg, prm + P_LB, v, ph, pl, pxx, psh, psl, scl[6], scl[7]);
     }
     // rgb_fc in fp32 on the VALU (outside the record loop for the same reason as alpha_fc)
     {
@@ -995,7 +992,7 @@ __device__ __forceinline__ FRing f_ring_begin(const float *pk, const float *lb, 
             if (i < P_B1) v = pk[F_OFF_B0 + i - P_B0];
             else if (i < P_B2) v = pk[F_OFF_B1 + i - P_B1];
             else if (i < P_LB) v = pk[F_OFF_B2 + i - P_B2];
-            else if (i < P_BV) v = lb[i - P_LB];
+            else if (i < P_BV) v = i - P_LB < 128 ? lb[256 + i - P_LB] : 0.f;  // bias of the folded view layer
             else if (i < P_AW) v = pk[F_OFF_BV + i - P_BV];
             else if (i < P_RW) v = pk[F_OFF_AW + i - P_AW];
             else if (i < P_AB) v = pk[F_OFF_RW + i - P_RW];
@@ -1123,7 +1120,7 @@ __global__ __launch_bounds__(256) void F_KERNEL(MarchArgs a, const char *stream)
 
 // ---------------------------------------------------------------- weight stream packing
 // weight of layer phase `ph` at (output row, operand element q of a lane with half index kg); 0 for padding
-// phases: 0 fc_0, 1 fc_1, 2 fc_2, 3 merged feature/latent layer, 4 view_fc over the merged outputs, 5 view_fc over the encodings
+// phases: 0 fc_0, 1 fc_1, 2 fc_2, 3 the folded colour-head layer over fc_2's outputs, 4 view_fc over the encodings
 __device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const float *f32_blob, int ph, int row, int q, int kg) {
     if (ph == 0) {  // fc_0: slots [level 1 | level 2 | level 3 | level 0 | zeros]
         int L, idx;
@@ -1137,17 +1134,21 @@ __device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const floa
     if (ph == 1) return p.fc1_w[row * 256 + col_hidden(q, kg)];
     if (ph == 2) return p.fc2_w[row * 256 + col_hidden(q, kg)];
     if (ph == 3) {
-        // merged latent_fc[:, :256] @ feature_fc from the fp32 section (computed in fp64 there): invert col_hidden
+        // view_w[:, :256] . (latent_w[:, :256] . feature_w): the inner product comes from the fp32 section (formed in fp64
+        // there, fragment order: invert col_hidden), the outer one is summed in fp64 here
         const int col = col_hidden(q, kg);
         const int tt = col >> 5, rr = col & 31, hi2 = (rr >> 2) & 1, r2 = (rr & 3) + 4 * (rr >> 3), q2 = 16 * tt + r2;
-        return f32_blob[F_OFF_L4 + (((row >> 5) * 32 + (q2 >> 2)) * 64 + (hi2 * 32 + (row & 31))) * 4 + (q2 & 3)];
+        double s = 0.0;
+        for (int m = 0; m < 256; ++m)
+            s += (double)p.view_w[row * 346 + m] *
+                 (double)f32_blob[F_OFF_L4 + (((m >> 5) * 32 + (q2 >> 2)) * 64 + (hi2 * 32 + (m & 31))) * 4 + (q2 & 3)];
+        return (float)s;
     }
-    if (ph == 4) return p.view_w[row * 346 + col_hidden(q, kg)];
     const int col = col_pe(q, kg);  // q >= 45 -> -1
     return col < 0 ? 0.f : p.view_w[row * 346 + col];
 }
-__device__ __forceinline__ int phase_layer(int ph) { return ph < 4 ? ph : 4; }
-constexpr int N_PHASES = 6;
+__device__ __forceinline__ int phase_layer(int ph) { return ph < 3 ? ph : 3; }
+constexpr int N_PHASES = 5, N_LAYERS = 4;
 
 struct PhaseGeom {
     int rec0, nt, nblk, nch_last, x;
@@ -1157,8 +1158,7 @@ __device__ __forceinline__ PhaseGeom phase_geom(int ph) {
         case 0: return {FR_F0, 8, 6, 2, 1};
         case 1: return {FR_L1, 8, 4, 4, 1};
         case 2: return {FR_L2, 8, 4, 4, 1};
-        case 3: return {FR_L4, 8, 4, 4, F_MERGED_X};
-        case 4: return {FR_VG, 4, 4, 4, 1};
+        case 3: return {FR_VG, 4, 4, 4, 1};
         default: return {FR_VP, 4, 2, 2, 1};
     }
 }
@@ -1166,10 +1166,10 @@ __device__ __forceinline__ PhaseGeom phase_geom(int ph) {
 // per layer: max |W_h| and max |W_l| -> largest power-of-two scales that keep the fp8 images inside +-448, stored as the
 // E8M0 operands (127 - exponent) the scaled MFMA needs to undo them; out[2 * layer] for W_h, out[2 * layer + 1] for W_l
 __global__ void nb_f16_scales_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, int *__restrict__ out) {
-    const int layer = blockIdx.x;  // fc_0, fc_1, fc_2, merged, view_fc
+    const int layer = blockIdx.x;  // fc_0, fc_1, fc_2, the folded view layer
     __shared__ float mh[256], ml[256];
     float a = 0.f, b = 0.f;
-    const int ph0 = layer, ph1 = layer < 4 ? layer + 1 : N_PHASES;  // view_fc = phases 4 and 5
+    const int ph0 = layer, ph1 = layer < 3 ? layer + 1 : N_PHASES;  // view layer = phases 3 and 4
     for (int ph = ph0; ph < ph1; ++ph) {
         const PhaseGeom g = phase_geom(ph);
         const int rows = 32 * g.nt, nq = 32 * g.nblk;
@@ -1346,7 +1346,7 @@ int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off,
     // small-element statistic the pack kernel accumulates
     NB_REQUIRE(hipMemsetAsync(scales, 0, F_N_SCALES * sizeof(int), st) == hipSuccess, "pack_f6_stream: hipMemsetAsync failed");
 #else
-    hipLaunchKernelGGL(nb_f16_scales_kernel, dim3(5), dim3(256), 0, st, *p, packed, scales);
+    hipLaunchKernelGGL(nb_f16_scales_kernel, dim3(N_LAYERS), dim3(256), 0, st, *p, packed, scales);
     NB_CHECK_LAUNCH("nb_f16_scales_kernel");
 #endif
     hipLaunchKernelGGL(nb_pack_f16_kernel, dim3(nb_ceil_div((long long)FN_RECS_PAD * 64, 256)), dim3(256), 0, st, *p, packed, scales, scales, stream);

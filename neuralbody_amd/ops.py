@@ -124,10 +124,11 @@ def mlp_pack(params, out=None, precisions=None):
 
 
 def six_bit_small_fraction(packed):
-    """Per layer (fc_0, fc_1, fc_2, merged, view_fc): the share of non-zero weights below 1/8 of their (row, 32 K)
-    block's maximum, counted while the 'f16f6' section was packed (nb_mlp_six_bit_stats_offset).  Device tensor [5]."""
+    """Per layer of the 'f16f6' kernel (fc_0, fc_1, fc_2, the folded feature_fc / latent_fc / view_fc layer): the share of
+    non-zero weights below 1/8 of their (row, 32 K) block's maximum, counted while that section was packed
+    (nb_mlp_six_bit_stats_offset).  Device tensor [4]."""
     off = int(_lib.lib().nb_mlp_six_bit_stats_offset())
-    c = packed[off:off + 10].view(torch.int32).reshape(5, 2).to(torch.float32)
+    c = packed[off:off + 8].view(torch.int32).reshape(4, 2).to(torch.float32)
     return c[:, 0] / c[:, 1].clamp_min(1.0)
 
 
@@ -135,9 +136,10 @@ def mlp_latent_bias(params, latent_row, out=None):
     p, keep = _mlp_params(params)
     latent_row = latent_row.detach()
     _req(latent_row, torch.float32, (128,), "latent_row")
+    n = int(_lib.lib().nb_mlp_latent_bias_size())
     if out is None:
-        out = torch.empty(256, dtype=torch.float32, device=latent_row.device)
-    _req(out, torch.float32, (256,), "latent_bias")
+        out = torch.empty(n, dtype=torch.float32, device=latent_row.device)
+    _req(out, torch.float32, (n,), "latent_bias")
     check(_lib.lib().nb_mlp_latent_bias(C.byref(p), ptr(latent_row), ptr(out), _stream()), "nb_mlp_latent_bias")
     return out
 
@@ -150,7 +152,7 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
     n = wpts.shape[0]
     if not density_only:
         _req(viewdir, torch.float32, (n, 3), "viewdir")
-        _req(latent_bias, torch.float32, (256,), "latent_bias")
+        _req(latent_bias, torch.float32, (int(_lib.lib().nb_mlp_latent_bias_size()),), "latent_bias")
     out = torch.empty((n, 1 if density_only else 4), dtype=torch.float32, device=wpts.device)
     dbg = torch.zeros((n, DBG_WIDTH), dtype=torch.float32, device=wpts.device) if debug else None
     check(_lib.lib().nb_decode_points(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(wpts), ptr(viewdir), n,
@@ -164,7 +166,7 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
     """nb_march: all rays of one batch element -> dict of per-ray outputs."""
     sc, _keep = scene
     _req(packed, torch.float32, (mlp_pack_size(),), "packed")
-    _req(latent_bias, torch.float32, (256,), "latent_bias")
+    _req(latent_bias, torch.float32, (int(_lib.lib().nb_mlp_latent_bias_size()),), "latent_bias")
     _req(ray_o, torch.float32, (None, 3), "ray_o")
     n = ray_o.shape[0]
     _req(ray_d, torch.float32, (n, 3), "ray_d")
