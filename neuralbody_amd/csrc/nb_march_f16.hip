@@ -8,6 +8,7 @@
 //            + fp8(W_h 2^a).bf8(X_l 2^12) 2^-(a+12)      v_mfma_scale_f32_32x32x64_f8f6f4   (K = 64 per instruction; the
 //            + fp8(W_l 2^b).bf8(X_h)      2^-b            E8M0 scale operands undo the 2^k)
 //
+// (feature_fc, latent_fc and view_fc are folded into one layer at pack time, see the stream geometry below.)
 // The cross terms are 2^-11 of the main term, so 3-4 significant bits are enough for them: ~2^-15 relative error per
 // term (round 1's three bf16 products: 2^-16) at 1.8 instead of 3 matrix-pipe units — on MI355X the K=64 scaled 8-bit
 // MFMA costs 1.6x a K=16 fp16 MFMA (profiles/r02_probe_filler.log).  Activations use bf8 e5m2 (fp16's exponent range:
@@ -60,9 +61,8 @@ constexpr int FN_SLOTS = 5;
 constexpr int FAHEAD = FN_SLOTS - 1;
 constexpr int FDMA_PER_WAVE = FPAGE_BYTES / 1024 / 4;  // 6
 
-// x = 0: a phase WITHOUT cross-term records (single fp16 product)
-__host__ __device__ constexpr int recs_per_pair(int nblk, int nch_last, int x = 1) { return (nblk - 1) * (4 + 4 * x) + nch_last + 4 * x; }
-__host__ __device__ constexpr int recs_phase(int nt, int nblk, int nch_last, int x = 1) { return (nt / 2) * recs_per_pair(nblk, nch_last, x); }
+__host__ __device__ constexpr int recs_per_pair(int nblk, int nch_last) { return (nblk - 1) * 8 + nch_last + 4; }
+__host__ __device__ constexpr int recs_phase(int nt, int nblk, int nch_last) { return (nt / 2) * recs_per_pair(nblk, nch_last); }
 // fc_0 is ONE phase over the 176 gathered values of a lane in the order [level 1 (32) | level 2 (64) | level 3 (64) |
 // level 0 (16) | 16 zeros] = 6 K-blocks, the last with 2 chunks (all four pyramid levels are gathered before the layer
 // starts: their tile fetches are in flight together, and the 184 records run without a gather in between).
@@ -478,10 +478,7 @@ __device__ __forceinline__ void pack_exps(const int (&eb)[NB], int (&sh)[(NB + 3
 // MFMAs: 8 slices of 4 values (relu, fp16 head, remainder, two 8-bit packs: ~14 VALU) per tile, one slice behind each of
 // the first 16 records of the next pair, fenced in place with sched_barrier (fillers placed like this are ~70 % hidden,
 // anything left to the scheduler clusters after the MFMAs: profiles/r02_probe_filler.log).  Only the last pair's
-// conversion stays exposed.  `Extra` rides on every slice with the 4 (activated) values: alpha_fc / rgb_fc partial sums.
-struct NoExtra {
-    __device__ __forceinline__ void operator()(int, int, float, float) const {}
-};
+// conversion stays exposed.
 struct NextOps8 {  // operands of the next layer being assembled word by word
     unsigned h[64];
     int l[32], x[32];
@@ -613,15 +610,13 @@ __device__ __forceinline__ void ops_from(const NextOps8 &o, f16x8 (&xh)[2 * NT8]
 
 // acc[NT] (+)= W[:, K range of this phase] . X, X given as NBLK blocks (4 fp16 chunks + bf8 remainder + bf8 value each; the
 // last block may carry only NCH_LAST chunks).  sc_h / sc_l: E8M0 scale operands of W_h / W_l for this layer.
-// CV: 0 = leave the result in acc; 1 / 2 = convert finished tiles into `out` with / without relu (in-flight, see above);
-// 3 = no conversion, but `extra` still sees the relu'd values of every finished tile (rgb_fc over view_fc's output).
-template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT, int CV = 0, class Extra = NoExtra, int XT = 1>
+// CV: 0 = leave the result in acc; 1 = relu and convert the finished tiles into the next layer's operands `out` (in flight, see above).
+template <int REC0, int NT, int NBLK, int NCH_LAST, bool INIT, int CV = 0>
 __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f32x16 (&acc)[NT], const f16x8 *xh, const XB *xl,
                                             const XB *xx, const int *xsh, const int *xsl, int sc_h, int sc_l, NextOps *out = nullptr,
-                                            Extra &&extra = Extra(), unsigned *trace = nullptr) {
+                                            unsigned *trace = nullptr) {
     const int hi = rg.lane >> 5;
-    constexpr int RPP = recs_per_pair(NBLK, NCH_LAST, XT);
-    constexpr int BR = 4 + 4 * XT;  // records per full block
+    constexpr int RPP = recs_per_pair(NBLK, NCH_LAST);
     constexpr int NREC = (NT / 2) * RPP;
     constexpr int SC_XL = 127 - LO_SHIFT, SC_ONE = 127;
     // In-flight conversion: the 32 values a lane holds of the PREVIOUS pair are converted in 32 half-slices (16 when only the
@@ -629,7 +624,7 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
     // issue slot per 4 cycles: a 32-cycle fp16 MFMA hides ~5 other instructions, a 51-cycle 8-bit one ~10), and whole
     // slices behind the main records only (9 VALU + 2 fragment reads + wait + half a DMA piece per 2 MFMAs) overran that.
     constexpr int NMAIN = (NBLK - 1) * 4 + NCH_LAST;
-    constexpr int NH = CV == 4 ? 16 : 32;        // half-slices per pair
+    constexpr int NH = 32;                       // half-slices per pair
     constexpr int HPR = (NH + RPP - 1) / RPP;    // per record
     SliceRegs sr;
     // fragment reads run TWO records ahead of the MFMAs (one record = 64-100 matrix-pipe cycles, less than the LDS
@@ -658,14 +653,11 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
 #endif
     auto half_slice = [&](auto tpc, auto qc) {  // half-slice q of the pair tpp
         constexpr int tpp = decltype(tpc)::value, q = decltype(qc)::value;
-        constexpr int sl = CV == 4 ? q : q / 2, half = CV == 4 ? 0 : q % 2;
+        constexpr int sl = q / 2, half = q % 2;
         constexpr int tt = sl / 8, t = 2 * tpp + tt, P = sl % 8;
 #if F_SIX
-        if constexpr (CV == 4) {  // heads only
-            cv_half_a<true>(acc[t][2 * P], acc[t][2 * P + 1], sr);
-            out->hv[tpp][8 * tt + P] = sr.h;
-        } else if constexpr (half == 0) {
-            cv6_half_a<CV != 2>(acc[t][2 * P], acc[t][2 * P + 1], sr);
+        if constexpr (half == 0) {
+            cv6_half_a<true>(acc[t][2 * P], acc[t][2 * P + 1], sr);
         } else {
             float r0, r1;
             cv6_half_b(sr, mx, r0, r1);
@@ -688,7 +680,7 @@ __device__ __forceinline__ void layer_phase(const FRing &rg, const float *bp, f3
         }
 #else
         if constexpr (half == 0) {
-            cv_half_a<CV != 2>(acc[t][2 * P], acc[t][2 * P + 1], sr);
+            cv_half_a<true>(acc[t][2 * P], acc[t][2 * P + 1], sr);
             out->h[8 * t + P] = sr.h;
         } else {
             cv_half_b<(P & 1)>(sr, out->l[4 * t + P / 2], out->x[4 * t + P / 2]);
@@ -904,7 +896,7 @@ __device__ __forceinline__ void decode_f16(const SceneDev &sc, const FRing &rg, 
     }
     ops_from<8>(nx, xh, xl, xx, xsh, xsl);
 #ifdef F_TIMING  // per-record trace of fc_1
-    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, xsh, xsl, scl[2], scl[3], &nx, NoExtra(), tbuf ? tbuf0 + 8192 + 128 * ((tbuf - tbuf0) / 32) : nullptr);
+    layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, xsh, xsl, scl[2], scl[3], &nx, tbuf ? tbuf0 + 8192 + 128 * ((tbuf - tbuf0) / 32) : nullptr);
 #else
     layer_phase<FR_L1, 8, 4, 4, true, 1>(rg, prm + P_B1, acc, xh, xl, xx, xsh, xsl, scl[2], scl[3], &nx);
 #endif
@@ -1151,15 +1143,15 @@ __device__ __forceinline__ int phase_layer(int ph) { return ph < 3 ? ph : 3; }
 constexpr int N_PHASES = 5, N_LAYERS = 4;
 
 struct PhaseGeom {
-    int rec0, nt, nblk, nch_last, x;
+    int rec0, nt, nblk, nch_last;
 };
 __device__ __forceinline__ PhaseGeom phase_geom(int ph) {
     switch (ph) {
-        case 0: return {FR_F0, 8, 6, 2, 1};
-        case 1: return {FR_L1, 8, 4, 4, 1};
-        case 2: return {FR_L2, 8, 4, 4, 1};
-        case 3: return {FR_VG, 4, 4, 4, 1};
-        default: return {FR_VP, 4, 2, 2, 1};
+        case 0: return {FR_F0, 8, 6, 2};
+        case 1: return {FR_L1, 8, 4, 4};
+        case 2: return {FR_L2, 8, 4, 4};
+        case 3: return {FR_VG, 4, 4, 4};
+        default: return {FR_VP, 4, 2, 2};
     }
 }
 
@@ -1246,12 +1238,11 @@ __global__ void nb_pack_f16_kernel(nb_mlp_params p, const float *__restrict__ f3
             break;
         }
     const PhaseGeom g = phase_geom(ph);
-    const int rpp = recs_per_pair(g.nblk, g.nch_last, g.x), br = 4 + 4 * g.x;
+    const int rpp = recs_per_pair(g.nblk, g.nch_last);
     const int rel = rec - g.rec0, tp = rel / rpp, j0 = rel % rpp;
     const int nmain = (g.nblk - 1) * 4 + g.nch_last;
     const bool is_main = j0 < nmain;
     const int b = is_main ? j0 / 4 : (j0 - nmain) / 4;  // main record j0 = chunk j0 of the phase; then 4 cross records per block
-    (void)br;
     unsigned w32[8];
     if (is_main) {  // main record: A16(c, t0) | A16(c, t1)
         const int c = j0;

@@ -174,9 +174,17 @@ def decode(sd, feat, wpts, viewdir, latent_index, mix):
     Wm = (Lw[:, :256] @ w["feature_fc.weight"].double()).float()
     lat = w["latent.weight"][latent_index].double().reshape(128)
     bm = (Lw[:, :256] @ w["feature_fc.bias"].double() + Lw[:, 256:] @ lat + w["latent_fc.bias"].double()).float()
-    g = mm(Wm, h, mix["merged"]) + bm[:, None]
     pe = torch.cat([orc.embed(viewdir, 4), orc.embed(wpts, 10)], -1).T
-    v = torch.relu(mm(w["view_fc.weight"], torch.cat([g, pe], 0), mix["view_fc"]) + w["view_fc.bias"][:, None])
+    if mix.get("fold"):
+        # what nb_march_f16.hip ships since the colour head was folded: view_w[:, :256] . latent_w[:, :256] . feature_w as ONE
+        # 128 x 256 layer over fc_2's output (product and bias formed in fp64), plus view_w[:, 256:] over the encodings
+        Vg = w["view_fc.weight"][:, :256].double()
+        W3 = (Vg @ Wm.double()).float()
+        b3 = (Vg @ bm.double() + w["view_fc.bias"].double()).float()
+        v = torch.relu(mm(W3, h, mix["view_fc"]) + mm(w["view_fc.weight"][:, 256:].contiguous(), pe, mix["view_fc"]) + b3[:, None])
+    else:
+        g = mm(Wm, h, mix["merged"]) + bm[:, None]
+        v = torch.relu(mm(w["view_fc.weight"], torch.cat([g, pe], 0), mix["view_fc"]) + w["view_fc.bias"][:, None])
     rgb = w["rgb_fc.weight"] @ v + w["rgb_fc.bias"][:, None]
     return torch.cat([rgb, alpha], 0).T
 
@@ -257,6 +265,10 @@ def main():
     print("| mix | " + " | ".join(data) + " | worst |")
     print("|---|" + "---|" * (len(data) + 1))
     if a.quick:
+        for sc in ("f16c8b", "f16c6"):
+            mix = {k: sc for k in LAYERS}
+            mix["fold"] = True
+            report("SHIPPED (folded colour head) %s" % ("f16f8" if sc == "f16c8b" else "f16f6"), mix)
         report("all bf16x3", {l: "bf16x3" for l in LAYERS})
         report("all f16c8s", {l: "f16c8s" for l in LAYERS})
         mix = {l: "f16c8s" for l in LAYERS}
@@ -282,10 +294,15 @@ def main():
             mix = {k: "bf16x3" for k in LAYERS}
             mix[l] = s
             report("bf16x3 except %s=%s" % (l, s), mix)
-    for sc in ("f16c8b", "f16c6"):  # the two shipped arithmetics: merged layer as a single fp16 product
+    for sc in ("f16c8b", "f16c6", "f16x1"):  # the shipped arithmetics (colour head folded into one layer), and what a single fp16 product would give there
+        mix = {k: ("f16c6" if sc == "f16x1" else sc) for k in LAYERS}
+        mix["view_fc"] = sc
+        mix["fold"] = True
+        report("SHIPPED (folded colour head) %s" % {"f16c8b": "f16f8", "f16c6": "f16f6", "f16x1": "f16f6 trunk, single fp16 product in the folded layer"}[sc], mix)
+    for sc in ("f16c8b", "f16c6"):  # before the fold: merged layer as a single fp16 product
         mix = {k: sc for k in LAYERS}
         mix["merged"] = "f16x1"
-        report("SHIPPED %s: %s, merged f16x1" % ("f16f8" if sc == "f16c8b" else "f16f6", sc), mix)
+        report("before the fold, %s: %s, merged f16x1" % ("f16f8" if sc == "f16c8b" else "f16f6", sc), mix)
     for trunk, head in itertools.product(("bf16x3", "f16c8", "f16x1"), ("f16x1", "bf16x1")):
         mix = {"fc_0": trunk, "fc_1": trunk, "fc_2": trunk, "merged": head, "view_fc": head}
         report("trunk %s / colour head %s" % (trunk, head), mix)
