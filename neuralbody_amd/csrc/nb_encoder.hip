@@ -187,13 +187,139 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_
     }
 }
 
+// ------------------------------------------------------------------ the same convolution on the 16-bit matrix pipe
+// Inference path (no backward record is kept): every operand as fp16 head + fp16 remainder and three products per K chunk
+// (A_hi.B_hi + A_hi.B_lo + A_lo.B_hi, fp32 accumulate) on v_mfma_f32_32x32x16_f16 — 8x the K per instruction and half the
+// cycles of v_mfma_f32_32x32x2_f32, and 16-byte operand loads instead of one float per lane per MFMA.  fp16, not bf16: the
+// operands are BatchNorm outputs and weights, O(1), so the 22 mantissa bits of an fp16 pair (relative error ~2^-21 per
+// product) come for free where a bf16 pair has 16; the first version used bf16 and drifted 2.2e-4 from the oracle over the
+// 17 layers.  The activated rows arrive ALREADY split from the producing BatchNorm kernel (two fp16 planes in the bytes of
+// one fp32 row matrix: [cap, C] heads | [cap, C] remainders), the weights from nb_enc_conv_pack16 in B-fragment order:
+// [offset][K chunk][channel tile][head, remainder][lane] x 8 fp16.
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));  // (the name predates the switch to fp16)
+typedef _Float16 nb_h16;
+#define NB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+__global__ void conv_pack16_kernel(const float *__restrict__ w, int cin, int cout, bf16x8 *__restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (((o * NC + c) * NTT + t) * 2 + part) * 64 + lane
+    const int nc = cin / 16, ntt = cout / 32;
+    if (idx >= (long long)27 * nc * ntt * 2 * 64) return;
+    const int lane = (int)(idx & 63), part = (int)((idx >> 6) & 1);
+    const long long q = idx >> 7;
+    const int t = (int)(q % ntt), c = (int)((q / ntt) % nc), o = (int)(q / ((long long)ntt * nc));
+    const int j = lane & 31, hi = lane >> 5;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = w[((size_t)o * cin + 16 * c + 8 * hi + e) * cout + 32 * t + j];
+        const nb_h16 h = (nb_h16)x;
+        v[e] = part ? (nb_h16)(x - (float)h) : h;
+    }
+    out[idx] = v;
+}
+
+// one wave = 32 output rows x NT tiles of 32 output channels (blockIdx.y selects the tile group)
+template <int CIN, int COUT, int NT>
+__global__ __launch_bounds__(256) void conv16_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
+                                                     const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
+                                                     const int *__restrict__ n_out, Dims go, int stride,
+                                                     const bf16x8 *__restrict__ wp, float *__restrict__ out_rows,
+                                                     double *__restrict__ stats) {
+    constexpr int NC = CIN / 16, NTT = COUT / 32;
+    const int ct = blockIdx.y * NT;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = *n_out;
+    const int row0 = wave * 32;
+    if (row0 >= n) return;  // wave-uniform
+    const int row = row0 + i;
+    const bool valid = row < n;
+    const int lin = valid ? out_lin[row] : 0;
+    const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // The wave has ~1.5 companions per SIMD on the deep levels, so nothing hides a dependent load chain (index -> row ->
+    // MFMA) but the wave itself: all 27 neighbour indices are fetched first, and the rows of offset o + 1 while offset o is
+    // multiplied (the fp32 kernel above pays ~9 k cycles per offset for what is 0.8 k cycles of MFMA work here).
+    int nbrs[27];
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
+        int nbr = -1;
+        if (valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
+            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+        nbrs[o] = nbr;
+    }
+    // A fragments: lane (row i, half hi) holds channels 16 c + 8 hi .. + 7 of its neighbour row (zeros when inactive)
+    auto load_rows = [&](int nbr, bf16x8 (&ah)[NC], bf16x8 (&al)[NC]) {
+        const size_t r = (size_t)(nbr >= 0 ? nbr : 0) * CIN + 8 * hi;
+        const bf16x8 *ph = reinterpret_cast<const bf16x8 *>(in_split + r);
+        const bf16x8 *pl = reinterpret_cast<const bf16x8 *>(in_split + in_plane + r);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            ah[c] = ph[2 * c];
+            al[c] = pl[2 * c];
+        }
+    };
+    bf16x8 ah[2][NC], al[2][NC];
+    load_rows(nbrs[0], ah[0], al[0]);
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+        if (o + 1 < 27) load_rows(nbrs[o + 1], ah[(o + 1) & 1], al[(o + 1) & 1]);
+        const int nbr = nbrs[o];
+        if (!__any(nbr >= 0)) continue;  // nothing active under this offset for the whole tile
+        const bf16x8 *wo = wp + (((size_t)o * NC * NTT + ct) * 2) * 64 + lane;
+        bf16x8 zero;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) zero[e] = (nb_h16)0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bf16x8 a_h = nbr >= 0 ? ah[o & 1][c] : zero, a_l = nbr >= 0 ? al[o & 1][c] : zero;  // row 0 was read for inactive lanes
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 bh = wo[((size_t)c * NTT + t) * 128], bl = wo[((size_t)c * NTT + t) * 128 + 64];
+                acc[t] = NB_MFMA16(a_h, bh, acc[t]);
+                acc[t] = NB_MFMA16(a_h, bl, acc[t]);
+                acc[t] = NB_MFMA16(a_l, bh, acc[t]);
+            }
+        }
+    }
+    // D fragment: lane (j = i, hi) holds channel (ct + t) * 32 + j of rows row0 + tile_row(r, hi)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = (ct + t) * 32 + i;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = row0 + tile_row(r, hi);
+            const float v = acc[t][r];
+            if (orow < n) {
+                out_rows[(size_t)orow * COUT + co] = v;
+                s += (double)v;
+                ss += (double)v * (double)v;
+            }
+        }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (hi == 0) {
+            atomicAdd(&stats[co], s);
+            atomicAdd(&stats[COUT + co], ss);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ BatchNorm1d + ReLU (+ .dense())
 __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__ n_rows, int C,
                                const double *__restrict__ stats, const float *__restrict__ gamma,
                                const float *__restrict__ beta, float *__restrict__ rmean,
                                float *__restrict__ rvar, int training, float eps, float momentum,
                                float *__restrict__ batch_stats, const int *__restrict__ rows_lin,
-                               float *__restrict__ dense, float *__restrict__ rows_out) {
+                               float *__restrict__ dense, float *__restrict__ rows_out, long long split_plane) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = *n_rows;
     if (batch_stats && idx <= C) {
@@ -229,7 +355,14 @@ __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__
     const float a = (float)(invstd * (double)gamma[c]);
     const float b = (float)((double)beta[c] - mean * invstd * (double)gamma[c]);
     const float y = fmaxf(fmaf(rows[idx], a, b), 0.f);
-    (rows_out ? rows_out : rows)[idx] = y;  // training keeps the raw conv output for the backward pass
+    if (split_plane > 0) {  // for nb_enc_conv16: fp16 head and remainder planes in the bytes of an fp32 row matrix
+        _Float16 *sp = reinterpret_cast<_Float16 *>(rows_out);
+        const _Float16 h = (_Float16)y;
+        sp[idx] = h;
+        sp[split_plane + idx] = (_Float16)(y - (float)h);
+    } else {
+        (rows_out ? rows_out : rows)[idx] = y;  // training keeps the raw conv output for the backward pass
+    }
     if (dense) dense[(size_t)rows_lin[r] * C + c] = y;
 }
 
@@ -346,9 +479,75 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
     const long long total = (long long)n_rows_max * c;
     const long long threads = total > c + 1 ? total : c + 1;
     hipLaunchKernelGGL(bn_relu_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_rows,
-                       c, stats, gamma, beta, running_mean, running_var, training, eps, momentum, batch_stats, rows_lin, dense, rows_out);
+                       c, stats, gamma, beta, running_mean, running_var, training, eps, momentum, batch_stats, rows_lin, dense, rows_out,
+                       0LL);
     NB_CHECK_LAUNCH("nb_enc_bn_relu");
     return NB_OK;
+}
+
+int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c, const double *stats,
+                         const float *gamma, const float *beta, float *running_mean, float *running_var, int training,
+                         float eps, float momentum, float *batch_stats, const int32_t *rows_lin, float *dense,
+                         uint16_t *rows_split, void *stream) {
+    NB_REQUIRE(rows && n_rows && gamma && beta && rows_split, "nb_enc_bn_relu_split: NULL pointer");
+    NB_REQUIRE(training ? stats != nullptr : (running_mean && running_var), "nb_enc_bn_relu_split: statistics missing");
+    NB_REQUIRE(!(training && momentum >= 0.f) || (running_mean && running_var && batch_stats),
+               "nb_enc_bn_relu_split: running statistics / batch_stats required to update them");
+    NB_REQUIRE(!dense || rows_lin, "nb_enc_bn_relu_split: rows_lin required with dense");
+    NB_REQUIRE(c > 0 && n_rows_max > 0, "nb_enc_bn_relu_split: bad sizes");
+    const long long total = (long long)n_rows_max * c;
+    const long long threads = total > c + 1 ? total : c + 1;
+    hipLaunchKernelGGL(bn_relu_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream,
+                       const_cast<float *>(rows), n_rows, c, stats, gamma, beta, running_mean, running_var, training, eps, momentum,
+                       batch_stats, rows_lin, dense, reinterpret_cast<float *>(rows_split), total);
+    NB_CHECK_LAUNCH("nb_enc_bn_relu_split");
+    return NB_OK;
+}
+
+int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, void *stream) {
+    NB_REQUIRE(weight && packed, "nb_enc_conv_pack16: NULL pointer");
+    NB_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 32 && cout % 32 == 0, "nb_enc_conv_pack16: channel pair %d -> %d", cin, cout);
+    const long long n = 27LL * (cin / 16) * (cout / 32) * 2 * 64;
+    hipLaunchKernelGGL(conv_pack16_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
+                       reinterpret_cast<bf16x8 *>(packed));
+    NB_CHECK_LAUNCH("nb_enc_conv_pack16");
+    return NB_OK;
+}
+
+int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *in_grid, const int32_t in_dhw[3],
+                  const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride,
+                  const uint16_t *wpacked, int32_t cin, int32_t cout, float *out_rows, double *stats, void *stream) {
+    NB_REQUIRE(in_split && in_grid && in_dhw && out_lin && n_out && out_dhw && wpacked && out_rows && stats,
+               "nb_enc_conv16: NULL pointer");
+    NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv16: stride %d", stride);
+    NB_REQUIRE(in_rows_cap > 0, "nb_enc_conv16: in_rows_cap %d", in_rows_cap);
+    hipStream_t st = (hipStream_t)stream;
+    const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]}, go = {out_dhw[0], out_dhw[1], out_dhw[2]};
+    NB_HIP(hipMemsetAsync(stats, 0, 2 * (size_t)cout * sizeof(double), st));
+    if (n_out_max <= 0) return NB_OK;
+    const long long plane = (long long)in_rows_cap * cin;
+    const int row_groups = (int)nb_ceil_div(n_out_max, 128);
+    // channel tiles per wave: all of them when the rows alone fill the chip (4 waves per group, 1024 SIMDs), else one per wave
+#define NB_CONV16_CASE(CI, CO)                                                                                              \
+    if (cin == CI && cout == CO) {                                                                                          \
+        constexpr int NTT = CO / 32;                                                                                        \
+        if (row_groups * 4 >= 2048 || NTT == 1)                                                                             \
+            hipLaunchKernelGGL((conv16_kernel<CI, CO, NTT>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, gi, \
+                               out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats);     \
+        else                                                                                                                \
+            hipLaunchKernelGGL((conv16_kernel<CI, CO, 1>), dim3(row_groups, NTT), dim3(256), 0, st, in_split, plane, in_grid, gi, \
+                               out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats);     \
+        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
+        return NB_OK;                                                                                                       \
+    }
+    NB_CONV16_CASE(32, 32)
+    NB_CONV16_CASE(32, 64)
+    NB_CONV16_CASE(64, 64)
+    NB_CONV16_CASE(64, 128)
+    NB_CONV16_CASE(128, 128)
+#undef NB_CONV16_CASE
+    nb_set_error("nb_enc_conv16: unsupported channel pair %d -> %d", cin, cout);
+    return NB_EINVAL;
 }
 
 int nb_enc_gather_codes(const float *codes, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,

@@ -32,6 +32,7 @@ ENCODER_BLOCKS = [
 DENSE_AFTER = ("conv1", "conv2", "conv3", "conv4")  # latent_xyzc.py:188-201
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
 DEFAULT_PRECISION = "auto"
+ENC_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # encoder convolutions with >= 32 input channels on the 16-bit matrix pipe
 SIX_BIT_MAX_SMALL = 0.5
 
 
@@ -65,6 +66,17 @@ class SparseConvNet(nn.Module):
         for name, cin, cout, n, stride in ENCODER_BLOCKS:
             setattr(self, name, _block(cin, cout, n, stride))
 
+    def _packed16(self, conv):
+        """fp16 head / remainder B fragments of one convolution's weight, rebuilt when the parameter changes (the entry
+        holds the storage it was packed from, so its address cannot be recycled under the key)."""
+        w = conv.weight.detach()
+        key = (w.untyped_storage(), w.data_ptr(), w._version)
+        old = getattr(conv, "_nb_packed16", None)
+        if old is None or old[0][0]._cdata != key[0]._cdata or old[0][1:] != key[1:]:
+            old = (key, ops.enc_conv_pack16(w))
+            conv._nb_packed16 = old
+        return old[1]
+
     def forward(self, codes, coord, out_sh, training, save=None):
         """codes [6890,16] fp32, coord [6890,3] int32 (d,h,w) -> 4 channels-last volumes [D,H,W,C].
         save: optional list that receives one record per conv+BN+ReLU layer (index structures, raw and activated
@@ -78,34 +90,50 @@ class SparseConvNet(nn.Module):
             save.append({"rows_vert": rows_vert, "n_rows": n_rows, "n_max": n_max})
         volumes = []
         bn_updates = []
-        for name, cin, cout, n, stride in ENCODER_BLOCKS:
+        # Inference (no backward record): convolutions with >= 32 input channels run on the 16-bit matrix pipe with split
+        # operands (ops.enc_conv16, three products, fp32 accumulation); their input rows then arrive as fp16 head / remainder
+        # planes written by the producing BatchNorm kernel.  NB_ENC_SPLIT=0 keeps every layer on the exact-fp32 MFMA kernel.
+        fast = save is None and ENC_SPLIT
+        layers = [(name, cin, cout, n, stride, j) for name, cin, cout, n, stride in ENCODER_BLOCKS for j in range(n)]
+        rows_are_split = False
+        for li, (name, cin, cout, n, stride, j) in enumerate(layers):
             block = getattr(self, name)
-            for j in range(n):
-                conv, bn = block[3 * j], block[3 * j + 1]
-                if stride == 2:
-                    out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw)
-                else:
-                    out_grid, out_lin, n_out, n_out_max, out_dhw = grid, rows_lin, n_rows, n_max, dhw
+            conv, bn = block[3 * j], block[3 * j + 1]
+            if stride == 2:
+                out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw)
+            else:
+                out_grid, out_lin, n_out, n_out_max, out_dhw = grid, rows_lin, n_rows, n_max, dhw
+            if rows_are_split:
+                new_rows, stats = ops.enc_conv16(rows, grid, dhw, out_lin, n_out, n_out_max, out_dhw, stride,
+                                                 self._packed16(conv), cin, cout)
+            else:
                 new_rows, stats = ops.enc_conv(rows, grid, dhw, out_lin, n_out, n_out_max, out_dhw, stride,
                                                conv.weight.detach())
-                dense = None
-                if name in DENSE_AFTER and j == n - 1:
-                    dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
-                    volumes.append(dense)
-                act = torch.empty_like(new_rows) if save is not None else None  # keep the raw conv output when saving
+            dense = None
+            if name in DENSE_AFTER and j == n - 1:
+                dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
+                volumes.append(dense)
+            next_split = fast and li + 1 < len(layers) and cout >= 32  # the consumer of these rows is an enc_conv16
+            act = torch.empty_like(new_rows) if save is not None else None  # keep the raw conv output when saving
+            if next_split:
+                new_rows, bstats = ops.enc_bn_relu_split(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
+                                                         bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
+                                                         momentum=bn.momentum if training else -1.0)
+            else:
                 bstats = ops.enc_bn_relu(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
                                          bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
                                          momentum=bn.momentum if training else -1.0,  # running stats updated in-kernel
                                          rows_out=act)
-                if save is not None:
-                    save.append({"conv": conv, "bn": bn, "stride": stride, "in_rows": rows, "in_grid": grid, "in_dhw": dhw,
-                                 "in_lin": rows_lin, "n_in": n_rows, "n_in_max": n_max, "out_grid": out_grid,
-                                 "out_lin": out_lin, "n_out": n_out, "n_out_max": n_out_max, "out_dhw": out_dhw,
-                                 "x": new_rows, "y": act, "bstats": bstats, "level": len(volumes) - 1 if dense is not None else None})
-                    new_rows = act
-                if training:
-                    bn_updates.append(bn.num_batches_tracked)
-                rows, grid, rows_lin, n_rows, n_max, dhw = new_rows, out_grid, out_lin, n_out, n_out_max, out_dhw
+            if save is not None:
+                save.append({"conv": conv, "bn": bn, "stride": stride, "in_rows": rows, "in_grid": grid, "in_dhw": dhw,
+                             "in_lin": rows_lin, "n_in": n_rows, "n_in_max": n_max, "out_grid": out_grid,
+                             "out_lin": out_lin, "n_out": n_out, "n_out_max": n_out_max, "out_dhw": out_dhw,
+                             "x": new_rows, "y": act, "bstats": bstats, "level": len(volumes) - 1 if dense is not None else None})
+                new_rows = act
+            if training:
+                bn_updates.append(bn.num_batches_tracked)
+            rows, grid, rows_lin, n_rows, n_max, dhw = new_rows, out_grid, out_lin, n_out, n_out_max, out_dhw
+            rows_are_split = next_split
         if training:
             torch._foreach_add_(bn_updates, 1)  # nn.BatchNorm1d bookkeeping, one fused launch
         return volumes

@@ -309,6 +309,57 @@ def enc_bn_relu(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, runn
     return batch_stats
 
 
+def enc_conv_pack16(weight):
+    """nb_enc_conv_pack16: spconv-layout fp32 weight -> fp16 head / remainder B fragments (int16 tensor)."""
+    _req(weight, torch.float32, (3, 3, 3, None, None), "conv weight")
+    cin, cout = int(weight.shape[3]), int(weight.shape[4])
+    packed = torch.empty(27 * cin * cout * 2, dtype=torch.int16, device=weight.device)
+    check(_lib.lib().nb_enc_conv_pack16(ptr(weight), cin, cout, ptr(packed), _stream()), "nb_enc_conv_pack16")
+    return packed
+
+
+def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, wpacked, cin, cout):
+    """nb_enc_conv16 on split rows (int16 [2, cap, Cin]: fp16 heads | remainders) -> (out_rows fp32, stats fp64)."""
+    _req(in_split, torch.int16, (2, None, cin), "in_split")
+    _req(wpacked, torch.int16, (27 * cin * cout * 2,), "wpacked")
+    _req(in_grid, torch.int32, tuple(int(s) for s in in_dhw), "in_grid")
+    _req(out_lin, torch.int32, (None,), "out_lin")
+    _req(n_out, torch.int32, (1,), "n_out")
+    if out_lin.shape[0] < n_out_max:
+        raise ValueError("out_lin shorter than n_out_max")
+    dev = in_split.device
+    out_rows = torch.empty((max(int(n_out_max), 1), cout), dtype=torch.float32, device=dev)
+    stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    check(_lib.lib().nb_enc_conv16(ptr(in_split), int(in_split.shape[1]), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out),
+                                   int(n_out_max), _i3(out_dhw), int(stride), ptr(wpacked), cin, cout, ptr(out_rows),
+                                   ptr(stats), _stream()), "nb_enc_conv16")
+    return out_rows, stats
+
+
+def enc_bn_relu_split(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, running_var, training, eps,
+                      rows_lin=None, dense=None, momentum=-1.0):
+    """nb_enc_bn_relu_split -> (rows_split int16 [2, n_rows_max, C], batch_stats)."""
+    c = int(rows.shape[1])
+    _req(rows, torch.float32, (None, c), "rows")
+    for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _req(t, torch.float32, (c,), nm)
+    if stats is not None:
+        _req(stats, torch.float64, (2 * c,), "stats")
+    if dense is not None:
+        _req(dense, torch.float32, (None, None, None, c), "dense")
+        _req(rows_lin, torch.int32, (None,), "rows_lin")
+    n_rows_max = max(int(n_rows_max), 1)
+    if rows.shape[0] < n_rows_max:
+        raise ValueError("rows shorter than n_rows_max")
+    split = torch.empty((2, n_rows_max, c), dtype=torch.int16, device=rows.device)
+    batch_stats = torch.empty(2 * c + 1, dtype=torch.float32, device=rows.device)
+    check(_lib.lib().nb_enc_bn_relu_split(ptr(rows), ptr(n_rows), n_rows_max, c, ptr(stats), ptr(gamma), ptr(beta),
+                                          ptr(running_mean), ptr(running_var), 1 if training else 0, float(eps),
+                                          float(momentum), ptr(batch_stats), ptr(rows_lin), ptr(dense), ptr(split),
+                                          _stream()), "nb_enc_bn_relu_split")
+    return split, batch_stats
+
+
 def enc_gather_codes(codes, rows_vert, n_rows, n_rows_max):
     _req(codes, torch.float32, (None, None), "codes")
     _req(rows_vert, torch.int32, (None,), "rows_vert")

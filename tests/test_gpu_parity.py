@@ -156,6 +156,32 @@ def test_network_forward_and_positional_encoding_tap():
     H.assert_close(pe, ref, 1e-6, "positional-encoding tap", rel=False)
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_encoder_split_fp16_convolutions_match_the_fp32_kernels(training, monkeypatch):
+    """Inference runs the >= 32-channel sparse convolutions on the 16-bit matrix pipe (nb_enc_conv16: head / remainder split,
+    three products); the exact-fp32 MFMA kernels (NB_ENC_SPLIT=0, and what the training path always uses) are the
+    reference here, the oracle comparison of the default path is test_encoder_matches_oracle_and_reference_probes."""
+    import neuralbody_amd.network as nw
+
+    r, sd, body, batch, cam, t_rand = scenes.build("full")
+    net = H.make_network(sd, DEV, training, "f32")
+    bd = H.device_batch(batch, DEV)
+    from neuralbody_amd.renderer import Renderer
+
+    sp = Renderer(net).prepare_sp_input(bd)
+    vols = {}
+    for split in (True, False):
+        monkeypatch.setattr(nw, "ENC_SPLIT", split)
+        net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)  # same BN running stats
+        with torch.no_grad():
+            vols[split] = [v.clone() for v in net.encode_sparse_voxels(sp)]
+    torch.cuda.synchronize()
+    for a, b in zip(vols[True], vols[False]):
+        assert a.shape == b.shape and float(b.abs().max()) > 0
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err <= 2e-5, err
+
+
 # ------------------------------------------------------------------------------------------- march
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ALL)

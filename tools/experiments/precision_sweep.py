@@ -181,7 +181,7 @@ def decode(sd, feat, wpts, viewdir, latent_index, mix):
         Vg = w["view_fc.weight"][:, :256].double()
         W3 = (Vg @ Wm.double()).float()
         b3 = (Vg @ bm.double() + w["view_fc.bias"].double()).float()
-        v = torch.relu(mm(W3, h, mix["view_fc"]) + mm(w["view_fc.weight"][:, 256:].contiguous(), pe, mix["view_fc"]) + b3[:, None])
+        v = torch.relu(mm(W3, h, mix["view_fc"]) + mm(w["view_fc.weight"][:, 256:].contiguous(), pe, mix.get("view_pe", mix["view_fc"])) + b3[:, None])
     else:
         g = mm(Wm, h, mix["merged"]) + bm[:, None]
         v = torch.relu(mm(w["view_fc.weight"], torch.cat([g, pe], 0), mix["view_fc"]) + w["view_fc.bias"][:, None])
@@ -265,6 +265,11 @@ def main():
     print("| mix | " + " | ".join(data) + " | worst |")
     print("|---|" + "---|" * (len(data) + 1))
     if a.quick:
+        for pe_s in ("f16x1", "f16x2w", "f16x2x"):
+            mix = {k: "f16c6" for k in LAYERS}
+            mix["fold"] = True
+            mix["view_pe"] = pe_s
+            report("folded f16f6, encodings part of view_fc as %s" % pe_s, mix)
         for sc in ("f16c8b", "f16c6"):
             mix = {k: sc for k in LAYERS}
             mix["fold"] = True
