@@ -21,6 +21,8 @@
 //   SparseConv3d(k=3,s=2,p=1): out[o] = sum_k W[k] . in[2 o - 1 + k], active where any input is
 //   BatchNorm1d(eps=1e-3) over ACTIVE rows, then ReLU;  .dense() -> zeros at inactive sites
 //   duplicate vertex coordinates: the LAST vertex wins; BN counts unique voxels
+#include <cstdlib>
+
 #include "nb_scan.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -313,6 +315,127 @@ __global__ __launch_bounds__(256) void conv16_kernel(const unsigned short *__res
     }
 }
 
+// The same with the weight slab of the current kernel offset SHARED through LDS by the four waves of a workgroup (128 output
+// rows x NT channel tiles): every B fragment is fetched from L2 once per workgroup instead of once per wave, by LDS-DMA
+// (one 1-KiB fragment = one global_load_lds_dwordx4, no registers), double buffered, one barrier per offset.  Used where the
+// per-wave kernel above is L2-bandwidth-bound: the 64- and 128-channel layers (1.4 GB of operand traffic per 128 -> 128 launch).
+typedef const void __attribute__((address_space(1))) *nb_gptr_t;
+typedef void __attribute__((address_space(3))) *nb_lptr_t;
+
+template <int CIN, int COUT, int NT>
+__global__ __launch_bounds__(256) void conv16_lds_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
+                                                         const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
+                                                         const int *__restrict__ n_out, Dims go, int stride,
+                                                         const bf16x8 *__restrict__ wp, float *__restrict__ out_rows,
+                                                         double *__restrict__ stats) {
+    constexpr int NC = CIN / 16, NTT = COUT / 32;
+    constexpr int NFRAG = NC * NT * 2;        // 1-KiB fragments of one offset's slab: [c][t][head, remainder]
+    constexpr int PER_WAVE = NFRAG / 4;       // DMAs per wave per offset
+    static_assert(NFRAG % 4 == 0, "slab must split evenly over the four waves");
+    __shared__ __attribute__((aligned(16))) char slab[2][NFRAG * 1024];
+    const int ct = blockIdx.y * NT;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = *n_out;
+    const int row0 = (blockIdx.x * 4 + wv) * 32;
+    if (blockIdx.x * 128 >= n) return;  // workgroup-uniform: every wave of a live workgroup takes part in the barriers
+    const int row = row0 + i;
+    const bool valid = row < n;
+    const int lin = valid ? out_lin[row] : 0;
+    const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto issue_slab = [&](int o, int buf) {  // this wave's share of offset o's fragments -> slab[buf]
+#pragma unroll
+        for (int q = 0; q < PER_WAVE; ++q) {
+            const int f = wv * PER_WAVE + q;           // local fragment (c, t, part) = ((c * NT) + t) * 2 + part
+            const int c = f / (NT * 2), rest = f % (NT * 2);
+            const bf16x8 *src = wp + (((size_t)o * NC + c) * NTT + ct) * 2 * 64 + (size_t)rest * 64 + lane;
+            __builtin_amdgcn_global_load_lds((nb_gptr_t)src, (nb_lptr_t)(slab[buf] + f * 1024), 16, 0, 0);
+        }
+    };
+    int nbrs[27];
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
+        int nbr = -1;
+        if (valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
+            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+        nbrs[o] = nbr;
+    }
+    auto load_rows = [&](int nbr, bf16x8 (&ah)[NC], bf16x8 (&al)[NC]) {
+        const size_t r = (size_t)(nbr >= 0 ? nbr : 0) * CIN + 8 * hi;
+        const bf16x8 *ph = reinterpret_cast<const bf16x8 *>(in_split + r);
+        const bf16x8 *pl = reinterpret_cast<const bf16x8 *>(in_split + in_plane + r);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            ah[c] = ph[2 * c];
+            al[c] = pl[2 * c];
+        }
+    };
+    bf16x8 ah[2][NC], al[2][NC];
+    issue_slab(0, 0);
+    load_rows(nbrs[0], ah[0], al[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int o = 0; o < 27; ++o) {
+        if (o + 1 < 27) {
+            issue_slab(o + 1, (o + 1) & 1);  // the other buffer: its last readers passed the barrier that ended offset o - 1
+            load_rows(nbrs[o + 1], ah[(o + 1) & 1], al[(o + 1) & 1]);
+        }
+        const int nbr = nbrs[o];
+        if (__any(nbr >= 0)) {
+            const bf16x8 *sl = reinterpret_cast<const bf16x8 *>(slab[o & 1]) + lane;
+            bf16x8 zero;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zero[e] = (nb_h16)0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bf16x8 a_h = nbr >= 0 ? ah[o & 1][c] : zero, a_l = nbr >= 0 ? al[o & 1][c] : zero;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 bh = sl[((c * NT + t) * 2) * 64], bl = sl[((c * NT + t) * 2 + 1) * 64];
+                    acc[t] = NB_MFMA16(a_h, bh, acc[t]);
+                    acc[t] = NB_MFMA16(a_h, bl, acc[t]);
+                    acc[t] = NB_MFMA16(a_l, bh, acc[t]);
+                }
+            }
+        }
+        if (o + 1 < 27) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of slab o + 1 (and the prefetched rows) have landed
+            __syncthreads();                                  // ... everybody's have, and everybody is done reading slab o
+        }
+    }
+    if (row0 >= n) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = (ct + t) * 32 + i;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = row0 + tile_row(r, hi);
+            const float v = acc[t][r];
+            if (orow < n) {
+                out_rows[(size_t)orow * COUT + co] = v;
+                s += (double)v;
+                ss += (double)v * (double)v;
+            }
+        }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (hi == 0) {
+            atomicAdd(&stats[co], s);
+            atomicAdd(&stats[COUT + co], ss);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ BatchNorm1d + ReLU (+ .dense())
 __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__ n_rows, int C,
                                const double *__restrict__ stats, const float *__restrict__ gamma,
@@ -528,6 +651,26 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
     const long long plane = (long long)in_rows_cap * cin;
     const int row_groups = (int)nb_ceil_div(n_out_max, 128);
     // channel tiles per wave: all of them when the rows alone fill the chip (4 waves per group, 1024 SIMDs), else one per wave
+    static const bool use_lds = getenv("NB_CONV16_NO_LDS") == nullptr;  // experiment switch
+    // 64- and 128-channel layers: weight slab shared through LDS (measured slower for the 32-channel ones: 35 vs 29 us); all channel tiles per wave when the rows alone give >= 512
+    // workgroups, else two per wave (128 x 64-channel workgroups)
+#define NB_CONV16_LDS_CASE(CI, CO)                                                                                          \
+    if (use_lds && cin == CI && cout == CO) {                                                                               \
+        constexpr int NTT = CO / 32;                                                                                        \
+        if (row_groups >= 512 || NTT <= 2)                                                                                  \
+            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, NTT>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, \
+                               gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, (NTT >= 2 ? 2 : 1)>), dim3(row_groups, NTT >= 2 ? NTT / 2 : 1), dim3(256), 0, st, in_split, plane, \
+                               in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,     \
+                               stats);                                                                                      \
+        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
+        return NB_OK;                                                                                                       \
+    }
+    NB_CONV16_LDS_CASE(64, 64)
+    NB_CONV16_LDS_CASE(64, 128)
+    NB_CONV16_LDS_CASE(128, 128)
+#undef NB_CONV16_LDS_CASE
 #define NB_CONV16_CASE(CI, CO)                                                                                              \
     if (cin == CI && cout == CO) {                                                                                          \
         constexpr int NTT = CO / 32;                                                                                        \
