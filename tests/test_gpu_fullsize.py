@@ -31,13 +31,21 @@ def _check(size, n_samples, n_check, precision):
     with torch.no_grad():
         ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=n_samples, training=True,
                          feature_volume=[v.detach().float().cpu().contiguous() for v in vols])
-    seld = sel.to(dev)
-    err = H.assert_close(out["rgb_map"][0, seld].cpu().numpy(), ref["rgb_map"][0].numpy(), H.RGB_TOL, "rgb_map", rel=False)
-    H.assert_close(out["acc_map"][0, seld].cpu().numpy(), ref["acc_map"][0].numpy(), 2e-4, "acc_map")
-    H.assert_close(out["weights"][0, seld].cpu().numpy(), ref["weights"][0].numpy(), 2e-4, "weights")
-    H.assert_close(out["depth_map"][0, seld].cpu().numpy(), ref["depth_map"][0].numpy(), 2e-4, "depth_map")
+    # The last sample of a ray has the interval 1e10 (raw2outputs, nerf_net_utils.py:28): its alpha is 0 or 1 by the SIGN of its
+    # density.  A ray whose last density is within bench.ILL_SIGMA of zero is ill-conditioned for ANY arithmetic (one of the 4096
+    # bench rays has sigma_last = 2.3e-4); such rays are left out, and there must be very few of them.
+    sigma_last = ref["raw"][0].reshape(n_check, n_samples, 4)[:, -1, 3]
+    ok = (sigma_last.abs() >= bench.ILL_SIGMA)
+    assert int((~ok).sum()) <= n_check // 200, "too many ill-conditioned rays: %d" % int((~ok).sum())
+    okd = ok.to(dev)
+    seld = sel.to(dev)[okd]
+    okn = ok.numpy()
+    err = H.assert_close(out["rgb_map"][0, seld].cpu().numpy(), ref["rgb_map"][0].numpy()[okn], H.RGB_TOL, "rgb_map", rel=False)
+    H.assert_close(out["acc_map"][0, seld].cpu().numpy(), ref["acc_map"][0].numpy()[okn], 2e-4, "acc_map")
+    H.assert_close(out["weights"][0, seld].cpu().numpy(), ref["weights"][0].numpy()[okn], 2e-4, "weights")
+    H.assert_close(out["depth_map"][0, seld].cpu().numpy(), ref["depth_map"][0].numpy()[okn], 2e-4, "depth_map")
     assert float(ref["rgb_map"].max() - ref["rgb_map"].min()) > 0.1, "degenerate view"
-    print("%dx%dx%d %s: rgb L-inf of %d rays vs oracle %.2e" % (size, size, n_samples, precision, n_check, err))
+    print("%dx%dx%d %s: rgb L-inf of %d rays vs oracle %.2e (%d ill-conditioned rays left out)" % (size, size, n_samples, precision, int(ok.sum()), err, int((~ok).sum())))
     return err
 
 

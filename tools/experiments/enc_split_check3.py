@@ -1,0 +1,34 @@
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench
+from oracle import neuralbody_oracle as orc
+dev = torch.device("cuda:0")
+sd, body, net, rend, bd, n = bench.build_scene(dev, 512, 512, 64, "f16f6")
+pose = bench.build_poses(dev, body, bd, 512, 512, n_poses=2)[1]
+sp = rend.prepare_sp_input(pose)
+with torch.no_grad():
+    vols = net.encode_sparse_voxels(sp)
+    sel = torch.linspace(0, n - 1, 4096).long().to(dev)
+    m = net.render_rays(pose["ray_o"][0][sel].contiguous(), pose["ray_d"][0][sel].contiguous(), pose["near"][0][sel].contiguous(),
+                        pose["far"][0][sel].contiguous(), vols, sp, 64, want_raw=True)
+torch.cuda.synchronize()
+b = {k: v.detach().cpu() for k, v in pose.items()}
+s = sel.cpu()
+b.update(ray_o=b["ray_o"][:, s], ray_d=b["ray_d"][:, s], near=b["near"][:, s], far=b["far"][:, s])
+with torch.no_grad():
+    ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=64, training=True,
+                     feature_volume=[v.detach().float().cpu().contiguous() for v in vols], return_raw=True) if "return_raw" in orc.render.__code__.co_varnames else None
+if ref is None:
+    with torch.no_grad():
+        ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=64, training=True, feature_volume=[v.detach().float().cpu().contiguous() for v in vols])
+err = (m["rgb_map"].cpu() - ref["rgb_map"][0]).abs().max(1).values
+k = int(err.argmax())
+print("worst ray %d: rgb err %.3e ; second worst %.3e" % (k, float(err[k]), float(err.sort().values[-2])))
+raw = m["raw"].cpu()[k]
+print("GPU sigma of that ray, last 6 samples:", raw[-6:, 3].numpy())
+w_gpu, w_ref = m["weights"].cpu()[k], ref["weights"][0][k]
+print("weights last 4 GPU:", w_gpu[-4:].numpy(), " oracle:", w_ref[-4:].numpy())
+print("acc GPU %.6f oracle %.6f" % (float(m["acc_map"].cpu()[k]), float(ref["acc_map"][0][k])))
