@@ -55,14 +55,27 @@ class Renderer:
         idx = torch.cat(idx).to(batch["coord"])
         coord = batch["coord"].view(-1, sh[-1])
         sp_input["coord"] = torch.cat([idx[:, None], coord], dim=1)
-        out_sh, _ = torch.max(batch["out_sh"], dim=0)
-        sp_input["out_sh"] = out_sh.tolist()  # one host sync per render(), as in the reference (:40-41)
+        sp_input["out_sh"] = self._host_out_sh(batch["out_sh"])
         sp_input["batch_size"] = sh[0]
         sp_input["bounds"] = batch["bounds"]
         sp_input["R"] = batch["R"]
         sp_input["Th"] = batch["Th"]
         sp_input["latent_index"] = batch["latent_index"]
         return sp_input
+
+    def _host_out_sh(self, t):
+        """max over the batch of out_sh as a host list (if_clight_renderer.py:40-41: one device -> host sync per render() when
+        the tensor lives on the device).  The last answer is kept together with the tensor OBJECT it was read from (identity
+        and version, the entry holds the tensor so its address cannot be recycled): a caller that renders many views of one
+        frame from the same batch tensors does not stall the launch queue on every view; a DataLoader loop, which makes fresh
+        tensors per frame, syncs once per frame like the reference."""
+        c = getattr(self, "_out_sh_cache", None)
+        if c is not None and c[0] is t and c[1] == t._version:
+            return list(c[2])
+        out_sh, _ = torch.max(t, dim=0)
+        val = out_sh.tolist()
+        self._out_sh_cache = (t, t._version, val)
+        return list(val)
 
     # -- if_clight_renderer.py:54-60
     def get_density_color(self, wpts, viewdir, raw_decoder):
@@ -143,6 +156,16 @@ class Renderer:
         # for another frame's mask while the entry lives (round 1 keyed on data_ptr/_version, which a freed-and-
         # reallocated batch reproduces).  A caller that rewrites the same tensor in place through a raw pointer
         # (nb_raygen) bumps nothing, so the frame token `batch.get("frame_token")` is part of the key when given.
+        if n_pixel == int(H) * int(W):
+            # every pixel of the image is a ray (in pixel order: the list is the mask's non-zeros): the permutation depends on
+            # the image geometry only — no torch.nonzero (a host sync) and no argsort per view
+            full = getattr(self, "_order_full", None)
+            if full is None:
+                full = self._order_full = {}
+            key = (int(H), int(W), b, e, str(mask.device))
+            if key not in full:
+                full[key] = ops.tile_order(torch.arange(b, e, device=mask.device), int(W))
+            return full[key]
         cached = getattr(self, "_order_cache", None)
         token = batch.get("frame_token")
         if cached is not None and cached[0] is mask and cached[1] == (mask._version, int(W), b, e, token):
