@@ -10,8 +10,8 @@
 //
 // (feature_fc, latent_fc and view_fc are folded into one layer at pack time, see the stream geometry below.)
 // The cross terms are 2^-11 of the main term, so 3-4 significant bits are enough for them: ~2^-15 relative error per
-// term (round 1's three bf16 products: 2^-16) at 1.8 instead of 3 matrix-pipe units — on MI355X the K=64 scaled 8-bit
-// MFMA costs 1.6x a K=16 fp16 MFMA (profiles/r02_probe_filler.log).  Activations use bf8 e5m2 (fp16's exponent range:
+// term (round 1's three bf16 products: 2^-16) at 1.94 instead of 3 matrix-pipe units — on MI355X the K=64 scaled 8-bit
+// MFMA costs 1.88x a K=16 fp16 MFMA (28.7 vs 15.3 ns, profiles/r02_probe_mxrate.log).  Activations use bf8 e5m2 (fp16's exponent range:
 // nothing to clamp), weights fp8 e4m3 with one power-of-two scale per layer chosen at pack time from max|W_h|, max|W_l|
 // (nb_f16_scales_kernel).  Operand layout of the scaled MFMA (probed, profiles/r02_probe_mx.log): lane l holds
 // row/column l%32 and K elements 32*(l/32)..+31 in its 8 registers, little endian; the scale byte of lane l applies to
