@@ -166,7 +166,14 @@ def decode(sd, feat, wpts, viewdir, latent_index, mix):
     nb_mlp_pack (fp64 product rounded to fp32, latent folded into the bias)."""
     w = {k: v[..., 0] if v.dim() == 3 else v for k, v in sd.items()}
     x = feat.T
-    h = torch.relu(mm(w["fc_0.weight"], x, mix["fc_0"]) + w["fc_0.bias"][:, None])
+    if "fc_0_levels" in mix:  # per pyramid level (32 | 64 | 128 | 128 input channels) schemes for fc_0
+        acc, c0 = 0.0, 0
+        for nch, sch in zip((32, 64, 128, 128), mix["fc_0_levels"]):
+            acc = acc + mm(w["fc_0.weight"][:, c0:c0 + nch].contiguous(), x[c0:c0 + nch].contiguous(), sch)
+            c0 += nch
+        h = torch.relu(acc + w["fc_0.bias"][:, None])
+    else:
+        h = torch.relu(mm(w["fc_0.weight"], x, mix["fc_0"]) + w["fc_0.bias"][:, None])
     h = torch.relu(mm(w["fc_1.weight"], h, mix["fc_1"]) + w["fc_1.bias"][:, None])
     h = torch.relu(mm(w["fc_2.weight"], h, mix["fc_2"]) + w["fc_2.bias"][:, None])
     alpha = w["alpha_fc.weight"] @ h + w["alpha_fc.bias"][:, None]
@@ -244,6 +251,7 @@ def main():
     ap.add_argument("--wide", action="store_true", help="also run the wide-dynamic-range weights variant")
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true", help="only the candidate shipping mixes")
+    ap.add_argument("--levels", action="store_true", help="fc_0 sensitivity per pyramid level (one or both cross terms dropped)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     names = list(scenes.SCENES)
@@ -264,6 +272,16 @@ def main():
 
     print("| mix | " + " | ".join(data) + " | worst |")
     print("|---|" + "---|" * (len(data) + 1))
+    if a.levels:
+        for lv in range(4):
+            for sch in ("f16x1", "f16x2w", "f16x2x"):
+                mix = {k: "f16c6" for k in LAYERS}
+                mix["fold"] = True
+                lvs = ["f16c6"] * 4
+                lvs[lv] = sch
+                mix["fc_0_levels"] = lvs
+                report("folded f16f6, fc_0 level %d as %s" % (lv, sch), mix)
+        return
     if a.quick:
         for pe_s in ("f16x1", "f16x2w", "f16x2x"):
             mix = {k: "f16c6" for k in LAYERS}
