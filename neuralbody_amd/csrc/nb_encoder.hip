@@ -21,8 +21,6 @@
 //   SparseConv3d(k=3,s=2,p=1): out[o] = sum_k W[k] . in[2 o - 1 + k], active where any input is
 //   BatchNorm1d(eps=1e-3) over ACTIVE rows, then ReLU;  .dense() -> zeros at inactive sites
 //   duplicate vertex coordinates: the LAST vertex wins; BN counts unique voxels
-#include <cstdlib>
-
 #include "nb_scan.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -651,11 +649,10 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
     const long long plane = (long long)in_rows_cap * cin;
     const int row_groups = (int)nb_ceil_div(n_out_max, 128);
     // channel tiles per wave: all of them when the rows alone fill the chip (4 waves per group, 1024 SIMDs), else one per wave
-    static const bool use_lds = getenv("NB_CONV16_NO_LDS") == nullptr;  // experiment switch
     // 64- and 128-channel layers: weight slab shared through LDS (measured slower for the 32-channel ones: 35 vs 29 us); all channel tiles per wave when the rows alone give >= 512
     // workgroups, else two per wave (128 x 64-channel workgroups)
 #define NB_CONV16_LDS_CASE(CI, CO)                                                                                          \
-    if (use_lds && cin == CI && cout == CO) {                                                                               \
+    if (cin == CI && cout == CO) {                                                                                           \
         constexpr int NTT = CO / 32;                                                                                        \
         if (row_groups >= 512 || NTT <= 2)                                                                                  \
             hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, NTT>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, \
@@ -685,9 +682,6 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
     }
     NB_CONV16_CASE(32, 32)
     NB_CONV16_CASE(32, 64)
-    NB_CONV16_CASE(64, 64)
-    NB_CONV16_CASE(64, 128)
-    NB_CONV16_CASE(128, 128)
 #undef NB_CONV16_CASE
     nb_set_error("nb_enc_conv16: unsupported channel pair %d -> %d", cin, cout);
     return NB_EINVAL;
