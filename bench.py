@@ -14,14 +14,16 @@ seed 0).  One STEP = `Renderer.render(batch)` for one view per GPU: structured-l
 Hygiene: the timed region cycles through N_POSES = 8 distinct camera poses whose ray tensors were
 generated on the device beforehand (no per-view cache can hit: each step sees other ray / mask tensors), `ms_per_step` is
 total / K as the contract says and `median_ms_per_step` is the median of per-step HIP-event times; `parity_linf` is the
-rgb L-inf of >= 4096 rays of the timed views against the oracle on the same feature volumes (rank 0, N = 1).
+rgb L-inf of 4096 rays of a timed view against the oracle on the same feature volumes (rank 0, N = 1; rays whose last
+sample's density is within ILL_SIGMA of zero are left out and counted, see parity_linf()).
 `--scaling strong` shards ONE view's rays over the ranks (parallel.render_sharded) instead of one view per rank.
 
 The JSON line also carries
-  roofline     — the dominant kernel (nb_march16_kernel, or nb_march_kernel with --precision f32): algorithmic MLP
+  roofline     — the dominant kernel (nb_march_f6_kernel by default; --precision picks the others): algorithmic MLP
                  flops (859 904 per ray-sample) / its average launch duration measured with HIP
-                 events inside the timed region, against the dense MFMA peak of the arithmetic it runs on
-                 (2.5 PFLOP/s bf16 for the default split-bf16 path, 157.3 TFLOP/s for exact fp32).
+                 events inside the timed region, against the dense MFMA peak of the arithmetic its main product runs on
+                 (2.5 PFLOP/s for the fp16 / bf16 paths, 157.3 TFLOP/s for exact fp32); `executed_frac` = the MFMA work the
+                 kernel actually issues, in fp16-equivalent pipe time, over the same peak.
   cpu_baseline — the CPU restatement of the reference (oracle/, torch CPU, all host cores) marching a
                  bounded sample of the same rays through the same feature volumes.
 """
