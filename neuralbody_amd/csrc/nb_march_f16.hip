@@ -1020,6 +1020,10 @@ __device__ __forceinline__ FRing f_ring_begin(const float *pk, const float *lb, 
 #define F_KERNEL nb_march_f16_kernel
 #define F_KERNEL_NAME "nb_march_f16_kernel"
 #endif
+// FULL = false: no sample culling and no `raw` output (the plain renderer: what bench.py and run.py's evaluation loop launch).
+// The two rarely used paths cost 30 SGPRs that live across the depth loop; without them the kernel spills 43 instead of 72
+// scalars and restores 60 instead of 232 per depth step (v_readlane = VALU issue slots, which this kernel is short of).
+template <bool FULL>
 __global__ __launch_bounds__(256) void F_KERNEL(MarchArgs a, const char *stream) {
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const FRing rg = f_ring_begin(a.pk, a.lb, stream, lds);
@@ -1075,7 +1079,7 @@ __global__ __launch_bounds__(256) void F_KERNEL(MarchArgs a, const char *stream)
         }
         // sample culling (nb_cull): a WORKGROUP decision, the four waves walk the weight ring in lock step
         bool ins = true, run = true;
-        if (a.cull.n_views) {
+        if (FULL && a.cull.n_views) {
             ins = cull_inside(a.cull, a.sc, px, py, pz);
             int *flags = reinterpret_cast<int *>(rg.lds + RING_BYTES) + P_SIZE;
             const int any_wave = __any(ins) ? 1 : 0;
@@ -1085,12 +1089,12 @@ __global__ __launch_bounds__(256) void F_KERNEL(MarchArgs a, const char *stream)
             __syncthreads();
         }
 #ifdef F_TIMING
-        unsigned *tbuf = (blockIdx.x == 0 && rg.wave_off == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + 32 * s : nullptr;
+        unsigned *tbuf = (FULL && blockIdx.x == 0 && rg.wave_off == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + 32 * s : nullptr;
         if (tbuf && lane_i == 0) tbuf[0] = (unsigned)__builtin_readcyclecounter();
 #else
         unsigned *tbuf = nullptr;
 #endif
-        if (run) decode_f16(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, tbuf, reinterpret_cast<unsigned *>(a.raw));
+        if (run) decode_f16(a.sc, r2, px, py, pz, vx, vy, vz, pe, out, tbuf, FULL ? reinterpret_cast<unsigned *>(a.raw) : nullptr);
         if (!ins || !run) out[0] = out[1] = out[2] = out[3] = 0.f;
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
         dist = __fmul_rn(dist, dn);
@@ -1099,7 +1103,7 @@ __global__ __launch_bounds__(256) void F_KERNEL(MarchArgs a, const char *stream)
 #ifdef F_TIMING
         if (tbuf && lane_i == 0) tbuf[20] = (unsigned)__builtin_readcyclecounter();
 #else
-        if (valid && hi == 0 && a.raw)
+        if (FULL && valid && hi == 0 && a.raw)
             *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
 #endif
         z_cur = z_next;
@@ -1350,7 +1354,9 @@ int launch_march_f6(const MarchArgs &a, long long stream_off, hipStream_t st) {
 #else
 int launch_march_f16(const MarchArgs &a, long long stream_off, hipStream_t st) {
 #endif
-    hipLaunchKernelGGL(F_KERNEL, dim3(a.n_wave_groups), dim3(256), 0, st, a, reinterpret_cast<const char *>(a.pk + stream_off));
+    const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
+    if (a.cull.n_views || a.raw) hipLaunchKernelGGL(F_KERNEL<true>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    else hipLaunchKernelGGL(F_KERNEL<false>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     NB_CHECK_LAUNCH(F_KERNEL_NAME);
     return NB_OK;
 }
