@@ -47,15 +47,16 @@ PRECISION_INFO = {
     "f32": ("f32", "nb_march_kernel", 663296.0, 157.3),
     # the same layers as 1944 v_mfma_f32_32x32x16_bf16 per 32 samples (bf16 hi/lo split: 3 products, K padded to 16)
     "bf16x3": ("bf16", "nb_march16_kernel", 1944 * 32768 / 32.0, 2500.0),
-    # M-split organisation of the same arithmetic: 4 waves x 984 MFMAs per 64 samples (encoding K padded to 128)
-    "bf16x3s": ("bf16", "nb_march16s_kernel", 4 * 984 * 32768 / 64.0, 2500.0),
     # fp16 main product (520 K=16 MFMAs per 32 samples: fc_0 176, fc_1 128, fc_2 128, the folded feature_fc/latent_fc/view_fc
     # layer 64, view_fc over the encodings 24) + 272 K=64 scaled 8-bit MFMAs for the two cross terms; the 8-bit flops are
     # counted at half weight (their dense peak is 2x the fp16 peak), i.e. in fp16-equivalent matrix-pipe time
     "f16f8": ("f16+f8", "nb_march_f16_kernel", (520 * 32768 + 272 * 131072 / 2.0) / 32.0, 2500.0),
     # the same with the cross terms in 6 bits: a K=64 fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA
     # (profiles/r02_probe_mxrate.log), so it is counted as one (a quarter of its flops)
-    "f16f6": ("f16+f6", "nb_march_f6_kernel", (520 + 272) * 32768 / 32.0, 2500.0),
+    "f16f6r": ("f16+f6", "nb_march_f6_kernel", (520 + 272) * 32768 / 32.0, 2500.0),
+    # the same arithmetic, M-split workgroups (the default): 4 waves x 408 MFMAs per 64 samples (fc_0's K padded to 384, the
+    # encodings' to 128)
+    "f16f6": ("f16+f6", "nb_march_ms6_kernel", 4 * 408 * 32768 / 64.0, 2500.0),
 }
 
 
@@ -278,7 +279,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--precision", default=None, choices=[None, "auto", "f32", "bf16x3", "bf16x3s", "f16f8", "f16f6"])
+    ap.add_argument("--precision", default=None, choices=[None, "auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one view per GPU per step (views shard with no collective but the tile all-gather); "
                          "strong: one view per step, its rays split over the GPUs")
@@ -364,9 +365,10 @@ def main():
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r02_march_%s_traffic.json" % {"f16f8": "f16", "f16f6": "f6"}[net.march_precision()]
-                         if net.march_precision() in ("f16f8", "f16f6") else "r01_march16_traffic.json")
-    if net.march_precision() in ("bf16x3", "f16f8", "f16f6") and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
+    tfile = {"bf16x3": "r01_march16_traffic.json", "f16f8": "r02_march_f16_traffic.json", "f16f6r": "r02_march_f6_traffic.json",
+             "f16f6": "r03_march_ms6_traffic.json"}.get(net.march_precision())
+    tpath = os.path.join(ROOT, "profiles", tfile or "none")
+    if tfile and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
         with open(tpath) as f:
             traffic = json.load(f)["hbm_bytes_per_launch"]
     views_per_step = world if args.scaling == "weak" else 1
@@ -388,8 +390,7 @@ def main():
                    "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                   "bf16x3": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
                                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate",
-                                  "bf16x3s": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
-                                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate (M-split workgroups)",
+                                  "f16f6r": "the f16f6 arithmetic on the ring organisation (round 2's default kernel)",
                                   "f16f8": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
                                            "terms in 8 bits (fp8 e4m3 weights, bf8 e5m2 activations) on "
                                            "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate",

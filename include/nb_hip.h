@@ -30,22 +30,25 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 14
+#define NB_ABI_VERSION 15
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
 #define NB_PREC_BF16X3 1 /* bf16 hi+lo split of both operands, 3 products on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
-#define NB_PREC_BF16X3S 2 /* nb_march only: the same arithmetic, workgroup organised by output-feature quarters
-                             (activations in LDS, weights straight from L2, two workgroups per CU) */
+#define NB_PREC_F16F6R 2  /* nb_march only: the NB_PREC_F16F6 arithmetic on the ring organisation (one wave = 32 sample columns
+                             with its activations in registers, weights through an LDS ring by LDS-DMA, one workgroup per
+                             CU): the host of sample culling, and the reference point for measurements */
 #define NB_PREC_F16F8 3   /* nb_march only: fp16 main product on v_mfma_f32_32x32x16_f16 + the two cross terms of the
                              fp16 head/remainder split in 8 bits (weights fp8 e4m3, activations bf8 e5m2) on
                              v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate: ~2^-15 relative error per term at 1.8
-                             instead of 3 matrix-pipe units */
-#define NB_PREC_F16F6 4   /* nb_march only: the same split with the cross terms in 6 bits (weights fp6 e2m3 with a pack-time
-                             E8M0 scale per row and 32 K, activations bf6 e3m2 with a run-time E8M0 scale per sample and
-                             32 K): the K=64 scaled MFMA then issues at the rate of one K=16 fp16 MFMA (8-bit: 1.9x).
+                             instead of 3 matrix-pipe units (ring organisation) */
+#define NB_PREC_F16F6 4   /* nb_march only, the default: the same split with the cross terms in 6 bits (weights fp6 e2m3 with a
+                             pack-time E8M0 scale per row and 32 K, activations bf6 e3m2 with a run-time E8M0 scale per sample
+                             and 32 K): the K=64 scaled MFMA then issues at the rate of one K=16 fp16 MFMA (8-bit: 1.9x).
+                             Workgroups organised by output-feature quarters (activations in LDS, weights straight from L2,
+                             two workgroups per CU); a culled march (nb_cull) runs on NB_PREC_F16F6R's kernel.
                              Weight blocks whose elements span more than ~2^5 lose their small elements: see
-                             nb_mlp_six_bit_loss() */
+                             nb_mlp_six_bit_stats_offset() */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */
@@ -115,7 +118,7 @@ int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream);
  * decodes with NB_PREC_F32 only).  The fp32 section (NB_PACK_F32) is always written. */
 #define NB_PACK_F32 1
 #define NB_PACK_BF16X3 2
-#define NB_PACK_BF16X3S 4
+#define NB_PACK_F16F6R 4 /* the ring-organised six-bit stream alone (NB_PACK_F16F6 includes it) */
 #define NB_PACK_F16F8 8
 #define NB_PACK_F16F6 16
 #define NB_PACK_ALL 31

@@ -9,9 +9,9 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 14
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x3s": 2, "f16f8": 3, "f16f6": 4}
-PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "bf16x3s": 4, "f16f8": 8, "f16f6": 16}
+ABI_VERSION = 15
+PRECISIONS = {"f32": 0, "bf16x3": 1, "f16f6r": 2, "f16f8": 3, "f16f6": 4}
+PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "f16f6r": 4, "f16f8": 8, "f16f6": 16}
 
 
 class NbScene(C.Structure):

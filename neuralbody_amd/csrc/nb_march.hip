@@ -428,7 +428,8 @@ __global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__
 
 extern "C" {
 
-static long long f16_stream_off() { return PACK_SIZE + nbm::bf16_stream_floats() + nbm::msplit_stream_floats(); }
+static long long ms6_stream_off() { return PACK_SIZE + nbm::bf16_stream_floats(); }
+static long long f16_stream_off() { return ms6_stream_off() + nbm::ms6_stream_floats(); }
 static long long f6_stream_off() { return f16_stream_off() + nbm::f16_stream_floats(); }
 int64_t nb_mlp_pack_size(void) { return f6_stream_off() + nbm::f6_stream_floats(); }
 int64_t nb_mlp_latent_bias_size(void) { return 384; }
@@ -455,11 +456,12 @@ int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, vo
     NB_CHECK_LAUNCH("nb_pack_kernel");
     if (sections & NB_PACK_BF16X3)
         if (int rc = nbm::pack_bf16_stream(p, packed, (hipStream_t)stream)) return rc;
-    if (sections & NB_PACK_BF16X3S)
-        if (int rc = nbm::pack_msplit_stream(p, packed, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream)) return rc;
+    if (sections & NB_PACK_F16F6)
+        if (int rc = nbm::pack_ms6_stream(p, packed, ms6_stream_off(), (hipStream_t)stream)) return rc;
     if (sections & NB_PACK_F16F8)
         if (int rc = nbm::pack_f16_stream(p, packed, f16_stream_off(), (hipStream_t)stream)) return rc;
-    if (sections & NB_PACK_F16F6)
+    // the ring-organised six-bit stream: NB_PREC_F16F6R, culled marches of NB_PREC_F16F6, and the small-element statistic
+    if (sections & (NB_PACK_F16F6 | NB_PACK_F16F6R))
         if (int rc = nbm::pack_f6_stream(p, packed, f6_stream_off(), (hipStream_t)stream)) return rc;
     return NB_OK;
 }
@@ -519,14 +521,13 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, ray_order,
                     white_bkgd,
                     rgb_map, disp_map, acc_map, weights, depth_map, raw);
-    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_BF16X3S || precision == NB_PREC_F16F8 ||
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_F16F6R || precision == NB_PREC_F16F8 ||
                    precision == NB_PREC_F16F6,
                "nb_march: precision %d", precision);
     if (precision == NB_PREC_F16F8) return nbm::launch_march_f16(a, f16_stream_off(), (hipStream_t)stream);
-    if (precision == NB_PREC_F16F6) return nbm::launch_march_f6(a, f6_stream_off(), (hipStream_t)stream);
-    // the M-split kernel has no sample culling: culled marches take the ring kernel (same arithmetic)
-    if (precision == NB_PREC_BF16X3S && !cull)
-        return nbm::launch_march_msplit(a, PACK_SIZE + nbm::bf16_stream_floats(), (hipStream_t)stream);
+    // the M-split kernel has no sample culling: culled marches take the ring kernel (same arithmetic, same packed section)
+    if (precision == NB_PREC_F16F6 && !a.cull.n_views) return nbm::launch_march_ms6(a, ms6_stream_off(), (hipStream_t)stream);
+    if (precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6R) return nbm::launch_march_f6(a, f6_stream_off(), (hipStream_t)stream);
     if (precision != NB_PREC_F32) return nbm::launch_march_bf16(a, (hipStream_t)stream);
     hipLaunchKernelGGL(nb_march_kernel, dim3(a.n_wave_groups), dim3(256), 0, (hipStream_t)stream, a);
     NB_CHECK_LAUNCH("nb_march_kernel");

@@ -676,10 +676,10 @@ long long bf16_stream_floats();
 int pack_bf16_stream(const nb_mlp_params *p, float *packed, hipStream_t st);
 int launch_points_bf16(const MarchArgs &a, int density_only, hipStream_t st);
 int launch_march_bf16(const MarchArgs &a, hipStream_t st);
-// M-split split-bf16 march (nb_march_msplit.hip); stream_off = float offset of its weight stream inside the packed blob
-long long msplit_stream_floats();
-int pack_msplit_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
-int launch_march_msplit(MarchArgs a, long long stream_off, hipStream_t st);
+// M-split fp16 + scaled-6-bit march (nb_march_ms6.hip); stream_off = float offset of its weight stream inside the packed blob
+long long ms6_stream_floats();
+int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
+int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st);
 // fp16 + scaled-8-bit march (nb_march_f16.hip)
 long long f16_stream_floats();
 int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);

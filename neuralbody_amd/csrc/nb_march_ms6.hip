@@ -1,0 +1,783 @@
+// nb_march_ms6.hip — the default march kernel (NB_PREC_F16F6) for gfx950: the "f16f6" arithmetic of nb_march_f16.hip
+//
+//     W.X  ~=  W_h.X_h                               v_mfma_f32_32x32x16_f16            (products exact, fp32 accumulate)
+//            + fp6(W_h).bf6(X_l) + fp6(W_l).bf6(X_h)  v_mfma_scale_f32_32x32x64_f8f6f4   (K = 64, E8M0 block scales)
+//
+// (feature_fc, latent_fc and view_fc folded into one layer) on the "M-split" workgroup organisation, chosen from the
+// counters of the ring kernel (profiles/r02_march_pmc.md: matrix pipe 0.34 busy, one wave per SIMD, every 2-KiB weight
+// record feeding 1-2 MFMAs of a wave at the price of two LDS reads, a counted wait and half an LDS-DMA piece):
+//
+//   * a workgroup (4 waves) marches 64 rays = two 32-sample N tiles; wave w owns a QUARTER OF EVERY LAYER'S OUTPUT
+//     FEATURES for all 64 samples, so a weight fragment feeds 2 MFMAs and comes straight from L2 into a register ring
+//     (plain global_load_dwordx4, no LDS-DMA, no page barriers);
+//   * activations live in LDS as ready-made B operands (fp16 heads by K=16 chunk, the two bf6 forms with their E8M0
+//     scale by K=64 block) and are rewritten in place after every layer; the two output tiles of wave w ARE K block w of
+//     the next layer, so the run-time block scale (max over 32 values of a lane) stays lane-local exactly as in the ring
+//     kernel, and every lane publishes into its own fragment slot;
+//   * <= 256 registers and 68 KiB of LDS: TWO workgroups per CU.  A wave is either in an MFMA phase or in a VALU phase
+//     (gather, encodings, conversions, heads); with two independent workgroups per SIMD one's VALU phases run in the
+//     matrix-pipe gaps of the other (tools/experiments/probe_coissue.hip: a partner's VALU work hides whenever the matrix
+//     wave is not issuing back to back).
+//
+// Per-sample work (ray set-up, trilinear gather, positional encoding, compositing) is done by "owner" lanes: wave w,
+// lane l owns sample 16 w + (l & 15) and, of that sample, channel quarter / axis `part` = l >> 4.
+//
+// K layout.  A layer input is a list of K=64 blocks; block b, half kh is the 32-value group of one lane ("half-block"):
+// element e of it sits in fp16 chunk 4 b + e / 8 at B-fragment lane kg = kh, register element e % 8, and at element e
+// (heads) / interleaved position (remainders) of the lane's bf6 operands of block b.  Weights are packed to match.
+#include "nb_f6_ops.h"
+
+using namespace nbm;
+
+namespace {
+
+// ---------------------------------------------------------------- weight stream (per wave), in 1-KiB pieces
+// phase = NB K blocks x MT output tiles of this wave; per block: for each of its 4 chunks, for each tile: A16 (1 piece);
+// then for each tile: A6h (W_h in fp6, 2 pieces: multiplies the remainder operand), for each tile: A6l (W_l, 2 pieces)
+#ifndef NB_MS6_RING
+#define NB_MS6_RING 8
+#endif
+constexpr int S_R = NB_MS6_RING;  // register ring depth in pieces
+__host__ __device__ constexpr int phase_pieces(int nb, int mt) { return nb * mt * 8; }
+constexpr int N_PH = 7;
+// fc_0 in three K phases of 128 (pyramid level 3 | level 2 | levels 0 and 1 + 8 zero slots per lane), fc_1, fc_2,
+// the folded colour head over fc_2's outputs (one tile per wave), view_fc over the positional encodings
+constexpr int PH_NB[N_PH] = {2, 2, 2, 4, 4, 4, 2};
+constexpr int PH_MT[N_PH] = {2, 2, 2, 2, 2, 1, 1};
+__host__ __device__ constexpr int phase_p0(int ph) {
+    int p = 0;
+    for (int i = 0; i < ph; ++i) p += phase_pieces(PH_NB[i], PH_MT[i]);
+    return p;
+}
+constexpr int P_A = phase_p0(0), P_B = phase_p0(1), P_C = phase_p0(2), P_L1 = phase_p0(3), P_L2 = phase_p0(4), P_VG = phase_p0(5),
+              P_VP = phase_p0(6), P_TOTAL = phase_p0(7);
+static_assert(P_TOTAL == 272, "pieces per wave per depth step");
+static_assert(P_TOTAL % S_R == 0 && S_R % 2 == 0, "static ring slot of every piece, also across steps; six-bit fragments on even pieces");
+
+// fp32 section of the packed blob (written by nb_pack_kernel, nb_march.hip): offsets in floats
+constexpr int F_OFF_B0 = 8 * 44 * 256;
+constexpr int F_OFF_B1 = F_OFF_B0 + 256 + 8 * 32 * 256;
+constexpr int F_OFF_B2 = F_OFF_B1 + 256 + 8 * 32 * 256;
+constexpr int F_OFF_AW = F_OFF_B2 + 256;
+constexpr int F_OFF_AB = F_OFF_AW + 256;
+constexpr int F_OFF_L4 = F_OFF_AB + 4;
+constexpr int F_OFF_LV = F_OFF_L4 + 8 * 32 * 256;
+constexpr int F_OFF_BV = F_OFF_LV + 4 * 44 * 256;
+constexpr int F_OFF_RW = F_OFF_BV + 128;
+constexpr int F_OFF_RB = F_OFF_RW + 384;
+
+// ---------------------------------------------------------------- LDS
+constexpr int CH_BYTES = 2048;                 // one K=16 chunk: 2 N tiles x 1 KiB B fragment (64 lanes x 8 fp16)
+constexpr int ACT16_BYTES = 16 * CH_BYTES;     // 32 KiB
+constexpr int F6_BYTES = 2048;                 // one bf6 fragment: 64 lanes x (24 B data | scale word | pad), as two 1-KiB halves
+constexpr int ACT6_OFF = ACT16_BYTES;          // [block 4][form 2: heads, remainders][N tile 2] fragments
+constexpr int ACT6_BYTES = 4 * 2 * 2 * F6_BYTES;  // 32 KiB
+constexpr int TILE_BYTES = 8192;               // voxel tile of the gather, per wave: in the halves of both regions that fc_0's
+                                               // 128-wide K phases leave free (chunks 8..15, blocks 2..3)
+constexpr int SCR_A = ACT6_OFF + ACT6_BYTES;   // alpha_fc partial sums [64 samples][4 waves] floats
+constexpr int SCR_C = SCR_A + 1024;            // rgb_fc partial sums [3][64][4] floats
+// small fp32 parameters staged once per workgroup (LDS reads are counted on lgkmcnt: a global load at the head of a layer
+// phase would drain the weight ring's vmcnt queue): offsets in floats
+constexpr int PRM_OFF = SCR_C + 3072;
+constexpr int P_B0 = 0, P_B1 = 256, P_B2 = 512, P_AW = 768, P_RW = 1024, P_AB = 1408, P_RB = 1412, P_LB = 1416, P_SIZE = 1544;
+constexpr int LDS_BYTES = PRM_OFF + P_SIZE * 4;
+static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
+__device__ __forceinline__ int tile_off(int wave) { return wave < 2 ? 8 * CH_BYTES + wave * TILE_BYTES : ACT6_OFF + 2 * 4 * F6_BYTES + (wave - 2) * TILE_BYTES; }
+
+__device__ __forceinline__ f32x16 bias_tile_g(const float *bp, int t, int hi) {
+    const f32x4 *b4 = reinterpret_cast<const f32x4 *>(bp + (t * 2 + hi) * 16);
+    const f32x4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+    return f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+}
+
+// ---------------------------------------------------------------- operands -> LDS
+// 32 values of one half-block (block b, half kh) of sample column `slot` (0..31) of N tile n: fp16 heads into the four
+// chunks of the block, the two bf6 forms + their E8M0 scales into the block's fragments
+template <bool RELU, class Get>
+__device__ __forceinline__ void write_halfblock(char *act, int b, int kh, int n, int slot, Get get) {
+    f16x8 xh[4];
+    i32x6 xl[1], xx[1];
+    int eb[1];
+    make_operands6<2, RELU>(get, xh, xl, xx, eb);
+    const int ls = (kh * 32 + slot) * 16;
+    char *p16 = act + (4 * b) * CH_BYTES + n * 1024 + ls;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f16x8 *>(p16 + j * CH_BYTES) = xh[j];
+    char *p6 = act + ACT6_OFF + ((b * 2 + 0) * 2 + n) * F6_BYTES + ls;
+    *reinterpret_cast<i32x4 *>(p6) = i32x4{xx[0][0], xx[0][1], xx[0][2], xx[0][3]};
+    *reinterpret_cast<i32x4 *>(p6 + 1024) = i32x4{xx[0][4], xx[0][5], eb[0], 0};
+    *reinterpret_cast<i32x4 *>(p6 + 2 * F6_BYTES) = i32x4{xl[0][0], xl[0][1], xl[0][2], xl[0][3]};
+    *reinterpret_cast<i32x4 *>(p6 + 2 * F6_BYTES + 1024) = i32x4{xl[0][4], xl[0][5], eb[0] - 11, 0};
+}
+
+// ---------------------------------------------------------------- one layer phase of this wave
+struct WRing {
+    i32x8 f[S_R / 2];  // piece p in half (p & 1) of f[(p % S_R) / 2]
+};
+// the wave's share of the stream through a buffer descriptor (4 SGPRs, wave-uniform): `buffer_load_dwordx4 v, v_off, s[rsrc],
+// s_off offen` with the lane's 32-bit offset in a VGPR and the 1-KiB piece stride on the scalar unit — left to the compiler
+// as plain pointers every piece costs a 64-bit VALU address (v_add_co / v_addc pairs and their register pairs)
+typedef unsigned u32x4v __attribute__((__vector_size__(16)));
+struct WSrc {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned voff;  // lane * 16
+};
+__device__ __forceinline__ i32x4 load_piece(const WSrc &wl, int p) {
+    const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(wl.rsrc, wl.voff, (p % P_TOTAL) * 1024, 0);
+    return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+}
+template <int P>
+__device__ __forceinline__ void ring_put(WRing &r, const i32x4 v) {
+    i32x8 &d = r.f[(P % S_R) / 2];
+    if (P & 1) {
+        d[4] = v.x; d[5] = v.y; d[6] = v.z; d[7] = v.w;
+    } else {
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+template <int P>
+__device__ __forceinline__ i32x4 ring_get(const WRing &r) {
+    const i32x8 &d = r.f[(P % S_R) / 2];
+    return (P & 1) ? i32x4{d[4], d[5], d[6], d[7]} : i32x4{d[0], d[1], d[2], d[3]};
+}
+
+__device__ __forceinline__ f32x16 mfma16(const i32x4 a, const i32x4 b, const f32x16 c) {
+#ifdef MS6_ABL_NOM
+    return c;
+#endif
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// A: fp6 e2m3 (cbsz 2), 24 B of data + the lane's E8M0 scale in register 6; B: bf6 e3m2 (blgp 3), same layout
+__device__ __forceinline__ f32x16 mfma6(const i32x8 a, const i32x8 b, const f32x16 c) {
+#ifdef MS6_ABL_NOM
+    return c;
+#endif
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 3, 0, a[6], 0, b[6]);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+
+// the first S_R pieces of the phase at P0: issued by the caller when the preceding phase did not prefetch them (a register-
+// hungry VALU phase in between: a ring that is live across the gather gets spilled, and its reloads wait vmcnt(0))
+template <int P0>
+__device__ __forceinline__ void ring_prime(const WSrc &wl, WRing &ring) {
+    sfor<0, S_R>([&](auto pc) { ring_put<P0 + decltype(pc)::value>(ring, load_piece(wl, P0 + decltype(pc)::value)); });
+}
+
+// acc[m][n] += W[tiles of this wave, K range of the phase] . X for the NB blocks at LDS blocks 0..NB-1
+// AHEAD: the last S_R pieces' slots are refilled with the first pieces of the FOLLOWING phase (otherwise: ring_prime).
+// A phase is a flat list of steps, six per block: the block's four K=16 chunks (MT x 2 fp16 MFMAs each), then its two cross
+// terms (k = 0: W_h (fp6) x remainders, LDS form 1; k = 1: W_l x heads, form 0; MT x 2 scaled MFMAs each).  The B operands
+// of step t + 1 are read from LDS before the MFMAs of step t are issued.
+struct BOps {
+    i32x4 m[2][2];  // [buffer][N tile]: main
+    i32x8 c[2][2];  // cross: 6 registers of bf6 data, the scale byte in register 6
+};
+template <int T>
+__device__ __forceinline__ void read_b(const char *b16, const char *b6, BOps &x) {
+    constexpr int b = T / 6, j = T % 6, buf = T & 1;
+    if constexpr (j < 4) {
+        constexpr int c = 4 * b + j;
+        x.m[buf][0] = *reinterpret_cast<const i32x4 *>(b16 + c * CH_BYTES);
+        x.m[buf][1] = *reinterpret_cast<const i32x4 *>(b16 + c * CH_BYTES + 1024);
+    } else {
+        constexpr int form = 1 - (j - 4);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const char *q = b6 + ((b * 2 + form) * 2 + n) * F6_BYTES;
+            const i32x4 lo = *reinterpret_cast<const i32x4 *>(q), hi4 = *reinterpret_cast<const i32x4 *>(q + 1024);
+            x.c[buf][n] = i32x8{lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        }
+    }
+}
+template <int P0, int MT, int NB, bool AHEAD>
+__device__ __forceinline__ void layer_s(const WSrc &wl, const char *act, int lane, WRing &ring, f32x16 (&acc)[2][2]) {
+    constexpr int PPB = 8 * MT;  // pieces per block
+    constexpr int PEND = P0 + NB * PPB;
+    constexpr int NT = 6 * NB;
+    const char *b16 = act + lane * 16;
+    const char *b6 = act + ACT6_OFF + lane * 16;
+    BOps x;
+    read_b<0>(b16, b6, x);
+    sfor<0, NT>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, b = t / 6, j = t % 6, buf = t & 1;
+        if constexpr (t + 1 < NT) read_b<t + 1>(b16, b6, x);
+        if constexpr (j < 4) {
+            sfor<0, MT>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, P = P0 + b * PPB + j * MT + m;
+                const i32x4 a = ring_get<P>(ring);
+                acc[m][0] = mfma16(a, x.m[buf][0], acc[m][0]);
+                acc[m][1] = mfma16(a, x.m[buf][1], acc[m][1]);
+                if constexpr (AHEAD || P + S_R < PEND) ring_put<P>(ring, load_piece(wl, P + S_R));
+            });
+        } else {
+            constexpr int k = j - 4;
+            // the operands as pinned 8-register tuples: a 6-of-8 use of two separately allocated 16-byte loads costs two
+            // copies per operand
+            asm volatile("" : "+v"(x.c[buf][0]), "+v"(x.c[buf][1]));
+            sfor<0, MT>([&](auto mc) {
+                constexpr int m = decltype(mc)::value, P = P0 + b * PPB + 4 * MT + (k * MT + m) * 2;
+                static_assert(P % 2 == 0, "a six-bit fragment is one ring entry");
+                i32x8 a = ring.f[(P % S_R) / 2];
+                asm volatile("" : "+v"(a));
+                acc[m][0] = mfma6(a, x.c[buf][0], acc[m][0]);
+                acc[m][1] = mfma6(a, x.c[buf][1], acc[m][1]);
+                if constexpr (AHEAD || P + S_R < PEND) {
+                    ring_put<P>(ring, load_piece(wl, P + S_R));
+                    ring_put<P + 1>(ring, load_piece(wl, P + 1 + S_R));
+                }
+            });
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    // pin the end of the accumulator chains HERE: MFMAs are pure, and hipcc otherwise sinks the tail of a phase past the
+    // barrier and the following gather / conversion down to the next reader of the tile, keeping the operands they read
+    // alive (spilled) all the way
+#pragma unroll
+    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
+}
+
+template <int MT>
+__device__ __forceinline__ void init_bias(const float *bp, int tile0, int hi, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const f32x16 b = bias_tile_g(bp, tile0 + m, hi);
+        acc[m][0] = b;
+        acc[m][1] = b;
+    }
+}
+
+// relu'd accumulators of this wave (two tiles x two N tiles) -> K block `wave` of the next layer, in place: the lane's 16 +
+// 16 values of an N tile are half-block (wave, hi) and go into the lane's own fragment slot
+__device__ __forceinline__ void publish_s(char *act, int lane, int wave, f32x16 (&acc)[2][2]) {
+    const int i = lane & 31, hi = lane >> 5;
+    __syncthreads();  // every wave is done reading the previous activations
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = relu1(acc[m][n][r]);
+        write_halfblock<false>(act, wave, hi, n, i, [&](int q) { return q < 16 ? acc[0][n][q & 15] : acc[1][n][q & 15]; });
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------- gather, owner-lane layout (sample = lane & 15, part = lane >> 4)
+__device__ __forceinline__ float red_min16(float v) {
+    v = fminf(v, swz_xor<8>(v));
+    v = fminf(v, swz_xor<4>(v));
+    v = fminf(v, swz_xor<2>(v));
+    v = fminf(v, swz_xor<1>(v));
+    return v;
+}
+__device__ __forceinline__ float red_max16(float v) {
+    v = fmaxf(v, swz_xor<8>(v));
+    v = fmaxf(v, swz_xor<4>(v));
+    v = fmaxf(v, swz_xor<2>(v));
+    v = fmaxf(v, swz_xor<1>(v));
+    return v;
+}
+
+// channels [part * C/4, (part+1) * C/4) of level L for this lane's sample; same corner order, weights and zero
+// padding as gather_level / gather_level_coop (nb_march_common.h), tile = wave-private LDS
+template <int L, typename Sink>
+__device__ __forceinline__ void gather_parts(const SceneDev &sc, const GridCoord &g, const WaveBox &wb, int part, int lane,
+                                             char *buf, Sink sink) {
+    constexpr int C = lvl_c(L), QC = C / 4, PC = C / 4;  // PC 16-byte pieces per voxel
+    constexpr int MAX_IT = TILE_BYTES / 1024;
+    const int D = sc.dhw[L][0], H = sc.dhw[L][1], W = sc.dhw[L][2];
+    const float ix = unnorm_clamped(g.gw, W), iy = unnorm_clamped(g.gh, H), iz = unnorm_clamped(g.gd, D);
+    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+    const float wx[2] = {(fx + 1.f) - ix, ix - fx};
+    const float wy[2] = {(fy + 1.f) - iy, iy - fy};
+    const float wz[2] = {(fz + 1.f) - iz, iz - fz};
+    const int xlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gw, W)), 0), W - 1));
+    const int ylo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gh, H)), 0), H - 1));
+    const int zlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gd, D)), 0), D - 1));
+    const int xhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gw, W)) + 1, 0), W - 1));
+    const int yhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gh, H)) + 1, 0), H - 1));
+    const int zhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gd, D)) + 1, 0), D - 1));
+    const int nx = xhi - xlo + 1, ny = yhi - ylo + 1, nz = zhi - zlo + 1;
+    const int pieces = nx * ny * nz * PC;
+    float cw[8];
+#pragma unroll
+    for (int corner = 0; corner < 8; ++corner) {
+        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
+        const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
+        cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
+    }
+    if (pieces <= TILE_BYTES / 16) {  // wave-uniform: the wave's voxel box fits its tile
+        const float rcp_xy = 1.f / (float)(nx * ny), rcp_x = 1.f / (float)nx;
+#pragma unroll
+        for (int b = 0; b < MAX_IT; b += 4) {  // four coalesced 1-KiB fetches in flight at a time (register budget)
+            if (b * 64 < pieces) {
+                f32x4 t[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if ((b + it) * 64 < pieces) {
+                        const int p = min((b + it) * 64 + lane, pieces - 1);
+                        const int v = p / PC, q = p % PC;
+                        const int vz = (int)(((float)v + 0.5f) * rcp_xy);
+                        const int r = v - vz * nx * ny;
+                        const int vy = (int)(((float)r + 0.5f) * rcp_x);
+                        const int vx = r - vy * nx;
+                        const size_t lin = ((size_t)((zlo + vz) * H + (ylo + vy))) * W + (xlo + vx);
+                        t[it] = *reinterpret_cast<const f32x4 *>(sc.vol[L] + lin * C + q * 4);
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    if ((b + it) * 64 < pieces) {
+                        const int p = (b + it) * 64 + lane;
+                        if (p < pieces) *reinterpret_cast<f32x4 *>(buf + p * 16) = t[it];
+                    }
+                }
+            }
+        }
+        int co[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int xx = x0 + (corner & 1), yy = y0 + ((corner >> 1) & 1), zz = z0 + (corner >> 2);
+            const int xc = min(max(xx, xlo), xhi), yc = min(max(yy, ylo), yhi), zc = min(max(zz, zlo), zhi);
+            co[corner] = ((((zc - zlo) * ny + (yc - ylo)) * nx + (xc - xlo)) * C + part * QC) * 4;
+        }
+#pragma unroll
+        for (int grp = 0; grp < QC / 8; ++grp) {  // 8 channels at a time
+            float o8[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int corner = 0; corner < 8; ++corner) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + co[corner] + (2 * grp + h) * 16);
+                    a.x = fmaf(cw[corner], v.x, a.x);
+                    a.y = fmaf(cw[corner], v.y, a.y);
+                    a.z = fmaf(cw[corner], v.z, a.z);
+                    a.w = fmaf(cw[corner], v.w, a.w);
+                }
+                o8[4 * h + 0] = a.x;
+                o8[4 * h + 1] = a.y;
+                o8[4 * h + 2] = a.z;
+                o8[4 * h + 3] = a.w;
+            }
+            sink(grp, o8);
+        }
+    } else {  // rays far apart (small images, random rays): read the corners from global memory
+        const float *cpb[8];
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const int xx = x0 + (corner & 1), yy = y0 + ((corner >> 1) & 1), zz = z0 + (corner >> 2);
+            const int xc = min(max(xx, 0), W - 1), yc = min(max(yy, 0), H - 1), zc = min(max(zz, 0), D - 1);
+            cpb[corner] = sc.vol[L] + ((size_t)(zc * H + yc) * W + xc) * C + part * QC;
+        }
+#pragma unroll
+        for (int grp = 0; grp < QC / 8; ++grp) {
+            float o8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(cpb[corner] + 8 * grp);
+                const f32x4 v1 = *reinterpret_cast<const f32x4 *>(cpb[corner] + 8 * grp + 4);
+                o8[0] = fmaf(cw[corner], v0.x, o8[0]);
+                o8[1] = fmaf(cw[corner], v0.y, o8[1]);
+                o8[2] = fmaf(cw[corner], v0.z, o8[2]);
+                o8[3] = fmaf(cw[corner], v0.w, o8[3]);
+                o8[4] = fmaf(cw[corner], v1.x, o8[4]);
+                o8[5] = fmaf(cw[corner], v1.y, o8[5]);
+                o8[6] = fmaf(cw[corner], v1.z, o8[6]);
+                o8[7] = fmaf(cw[corner], v1.w, o8[7]);
+            }
+            sink(grp, o8);
+        }
+    }
+}
+
+// compositing state of the weights output: 16 consecutive depth steps of a ray = 64 bytes, 4 steps per owner lane
+struct WeightStore4 {
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+    __device__ __forceinline__ void push(const MarchArgs &a, long long ray, int s, int S, int part, bool valid, float w) {
+        if ((S & 15) != 0) {
+            if (valid && part == 0) a.weights[ray * S + s] = w;
+            return;
+        }
+        const int slot = s & 15;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (slot == part * 4 + i) q[i] = w;
+        if (slot == 15 && valid)
+            *reinterpret_cast<f32x4 *>(a.weights + ray * S + (s - 15) + part * 4) = f32x4{q[0], q[1], q[2], q[3]};
+    }
+};
+
+// view_fc column of encoding slot `slot` (0..31) of axis a: [x, (sin, cos)(x 2^k) k<10, v, (sin, cos)(v 2^k) k<4, 0, 0]; -1 = zero pad
+__host__ __device__ inline int pe_slot_col(int a, int slot) {
+    if (a >= 3 || slot >= 30) return -1;
+    if (slot == 0) return 256 + 27 + a;
+    if (slot <= 20) {
+        const int k = (slot - 1) >> 1, is_cos = (slot - 1) & 1;
+        return 256 + 27 + 3 + 6 * k + 3 * is_cos + a;
+    }
+    if (slot == 21) return 256 + a;
+    const int k = (slot - 22) >> 1, is_cos = (slot - 22) & 1;
+    return 256 + 3 + 6 * k + 3 * is_cos + a;
+}
+
+// ---------------------------------------------------------------- the kernel
+// MS6_TAP (debug builds): workgroup 0 dumps, at depth step 0, every layer's accumulators as [layer][feature][sample]
+// fp32 into a.raw instead of the raw output (fc_0, fc_1, fc_2 pre-activation: 3 x 256 x 64; folded view layer: 128 x 64) —
+// tools/experiments/ms6_tap_check.py compares them with nb_decode_points' fp32 activation tap
+__global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const char *stream) {
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    char *act = lds;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hi = lane >> 5;
+    const int os = lane & 15, part = lane >> 4;  // owner role
+    const int sample = 16 * wave + os;            // 0..63 inside the workgroup
+    const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
+    long long ray = (long long)grp * 64 + sample;
+    const bool valid = ray < a.n_rays;
+    if (!valid) ray = a.n_rays - 1;
+    if (a.ray_order) ray = a.ray_order[ray];
+    const int S = a.n_samples;
+    const float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
+    const float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
+    const float near = a.near[ray], far = a.far[ray];
+    const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    const float vx = dx / dn, vy = dy / dn, vz = dz / dn;
+    // positional encoding of the view direction for this lane's axis (constant along the ray): v, sin/cos(v 2^k), k < 4
+    float vpe[9];
+    {
+        const float va = part == 0 ? vx : (part == 1 ? vy : vz);
+        const double t = (double)va * NB_INV_2PI;
+        vpe[0] = va;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            vpe[1 + 2 * k] = sin_rev(t * (double)(1 << k));
+            vpe[2 + 2 * k] = sin_rev(t * (double)(1 << k) + 0.25);
+        }
+    }
+    const float *tr = a.t_rand ? a.t_rand + ray * S : nullptr;
+    auto z_at = [&](int s) -> float {
+        const float zc = z_lin(near, far, a.t_vals[s]);
+        if (!tr) return zc;
+        const float lower = s == 0 ? zc : 0.5f * __fadd_rn(zc, z_lin(near, far, a.t_vals[s - 1]));
+        const float upper = s == S - 1 ? zc : 0.5f * __fadd_rn(z_lin(near, far, a.t_vals[s + 1]), zc);
+        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), tr[s]));
+    };
+
+    {
+        float *prm = reinterpret_cast<float *>(lds + PRM_OFF);
+        for (int i = threadIdx.x; i < P_SIZE; i += 256) {
+            float v;
+            if (i < P_B1) v = a.pk[F_OFF_B0 + i - P_B0];
+            else if (i < P_B2) v = a.pk[F_OFF_B1 + i - P_B1];
+            else if (i < P_AW) v = a.pk[F_OFF_B2 + i - P_B2];
+            else if (i < P_RW) v = a.pk[F_OFF_AW + i - P_AW];
+            else if (i < P_AB) v = a.pk[F_OFF_RW + i - P_RW];
+            else if (i < P_RB) v = a.pk[F_OFF_AB + i - P_AB];
+            else if (i < P_LB) v = a.pk[F_OFF_RB + i - P_RB];
+            else v = a.lb[256 + i - P_LB];  // bias of the folded view layer (nb_mlp_latent_bias, second block)
+            prm[i] = v;
+        }
+        __syncthreads();
+    }
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(stream) + (size_t)wave * P_TOTAL * 1024, 0, P_TOTAL * 1024, 0x00020000);
+    WRing ring;
+
+    RayAccum ra;
+    WeightStore4 wstore;
+    float z_cur = z_at(0);
+    for (int s = 0; s < S; ++s) {
+        // loop-invariant address roots are laundered so that LICM does not hoist (and spill) hundreds of addresses
+        int zero = 0, lane_i = lane;
+        asm volatile("" : "+s"(zero), "+v"(lane_i));
+        const WSrc wl = {wrsrc, (unsigned)lane_i * 16u};
+        char *actz = act + zero;
+        char *tile = actz + tile_off(wave);
+        const float *pk = reinterpret_cast<const float *>(actz + PRM_OFF);
+        const float z_next = (s + 1 < S) ? z_at(s + 1) : 0.f;
+        const float px = __fadd_rn(ox, __fmul_rn(dx, z_cur));
+        const float py = __fadd_rn(oy, __fmul_rn(dy, z_cur));
+        const float pz = __fadd_rn(oz, __fmul_rn(dz, z_cur));
+        f32x16 acc[2][2];
+        const int sn = sample >> 5, ss = sample & 31;  // N tile and column of this lane's sample
+
+        // ---- fc_0 in three K phases of 128 = two blocks; part p fills half-block (p >> 1, p & 1)
+        {
+            const GridCoord g = grid_coords(a.sc, px, py, pz);
+            WaveBox wb;
+            wb.lo.gw = red_min16(g.gw);
+            wb.lo.gh = red_min16(g.gh);
+            wb.lo.gd = red_min16(g.gd);
+            wb.hi.gw = red_max16(g.gw);
+            wb.hi.gh = red_max16(g.gh);
+            wb.hi.gd = red_max16(g.gd);
+            float v[32];
+            gather_parts<3>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
+            });
+            write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return v[q]; });
+            ring_prime<P_A>(wl, ring);
+            init_bias<2>(pk + P_B0, 2 * wave, hi, acc);
+            __syncthreads();
+            layer_s<P_A, 2, 2, false>(wl, actz, lane_i, ring, acc);
+            __syncthreads();
+            gather_parts<2>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
+            });
+            write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return v[q]; });
+            ring_prime<P_B>(wl, ring);
+            __syncthreads();
+            layer_s<P_B, 2, 2, false>(wl, actz, lane_i, ring, acc);
+            __syncthreads();
+            gather_parts<0>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
+            });
+            gather_parts<1>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[8 + 8 * grp8 + e] = o[e];
+            });
+#pragma unroll
+            for (int e = 24; e < 32; ++e) v[e] = 0.f;
+            write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return v[q]; });
+            ring_prime<P_C>(wl, ring);
+            __syncthreads();
+            layer_s<P_C, 2, 2, true>(wl, actz, lane_i, ring, acc);
+        }
+#ifdef MS6_TAP
+#define MS6_DUMP(LAYER, MT_)                                                                                              \
+    if (blockIdx.x == 0 && s == 0 && a.raw) {                                                                             \
+        for (int m = 0; m < (MT_); ++m)                                                                                   \
+            for (int n = 0; n < 2; ++n)                                                                                   \
+                for (int r = 0; r < 16; ++r)                                                                              \
+                    a.raw[((LAYER) * 256 + 32 * ((MT_) * wave + m) + tile_row(r, hi)) * 64 + n * 32 + (lane & 31)] = acc[m][n][r]; \
+    }
+#else
+#define MS6_DUMP(LAYER, MT_)
+#endif
+        MS6_DUMP(0, 2)
+        publish_s(actz, lane_i, wave, acc);
+        // ---- fc_1, fc_2
+        init_bias<2>(pk + P_B1, 2 * wave, hi, acc);
+        layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc);
+        MS6_DUMP(1, 2)
+        publish_s(actz, lane_i, wave, acc);
+        init_bias<2>(pk + P_B2, 2 * wave, hi, acc);
+        layer_s<P_L2, 2, 4, true>(wl, actz, lane_i, ring, acc);
+        MS6_DUMP(2, 2)
+        publish_s(actz, lane_i, wave, acc);  // acc now holds relu(h3)
+        // ---- alpha_fc: partial dot product over this wave's 64 features, finished by the owner lanes
+        {
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float sa = 0.f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const f32x4 *aw = reinterpret_cast<const f32x4 *>(pk + P_AW + hi * 128 + 16 * (2 * wave + m));
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 w4 = aw[q4];
+                        sa = fmaf(w4.x, acc[m][n][4 * q4 + 0], sa);
+                        sa = fmaf(w4.y, acc[m][n][4 * q4 + 1], sa);
+                        sa = fmaf(w4.z, acc[m][n][4 * q4 + 2], sa);
+                        sa = fmaf(w4.w, acc[m][n][4 * q4 + 3], sa);
+                    }
+                }
+                sa = add_halves(sa);
+                if (hi == 0) reinterpret_cast<float *>(actz + SCR_A)[(n * 32 + (lane_i & 31)) * 4 + wave] = sa;
+            }
+        }
+        // ---- the colour head's linear part as ONE layer (feature_fc . latent_fc . view_fc folded at pack time, bias: second
+        // block of nb_mlp_latent_bias): one tile per wave, K phase over fc_2's outputs, then over the encodings
+        init_bias<1>(pk + P_LB, wave, hi, acc);
+        layer_s<P_VG, 1, 4, true>(wl, actz, lane_i, ring, acc);
+        __syncthreads();
+        {
+            // encodings: lane (sample, axis a = part < 3) fills half-block (part >> 1, part & 1); part 3 writes zeros
+            const float xa = part == 0 ? px : (part == 1 ? py : pz);
+            const double t = (double)xa * NB_INV_2PI;
+            const float keep = part < 3 ? 1.f : 0.f;
+            float e[32];
+            e[0] = xa;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                e[1 + 2 * k] = sin_rev(t * (double)(1 << k));
+                e[2 + 2 * k] = sin_rev(t * (double)(1 << k) + 0.25);
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) e[21 + k] = vpe[k];
+            e[30] = 0.f;
+            e[31] = 0.f;
+            write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return e[q] * keep; });
+        }
+        __syncthreads();
+        layer_s<P_VP, 1, 2, false>(wl, actz, lane_i, ring, acc);
+        MS6_DUMP(3, 1)
+        // ---- rgb_fc partial sums over this wave's 32 view features
+        {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const f32x4 *rw = reinterpret_cast<const f32x4 *>(pk + P_RW + (ch * 2 + hi) * 64 + 16 * wave);
+                    float sc = 0.f;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 w4 = rw[q4];
+                        sc = fmaf(w4.x, relu1(acc[0][n][4 * q4 + 0]), sc);
+                        sc = fmaf(w4.y, relu1(acc[0][n][4 * q4 + 1]), sc);
+                        sc = fmaf(w4.z, relu1(acc[0][n][4 * q4 + 2]), sc);
+                        sc = fmaf(w4.w, relu1(acc[0][n][4 * q4 + 3]), sc);
+                    }
+                    sc = add_halves(sc);
+                    if (hi == 0) reinterpret_cast<float *>(actz + SCR_C)[(ch * 64 + n * 32 + (lane_i & 31)) * 4 + wave] = sc;
+                }
+        }
+        __syncthreads();
+        // ---- owner lanes: finish the heads, composite
+        float out[4];
+        {
+            const f32x4 pa = *reinterpret_cast<const f32x4 *>(actz + SCR_A + sample * 16);
+            out[3] = ((pa.x + pa.y) + (pa.z + pa.w)) + pk[P_AB];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const f32x4 pc = *reinterpret_cast<const f32x4 *>(actz + SCR_C + (ch * 64 + sample) * 16);
+                out[ch] = ((pc.x + pc.y) + (pc.z + pc.w)) + pk[P_RB + ch];
+            }
+        }
+        float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
+        dist = __fmul_rn(dist, dn);
+        const float w = ra.add(out, z_cur, dist);
+        wstore.push(a, ray, s, S, part, valid, w);
+#ifndef MS6_TAP
+        if (valid && part == 0 && a.raw)
+            *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
+#endif
+        z_cur = z_next;
+    }
+    if (valid && part == 0) ra.store(a, ray);
+}
+
+// ---------------------------------------------------------------- weight stream packing
+// input column of the layer phase `ph` held by element e of half-block (b, kh); -1 = zero padding
+__device__ __forceinline__ int phase_col(int ph, int b, int kh, int e) {
+    const int p = 2 * b + kh;  // fc_0 / encodings: the owner lane's part
+    switch (ph) {
+        case 0: return 224 + 32 * p + e;
+        case 1: return 96 + 32 * p + e;
+        case 2: return e < 8 ? 8 * p + e : (e < 24 ? 32 + 16 * p + (e - 8) : -1);
+        case 3: case 4: case 5: return col_hidden(32 * b + e, kh);
+        default: return pe_slot_col(p, e);
+    }
+}
+__device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const float *f32_blob, int ph, int row, int b, int kh, int e) {
+    const int col = phase_col(ph, b, kh, e);
+    if (col < 0) return 0.f;
+    if (ph < 3) return p.fc0_w[row * 352 + col];
+    if (ph == 3) return p.fc1_w[row * 256 + col];
+    if (ph == 4) return p.fc2_w[row * 256 + col];
+    if (ph == 5) {
+        // view_w[:, :256] . (latent_w[:, :256] . feature_w): the inner product comes from the fp32 section (formed in fp64
+        // there, fragment order: invert col_hidden), the outer one is summed in fp64 here
+        const int tt = col >> 5, rr = col & 31, hi2 = (rr >> 2) & 1, r2 = (rr & 3) + 4 * (rr >> 3), q2 = 16 * tt + r2;
+        double s = 0.0;
+        for (int m = 0; m < 256; ++m)
+            s += (double)p.view_w[row * 346 + m] *
+                 (double)f32_blob[F_OFF_L4 + (((m >> 5) * 32 + (q2 >> 2)) * 64 + (hi2 * 32 + (m & 31))) * 4 + (q2 & 3)];
+        return (float)s;
+    }
+    return p.view_w[row * 346 + col];
+}
+
+// one thread per (wave, piece, lane): the lane's 16 bytes
+__global__ void nb_pack_ms6_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, unsigned *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * P_TOTAL * 64) return;
+    const int lane = t & 63, piece = (t >> 6) % P_TOTAL, w = (t >> 6) / P_TOTAL;
+    const int i = lane & 31, kg = lane >> 5;
+    int ph = 0, p0 = 0;
+    for (int q = 0; q < N_PH; ++q) {
+        const int n = phase_pieces(PH_NB[q], PH_MT[q]);
+        if (piece < p0 + n) {
+            ph = q;
+            break;
+        }
+        p0 += n;
+    }
+    const int mt = PH_MT[ph], ppb = 8 * mt;
+    const int rel = piece - p0, b = rel / ppb, r = rel % ppb;
+    unsigned w32[4] = {0u, 0u, 0u, 0u};
+    if (r < 4 * mt) {  // A16 of chunk j, tile m
+        const int j = r / mt, m = r % mt;
+        const int row = (mt == 2 ? 64 * w + 32 * m : 32 * w) + i;
+        for (int q = 0; q < 8; q += 2) {
+            const f16x2 hp = {(_Float16)phase_weight(p, f32_blob, ph, row, b, kg, 8 * j + q),
+                              (_Float16)phase_weight(p, f32_blob, ph, row, b, kg, 8 * j + q + 1)};
+            w32[q / 2] = __builtin_bit_cast(unsigned, hp);
+        }
+    } else {  // six-bit fragment: k = 0 W_h (multiplies the interleaved remainder operand), k = 1 W_l (natural order)
+        const int r6 = r - 4 * mt, k = r6 / (2 * mt), m = (r6 / 2) % mt, half = r6 & 1;
+        const int row = (mt == 2 ? 64 * w + 32 * m : 32 * w) + i;
+        float wv[32], amax = 0.f;
+        for (int e = 0; e < 32; ++e) {
+            const int n = k ? e : 16 * (e & 1) + (e >> 1);
+            const float wt = phase_weight(p, f32_blob, ph, row, b, kg, n);
+            const float h = (float)(_Float16)wt;
+            wv[e] = k ? wt - h : h;
+            amax = fmaxf(amax, fabsf(wv[e]));
+        }
+        int ex = 0;
+        if (amax > 0.f && amax < 3.0e38f) {
+            ex = ilogbf(amax / 7.5f);
+            if (ldexpf(7.5f, ex) < amax) ++ex;  // the smallest power of two with max / 2^ex <= 7.5
+            ex = min(max(ex, -120), 120);
+        }
+        unsigned w8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        for (int e = 0; e < 32; ++e) {
+            const unsigned code = fp6_e2m3_bits(ldexpf(wv[e], -ex));
+            const int bit = 6 * e;
+            w8[bit >> 5] |= code << (bit & 31);
+            if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+        }
+        w8[6] = (unsigned)(127 + ex);
+        for (int q = 0; q < 4; ++q) w32[q] = w8[4 * half + q];
+    }
+    unsigned *dst = out + ((size_t)(w * P_TOTAL + piece) * 64 + lane) * 4;
+    for (int q = 0; q < 4; ++q) dst[q] = w32[q];
+}
+
+}  // namespace
+
+namespace nbm {
+
+long long ms6_stream_floats() { return (long long)4 * P_TOTAL * 1024 / 4; }
+
+int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st) {
+    const long long n = (long long)4 * P_TOTAL * 64;
+    hipLaunchKernelGGL(nb_pack_ms6_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, st, *p, packed,
+                       reinterpret_cast<unsigned *>(packed + stream_off));
+    NB_CHECK_LAUNCH("nb_pack_ms6_kernel");
+    return NB_OK;
+}
+
+int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st) {
+    a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 64);
+    hipLaunchKernelGGL(nb_march_ms6_kernel, dim3(a.n_wave_groups), dim3(256), 0, st, a,
+                       reinterpret_cast<const char *>(a.pk + stream_off));
+    NB_CHECK_LAUNCH("nb_march_ms6_kernel");
+    return NB_OK;
+}
+
+}  // namespace nbm

@@ -149,8 +149,8 @@ class Network(nn.Module):
         # decoder GEMM arithmetic: "bf16x3" (split-bf16 MFMA, 3 products, fp32 accumulate) or "f32" (exact
         # fp32 MFMA); both stay inside the 1e-4 RGB parity budget, see DESIGN.md
         self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
-        if self.precision not in ("auto", "f32", "bf16x3", "bf16x3s", "f16f8", "f16f6"):
-            raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'bf16x3s', 'f16f8' or 'f16f6'")
+        if self.precision not in ("auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6"):
+            raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'f16f6r', 'f16f8' or 'f16f6'")
         self._auto = None  # (weight key, chosen arithmetic) of precision 'auto'
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
@@ -182,9 +182,9 @@ class Network(nn.Module):
         return d
 
     def _point_precision(self):
-        """nb_decode_points has two kernel families (exact fp32, split bf16); the march-only arithmetics ('bf16x3s',
-        'f16f8') decode stand-alone points with the split-bf16 kernels."""
-        return "bf16x3" if self.precision in ("auto", "bf16x3s", "f16f8", "f16f6") else self.precision
+        """nb_decode_points has two kernel families (exact fp32, split bf16); the march-only arithmetics ('f16f6',
+        'f16f6r', 'f16f8') decode stand-alone points with the split-bf16 kernels."""
+        return "bf16x3" if self.precision in ("auto", "f16f6r", "f16f8", "f16f6") else self.precision
 
     def march_precision(self):
         """Arithmetic of the fused march.  'auto' = 'f16f6' (cross terms in six bits, the fastest) unless the weights have
@@ -205,8 +205,6 @@ class Network(nn.Module):
         arithmetics asked for since the last change are (re)written — a training step repacks every iteration and only
         ever decodes with 'f32'."""
         need = {self.march_precision(), self._point_precision()} if precision is None else {precision}
-        if "bf16x3s" in need:
-            need.add("bf16x3")  # a culled march (nb_cull) runs the ring kernel, which reads the 'bf16x3' stream
         d = self._mlp_param_dict()
         # keyed on the parameters' storages, which the entry keeps alive (so an address cannot be recycled under the
         # key), and on their version counters (optimizer steps and load_state_dict write in place)

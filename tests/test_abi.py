@@ -21,12 +21,12 @@ def test_library_exports_every_header_symbol(lib):
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.nb_abi_version() == _lib.ABI_VERSION == 14
+    assert lib.nb_abi_version() == _lib.ABI_VERSION == 15
 
 
 def test_sizes_and_struct_layout(lib):
     # 8*44*256 + 256 + 2*(8*32*256 + 256) + 256 + 4 + 8*32*256 + 4*44*256 + 128 + 384 + 4
-    assert lib.nb_mlp_pack_size() == 333320 + 650 * 2048 // 4 + 4 * 328 * 1024 // 4 + 2 * (540 * 2048 // 4 + 16)  # fp32 fragments + bf16 ring stream + M-split streams + f16f8 and f16f6 streams with their scale words
+    assert lib.nb_mlp_pack_size() == 333320 + 650 * 2048 // 4 + 4 * 272 * 1024 // 4 + 2 * (540 * 2048 // 4 + 16)  # fp32 fragments + bf16 ring stream + M-split f16f6 streams + ring f16f8 and f16f6 streams with their scale words
     assert lib.nb_mlp_latent_bias_size() == 384
     assert C.sizeof(_lib.NbMlpParams) == 16 * 8
     assert lib.nb_scan_scratch_size(0) >= 256 and lib.nb_scan_scratch_size(1 << 20) >= 2 * 4 * (1 << 20)

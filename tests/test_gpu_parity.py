@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 ALL = list(scenes.SCENES)
-PRECISIONS = ["f32", "bf16x3", "bf16x3s", "f16f8", "f16f6"]  # nb_march kernel families
-POINT_PRECISIONS = ["f32", "bf16x3"]  # nb_decode_points kernel families ("bf16x3s" only reorganises the march)
+PRECISIONS = ["f32", "bf16x3", "f16f6r", "f16f8", "f16f6"]  # nb_march kernel families
+POINT_PRECISIONS = ["f32", "bf16x3"]  # nb_decode_points kernel families (the f16 arithmetics are march-only)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -201,7 +201,7 @@ def test_march_on_oracle_volumes_matches_reference(name, precision):
     # disp = 1 / (depth / acc): a quotient of two sums that both vanish on rays grazing the body, so it amplifies the weights'
     # error there (the worst pixel of small_eval has acc 0.03); the six-bit cross terms get 5e-4 for it, everything else
     # keeps the common tolerances
-    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 5e-4 if precision == "f16f6" else 3e-4, "disp_map")
+    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 5e-4 if precision in ("f16f6", "f16f6r") else 3e-4, "disp_map")
     assert float(g["rgb_map"].max()) > 0.1, "fixture is degenerate"
 
 
@@ -399,7 +399,7 @@ def test_render_end_to_end_matches_reference(name, precision):
             pv = rend.get_pixel_value(bd["ray_o"], bd["ray_d"], bd["near"], bd["far"], vols, sp, bd)
             # the unfused path decodes points with the split-bf16 kernels whatever the march arithmetic is: for 'f16f8' the
             # two sides round differently (each within its own budget against the reference), otherwise they agree closely
-            H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 6e-5 if precision in ("f16f8", "f16f6") else 1e-5,
+            H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 6e-5 if precision in ("f16f8", "f16f6", "f16f6r") else 1e-5,
                            "fused vs unfused rgb")
 
 
