@@ -75,6 +75,8 @@ struct SceneDev {
     const float *pose;
     float vs[3];
     float osh[3];
+    float fm1[4][3], fp1[4][3];  // (float)(size - 1), (float)size + 1 of every level: scalar operands (a kernel that converts
+                                 // them itself keeps the results in VGPRs across its depth loop)
 };
 
 // sample culling against training-view silhouettes (nb_cull): the reference's fp32 operation order
@@ -615,6 +617,8 @@ inline int fill_scene(const nb_scene *s, SceneDev *d) {
         for (int k = 0; k < 3; ++k) {
             NB_REQUIRE(s->vol_dhw[l][k] >= 1, "nb_scene.vol_dhw[%d][%d] = %d", l, k, s->vol_dhw[l][k]);
             d->dhw[l][k] = s->vol_dhw[l][k];
+            d->fm1[l][k] = (float)(s->vol_dhw[l][k] - 1);
+            d->fp1[l][k] = (float)s->vol_dhw[l][k] + 1.f;
         }
     }
     NB_REQUIRE(s->pose != nullptr, "nb_scene.pose is NULL (device block R[9] | Th[3] | bounds_min[3])");

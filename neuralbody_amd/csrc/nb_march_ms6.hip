@@ -80,8 +80,17 @@ constexpr int SCR_C = SCR_A + 1024;            // rgb_fc partial sums [3][64][4]
 // phase would drain the weight ring's vmcnt queue): offsets in floats
 constexpr int PRM_OFF = SCR_C + 3072;
 constexpr int P_B0 = 0, P_B1 = 256, P_B2 = 512, P_AW = 768, P_RW = 1024, P_AB = 1408, P_RB = 1412, P_LB = 1416, P_SIZE = 1544;
-constexpr int LDS_BYTES = PRM_OFF + P_SIZE * 4;
+// per-sample ray record (20 floats): ox oy oz near | dx dy dz far | vx vy vz |d| | T r g b | depth acc - - (the compositing
+// state).  It lives here and not in registers: with 256 registers per wave hipcc spills ~70 long-lived per-ray values to
+// scratch, and every reload is a memory round trip behind an `s_waitcnt vmcnt` (tools/experiments/ms6_phase_times.py)
+constexpr int RAY_OFF = PRM_OFF + P_SIZE * 4, RAY_FLOATS = 20;
+static_assert(RAY_OFF % 16 == 0, "16-byte aligned records");
+#ifdef MS6_ONEWG
+constexpr int LDS_BYTES = RAY_OFF + 64 * RAY_FLOATS * 4 + 16384;  // experiment: one workgroup per CU
+#else
+constexpr int LDS_BYTES = RAY_OFF + 64 * RAY_FLOATS * 4;
 static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
+#endif
 __device__ __forceinline__ int tile_off(int wave) { return wave < 2 ? 8 * CH_BYTES + wave * TILE_BYTES : ACT6_OFF + 2 * 4 * F6_BYTES + (wave - 2) * TILE_BYTES; }
 
 __device__ __forceinline__ f32x16 bias_tile_g(const float *bp, int t, int hi) {
@@ -93,21 +102,51 @@ __device__ __forceinline__ f32x16 bias_tile_g(const float *bp, int t, int hi) {
 // ---------------------------------------------------------------- operands -> LDS
 // 32 values of one half-block (block b, half kh) of sample column `slot` (0..31) of N tile n: fp16 heads into the four
 // chunks of the block, the two bf6 forms + their E8M0 scales into the block's fragments
-template <bool RELU, class Get>
-__device__ __forceinline__ void write_halfblock(char *act, int b, int kh, int n, int slot, Get get) {
+struct HalfBlock {
     f16x8 xh[4];
+    i32x6 xl, xx;
+    int eb;
+};
+template <bool RELU, class Get>
+__device__ __forceinline__ HalfBlock convert_halfblock(Get get) {
+    HalfBlock h;
     i32x6 xl[1], xx[1];
     int eb[1];
-    make_operands6<2, RELU>(get, xh, xl, xx, eb);
+#ifdef MS6_ABL_NOCONV
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) h.xh[j][q] = (_Float16)0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h.xh[q][0] = __builtin_bit_cast(f16x2, __float_as_uint(get(8 * q)))[0];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        xl[0][q] = __float_as_int(get(q + 8));
+        xx[0][q] = __float_as_int(get(q + 16));
+    }
+    eb[0] = 127;
+#else
+    make_operands6<2, RELU>(get, h.xh, xl, xx, eb);
+#endif
+    h.xl = xl[0];
+    h.xx = xx[0];
+    h.eb = eb[0];
+    return h;
+}
+__device__ __forceinline__ void store_halfblock(char *act, int b, int kh, int n, int slot, const HalfBlock &h) {
     const int ls = (kh * 32 + slot) * 16;
     char *p16 = act + (4 * b) * CH_BYTES + n * 1024 + ls;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f16x8 *>(p16 + j * CH_BYTES) = xh[j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f16x8 *>(p16 + j * CH_BYTES) = h.xh[j];
     char *p6 = act + ACT6_OFF + ((b * 2 + 0) * 2 + n) * F6_BYTES + ls;
-    *reinterpret_cast<i32x4 *>(p6) = i32x4{xx[0][0], xx[0][1], xx[0][2], xx[0][3]};
-    *reinterpret_cast<i32x4 *>(p6 + 1024) = i32x4{xx[0][4], xx[0][5], eb[0], 0};
-    *reinterpret_cast<i32x4 *>(p6 + 2 * F6_BYTES) = i32x4{xl[0][0], xl[0][1], xl[0][2], xl[0][3]};
-    *reinterpret_cast<i32x4 *>(p6 + 2 * F6_BYTES + 1024) = i32x4{xl[0][4], xl[0][5], eb[0] - 11, 0};
+    *reinterpret_cast<i32x4 *>(p6) = i32x4{h.xx[0], h.xx[1], h.xx[2], h.xx[3]};
+    *reinterpret_cast<i32x4 *>(p6 + 1024) = i32x4{h.xx[4], h.xx[5], h.eb, 0};
+    *reinterpret_cast<i32x4 *>(p6 + 2 * F6_BYTES) = i32x4{h.xl[0], h.xl[1], h.xl[2], h.xl[3]};
+    *reinterpret_cast<i32x4 *>(p6 + 2 * F6_BYTES + 1024) = i32x4{h.xl[4], h.xl[5], h.eb - 11, 0};
+}
+template <bool RELU, class Get>
+__device__ __forceinline__ void write_halfblock(char *act, int b, int kh, int n, int slot, Get get) {
+    store_halfblock(act, b, kh, n, slot, convert_halfblock<RELU>(get));
 }
 
 // ---------------------------------------------------------------- one layer phase of this wave
@@ -123,6 +162,9 @@ struct WSrc {
     unsigned voff;  // lane * 16
 };
 __device__ __forceinline__ i32x4 load_piece(const WSrc &wl, int p) {
+#ifdef MS6_ABL_NOW
+    return i32x4{(int)wl.voff, p, 0, 0};
+#endif
     const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(wl.rsrc, wl.voff, (p % P_TOTAL) * 1024, 0);
     return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
 }
@@ -254,18 +296,22 @@ __device__ __forceinline__ void init_bias(const float *bp, int tile0, int hi, f3
 }
 
 // relu'd accumulators of this wave (two tiles x two N tiles) -> K block `wave` of the next layer, in place: the lane's 16 +
-// 16 values of an N tile are half-block (wave, hi) and go into the lane's own fragment slot
+// 16 values of an N tile are half-block (wave, hi) and go into the lane's own fragment slot.  The conversion runs BEFORE the
+// barrier that retires the previous activations (it needs this wave's accumulators only), the stores behind it.
 __device__ __forceinline__ void publish_s(char *act, int lane, int wave, f32x16 (&acc)[2][2]) {
     const int i = lane & 31, hi = lane >> 5;
-    __syncthreads();  // every wave is done reading the previous activations
+    HalfBlock h[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = relu1(acc[m][n][r]);
-        write_halfblock<false>(act, wave, hi, n, i, [&](int q) { return q < 16 ? acc[0][n][q & 15] : acc[1][n][q & 15]; });
+        h[n] = convert_halfblock<false>([&](int q) { return q < 16 ? acc[0][n][q & 15] : acc[1][n][q & 15]; });
     }
+    __syncthreads();  // every wave is done reading the previous activations
+#pragma unroll
+    for (int n = 0; n < 2; ++n) store_halfblock(act, wave, hi, n, i, h[n]);
     __syncthreads();
 }
 
@@ -285,27 +331,106 @@ __device__ __forceinline__ float red_max16(float v) {
     return v;
 }
 
-// channels [part * C/4, (part+1) * C/4) of level L for this lane's sample; same corner order, weights and zero
-// padding as gather_level / gather_level_coop (nb_march_common.h), tile = wave-private LDS
-template <int L, typename Sink>
-__device__ __forceinline__ void gather_parts(const SceneDev &sc, const GridCoord &g, const WaveBox &wb, int part, int lane,
-                                             char *buf, Sink sink) {
-    constexpr int C = lvl_c(L), QC = C / 4, PC = C / 4;  // PC 16-byte pieces per voxel
-    constexpr int MAX_IT = TILE_BYTES / 1024;
+// unnorm_clamped (nb_march_common.h) with the level's (float)(size - 1) and (float)size + 1 as scalar kernel arguments
+__device__ __forceinline__ float unnorm_s(float gcoord, float fm1, float fp1) {
+    const float i = __fmul_rn(__fdiv_rn(__fadd_rn(gcoord, 1.f), 2.f), fm1);
+    return fminf(fmaxf(i, -2.f), fp1);
+}
+
+// The wave's index box of level L (wave-uniform: SGPRs) for the grid box `wb` of its 16 samples.
+struct VoxBox {
+    int xlo, ylo, zlo, xhi, yhi, zhi;
+};
+template <int L>
+__device__ __forceinline__ VoxBox vox_box(const SceneDev &sc, const WaveBox &wb) {
     const int D = sc.dhw[L][0], H = sc.dhw[L][1], W = sc.dhw[L][2];
-    const float ix = unnorm_clamped(g.gw, W), iy = unnorm_clamped(g.gh, H), iz = unnorm_clamped(g.gd, D);
+    VoxBox b;
+    b.xlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_s(wb.lo.gw, sc.fm1[L][2], sc.fp1[L][2])), 0), W - 1));
+    b.ylo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_s(wb.lo.gh, sc.fm1[L][1], sc.fp1[L][1])), 0), H - 1));
+    b.zlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_s(wb.lo.gd, sc.fm1[L][0], sc.fp1[L][0])), 0), D - 1));
+    b.xhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_s(wb.hi.gw, sc.fm1[L][2], sc.fp1[L][2])) + 1, 0), W - 1));
+    b.yhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_s(wb.hi.gh, sc.fm1[L][1], sc.fp1[L][1])) + 1, 0), H - 1));
+    b.zhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_s(wb.hi.gd, sc.fm1[L][0], sc.fp1[L][0])) + 1, 0), D - 1));
+    return b;
+}
+__device__ __forceinline__ WaveBox wave_box16(const GridCoord &g) {
+    WaveBox wb;
+    wb.lo.gw = red_min16(g.gw);
+    wb.lo.gh = red_min16(g.gh);
+    wb.lo.gd = red_min16(g.gd);
+    wb.hi.gw = red_max16(g.gw);
+    wb.hi.gh = red_max16(g.gh);
+    wb.hi.gd = red_max16(g.gd);
+    return wb;
+}
+
+// Voxel tile of level L -> wave-private LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B per instruction, no
+// registers, no ds_write): piece p = (voxel v of the box, 16-byte quad q of its channel vector) lands at tile + p * 16.
+// Issued ONE PHASE AHEAD of the blend that reads it (the fetch latency, 1-2 k cycles from L2, was the largest single item of
+// a depth step: profiles/r03_ms6_phases.md), from inline asm so that hipcc keeps counting the weight ring's vmcnt (a DMA it
+// knows of makes it wait vmcnt(0) at every ring use); the blend waits vmcnt(0) itself, at a point where the ring is empty.
+// `lds_tile` = LDS byte address of the tile (wave-uniform), LIMIT = its size in bytes.
+template <int L, int LIMIT>
+__device__ __forceinline__ void tile_dma(const SceneDev &sc, const VoxBox &b, int lane, unsigned lds_tile) {
+    constexpr int C = lvl_c(L), PC = C / 4;
+    constexpr int MAX_IT = LIMIT / 1024;
+#ifdef MS6_ABL_NOGATHER
+    return;
+#endif
+    const int H = sc.dhw[L][1], W = sc.dhw[L][2];
+    const int nx = b.xhi - b.xlo + 1, ny = b.yhi - b.ylo + 1, nz = b.zhi - b.zlo + 1;
+    const int pieces = nx * ny * nz * PC;
+    // the previous tile's reads have returned (their values were consumed), but say so
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (pieces > LIMIT / 16) return;  // wave-uniform: the blend reads the corners from global memory
+    const float rcp_xy = 1.f / (float)(nx * ny), rcp_x = 1.f / (float)nx;
+    const float *vol = sc.vol[L];
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        if (it * 64 < pieces) {  // wave-uniform
+            const int p = min(it * 64 + lane, pieces - 1);
+            const int v = p / PC, q = p % PC;
+            const int vz = (int)(((float)v + 0.5f) * rcp_xy);
+            const int r = v - vz * nx * ny;
+            const int vy = (int)(((float)r + 0.5f) * rcp_x);
+            const int vx = r - vy * nx;
+            const unsigned lin = (unsigned)(((b.zlo + vz) * H + (b.ylo + vy)) * W + (b.xlo + vx));
+            const unsigned voff = (lin * C + q * 4) * 4u;  // byte offset: the largest volume is 104 MB
+            const unsigned dst = lds_tile + it * 1024;
+            asm volatile(
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %0, %1"
+                :
+                : "v"(voff), "s"(vol), "s"(dst)
+                : "memory", "m0");
+        }
+    }
+}
+
+// channels [part * C/4, (part+1) * C/4) of level L for this lane's sample from the tile fetched by tile_dma<L, LIMIT> (the
+// caller has waited for it); same corner order, weights and zero padding as gather_level (nb_march_common.h)
+template <int L, int LIMIT, typename Sink>
+__device__ __forceinline__ void gather_parts(const SceneDev &sc, const GridCoord &g, const VoxBox &b, int part, const char *buf, Sink sink) {
+    constexpr int C = lvl_c(L), QC = C / 4, PC = C / 4;
+#ifdef MS6_ABL_NOGATHER
+#pragma unroll
+    for (int grp = 0; grp < QC / 8; ++grp) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = g.gw * (float)(e + 1 + grp) + g.gh;
+        sink(grp, o8);
+    }
+    return;
+#endif
+    const int D = sc.dhw[L][0], H = sc.dhw[L][1], W = sc.dhw[L][2];
+    const float ix = unnorm_s(g.gw, sc.fm1[L][2], sc.fp1[L][2]), iy = unnorm_s(g.gh, sc.fm1[L][1], sc.fp1[L][1]), iz = unnorm_s(g.gd, sc.fm1[L][0], sc.fp1[L][0]);
     const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
     const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
     const float wx[2] = {(fx + 1.f) - ix, ix - fx};
     const float wy[2] = {(fy + 1.f) - iy, iy - fy};
     const float wz[2] = {(fz + 1.f) - iz, iz - fz};
-    const int xlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gw, W)), 0), W - 1));
-    const int ylo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gh, H)), 0), H - 1));
-    const int zlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gd, D)), 0), D - 1));
-    const int xhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gw, W)) + 1, 0), W - 1));
-    const int yhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gh, H)) + 1, 0), H - 1));
-    const int zhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gd, D)) + 1, 0), D - 1));
-    const int nx = xhi - xlo + 1, ny = yhi - ylo + 1, nz = zhi - zlo + 1;
+    const int nx = b.xhi - b.xlo + 1, ny = b.yhi - b.ylo + 1, nz = b.zhi - b.zlo + 1;
     const int pieces = nx * ny * nz * PC;
     float cw[8];
 #pragma unroll
@@ -315,40 +440,13 @@ __device__ __forceinline__ void gather_parts(const SceneDev &sc, const GridCoord
         const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
         cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
     }
-    if (pieces <= TILE_BYTES / 16) {  // wave-uniform: the wave's voxel box fits its tile
-        const float rcp_xy = 1.f / (float)(nx * ny), rcp_x = 1.f / (float)nx;
-#pragma unroll
-        for (int b = 0; b < MAX_IT; b += 4) {  // four coalesced 1-KiB fetches in flight at a time (register budget)
-            if (b * 64 < pieces) {
-                f32x4 t[4];
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    if ((b + it) * 64 < pieces) {
-                        const int p = min((b + it) * 64 + lane, pieces - 1);
-                        const int v = p / PC, q = p % PC;
-                        const int vz = (int)(((float)v + 0.5f) * rcp_xy);
-                        const int r = v - vz * nx * ny;
-                        const int vy = (int)(((float)r + 0.5f) * rcp_x);
-                        const int vx = r - vy * nx;
-                        const size_t lin = ((size_t)((zlo + vz) * H + (ylo + vy))) * W + (xlo + vx);
-                        t[it] = *reinterpret_cast<const f32x4 *>(sc.vol[L] + lin * C + q * 4);
-                    }
-                }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    if ((b + it) * 64 < pieces) {
-                        const int p = (b + it) * 64 + lane;
-                        if (p < pieces) *reinterpret_cast<f32x4 *>(buf + p * 16) = t[it];
-                    }
-                }
-            }
-        }
+    if (pieces <= LIMIT / 16) {  // wave-uniform: the wave's voxel box is in its tile
         int co[8];
 #pragma unroll
         for (int corner = 0; corner < 8; ++corner) {
             const int xx = x0 + (corner & 1), yy = y0 + ((corner >> 1) & 1), zz = z0 + (corner >> 2);
-            const int xc = min(max(xx, xlo), xhi), yc = min(max(yy, ylo), yhi), zc = min(max(zz, zlo), zhi);
-            co[corner] = ((((zc - zlo) * ny + (yc - ylo)) * nx + (xc - xlo)) * C + part * QC) * 4;
+            const int xc = min(max(xx, b.xlo), b.xhi), yc = min(max(yy, b.ylo), b.yhi), zc = min(max(zz, b.zlo), b.zhi);
+            co[corner] = ((((zc - b.zlo) * ny + (yc - b.ylo)) * nx + (xc - b.xlo)) * C + part * QC) * 4;
         }
 #pragma unroll
         for (int grp = 0; grp < QC / 8; ++grp) {  // 8 channels at a time
@@ -399,6 +497,8 @@ __device__ __forceinline__ void gather_parts(const SceneDev &sc, const GridCoord
         }
     }
 }
+// the tile a blend is about to read has landed (no weight-ring load is in flight at the points where this is called)
+__device__ __forceinline__ void tile_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // compositing state of the weights output: 16 consecutive depth steps of a ray = 64 bytes, 4 steps per owner lane
 struct WeightStore4 {
@@ -431,6 +531,19 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 }
 
 // ---------------------------------------------------------------- the kernel
+// MS6_TIMING (experiment builds): wave 0 of the first 32 workgroups stamps the cycle counter at the phase boundaries of every
+// depth step into the `raw` output as [workgroup][step][32] (tools/experiments/ms6_phase_times.py)
+#ifdef MS6_TIMING
+#define MS6_STAMP(i)                                                                                         \
+    do {                                                                                                     \
+        if (tbuf) {                                                                                          \
+            const unsigned long long t__ = __builtin_readcyclecounter();                                     \
+            if (lane == 0) tbuf[(i)] = (unsigned)t__;                                                        \
+        }                                                                                                    \
+    } while (0)
+#else
+#define MS6_STAMP(i) do { } while (0)
+#endif
 // MS6_TAP (debug builds): workgroup 0 dumps, at depth step 0, every layer's accumulators as [layer][feature][sample]
 // fp32 into a.raw instead of the raw output (fc_0, fc_1, fc_2 pre-activation: 3 x 256 x 64; folded view layer: 128 x 64) —
 // tools/experiments/ms6_tap_check.py compares them with nb_decode_points' fp32 activation tap
@@ -452,20 +565,16 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
     const float near = a.near[ray], far = a.far[ray];
     const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
     const float vx = dx / dn, vy = dy / dn, vz = dz / dn;
-    // positional encoding of the view direction for this lane's axis (constant along the ray): v, sin/cos(v 2^k), k < 4
-    float vpe[9];
-    {
-        const float va = part == 0 ? vx : (part == 1 ? vy : vz);
-        const double t = (double)va * NB_INV_2PI;
-        vpe[0] = va;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            vpe[1 + 2 * k] = sin_rev(t * (double)(1 << k));
-            vpe[2 + 2 * k] = sin_rev(t * (double)(1 << k) + 0.25);
-        }
+    if (part == 0) {
+        f32x4 *rec = reinterpret_cast<f32x4 *>(lds + RAY_OFF) + sample * (RAY_FLOATS / 4);
+        rec[0] = f32x4{ox, oy, oz, near};
+        rec[1] = f32x4{dx, dy, dz, far};
+        rec[2] = f32x4{vx, vy, vz, dn};
+        rec[3] = f32x4{1.f, 0.f, 0.f, 0.f};
+        rec[4] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float *tr = a.t_rand ? a.t_rand + ray * S : nullptr;
-    auto z_at = [&](int s) -> float {
+    auto z_at = [&](int s, float near, float far) -> float {
         const float zc = z_lin(near, far, a.t_vals[s]);
         if (!tr) return zc;
         const float lower = s == 0 ? zc : 0.5f * __fadd_rn(zc, z_lin(near, far, a.t_vals[s - 1]));
@@ -493,59 +602,96 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(stream) + (size_t)wave * P_TOTAL * 1024, 0, P_TOTAL * 1024, 0x00020000);
     WRing ring;
 
-    RayAccum ra;
     WeightStore4 wstore;
-    float z_cur = z_at(0);
+    float z_cur = z_at(0, near, far);
+    typedef void __attribute__((address_space(3))) *lptr_t;
+    const unsigned lds_tile = (unsigned)(unsigned long long)(lptr_t)(lds + tile_off(wave));  // wave-uniform LDS byte address
+    // grid coordinates and box of the step about to be marched (carried from the point where its first tile is requested)
+    GridCoord g = grid_coords(a.sc, __fadd_rn(ox, __fmul_rn(dx, z_cur)), __fadd_rn(oy, __fmul_rn(dy, z_cur)), __fadd_rn(oz, __fmul_rn(dz, z_cur)));
+    WaveBox wb = wave_box16(g);
+    tile_dma<3, TILE_BYTES>(a.sc, vox_box<3>(a.sc, wb), lane, lds_tile);
     for (int s = 0; s < S; ++s) {
         // loop-invariant address roots are laundered so that LICM does not hoist (and spill) hundreds of addresses
         int zero = 0, lane_i = lane;
         asm volatile("" : "+s"(zero), "+v"(lane_i));
+        // (these shadow the prologue's: everything derived from the lane id is re-derived from the laundered copy)
+        const int hi = lane_i >> 5, os = lane_i & 15, part = lane_i >> 4, sample = 16 * wave + os;
         const WSrc wl = {wrsrc, (unsigned)lane_i * 16u};
         char *actz = act + zero;
         char *tile = actz + tile_off(wave);
         const float *pk = reinterpret_cast<const float *>(actz + PRM_OFF);
-        const float z_next = (s + 1 < S) ? z_at(s + 1) : 0.f;
-        const float px = __fadd_rn(ox, __fmul_rn(dx, z_cur));
-        const float py = __fadd_rn(oy, __fmul_rn(dy, z_cur));
-        const float pz = __fadd_rn(oz, __fmul_rn(dz, z_cur));
+        const f32x4 *rec = reinterpret_cast<const f32x4 *>(actz + RAY_OFF) + sample * (RAY_FLOATS / 4);
         f32x16 acc[2][2];
         const int sn = sample >> 5, ss = sample & 31;  // N tile and column of this lane's sample
+#ifdef MS6_TIMING
+        unsigned *tbuf = (blockIdx.x < 32 && wave == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + ((size_t)blockIdx.x * S + s) * 32 : nullptr;
+#endif
+        MS6_STAMP(0);
 
-        // ---- fc_0 in three K phases of 128 = two blocks; part p fills half-block (p >> 1, p & 1)
+        // ---- fc_0 in three K phases of 128 = two blocks; part p fills half-block (p >> 1, p & 1).  The voxel tile of each
+        // phase was requested (LDS-DMA) a phase earlier: level 3 behind the previous step's view layer, level 2 behind this
+        // step's first blend, levels 0 and 1 (half a tile each) behind the second
         {
-            const GridCoord g = grid_coords(a.sc, px, py, pz);
-            WaveBox wb;
-            wb.lo.gw = red_min16(g.gw);
-            wb.lo.gh = red_min16(g.gh);
-            wb.lo.gd = red_min16(g.gd);
-            wb.hi.gw = red_max16(g.gw);
-            wb.hi.gh = red_max16(g.gh);
-            wb.hi.gd = red_max16(g.gd);
             float v[32];
-            gather_parts<3>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+            const VoxBox b3 = vox_box<3>(a.sc, wb);
+            tile_wait();
+            gather_parts<3, TILE_BYTES>(a.sc, g, b3, part, tile, [&](int grp8, const float (&o)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
             });
-            write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return v[q]; });
+            const VoxBox b2 = vox_box<2>(a.sc, wb);
+            {
+                HalfBlock hb = convert_halfblock<false>([&](int q) { return v[q]; });
+                tile_dma<2, TILE_BYTES>(a.sc, b2, lane_i, lds_tile);
+                store_halfblock(actz, part >> 1, part & 1, sn, ss, hb);
+            }
             ring_prime<P_A>(wl, ring);
             init_bias<2>(pk + P_B0, 2 * wave, hi, acc);
+            MS6_STAMP(1);
             __syncthreads();
+            MS6_STAMP(2);
             layer_s<P_A, 2, 2, false>(wl, actz, lane_i, ring, acc);
+            MS6_STAMP(3);
             __syncthreads();
-            gather_parts<2>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+            MS6_STAMP(4);
+            tile_wait();
+            MS6_STAMP(26);
+            gather_parts<2, TILE_BYTES>(a.sc, g, b2, part, tile, [&](int grp8, const float (&o)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
             });
-            write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return v[q]; });
+#ifdef MS6_TIMING
+            asm volatile("" : "+v"(v[0]), "+v"(v[8]), "+v"(v[16]), "+v"(v[24]), "+v"(v[31]));
+#endif
+            MS6_STAMP(27);
+            const VoxBox b0 = vox_box<0>(a.sc, wb), b1 = vox_box<1>(a.sc, wb);
+            MS6_STAMP(28);
+            {
+                HalfBlock hb = convert_halfblock<false>([&](int q) { return v[q]; });
+#ifdef MS6_TIMING
+                asm volatile("" : "+v"(hb.xl), "+v"(hb.xx));
+#endif
+                MS6_STAMP(29);
+                tile_dma<0, TILE_BYTES / 2>(a.sc, b0, lane_i, lds_tile);
+                tile_dma<1, TILE_BYTES / 2>(a.sc, b1, lane_i, lds_tile + TILE_BYTES / 2);
+                MS6_STAMP(30);
+                store_halfblock(actz, part >> 1, part & 1, sn, ss, hb);
+            }
+            MS6_STAMP(31);
             ring_prime<P_B>(wl, ring);
+            MS6_STAMP(5);
             __syncthreads();
+            MS6_STAMP(6);
             layer_s<P_B, 2, 2, false>(wl, actz, lane_i, ring, acc);
+            MS6_STAMP(7);
             __syncthreads();
-            gather_parts<0>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+            MS6_STAMP(8);
+            tile_wait();
+            gather_parts<0, TILE_BYTES / 2>(a.sc, g, b0, part, tile, [&](int grp8, const float (&o)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
             });
-            gather_parts<1>(a.sc, g, wb, part, lane_i, tile, [&](int grp8, const float (&o)[8]) {
+            gather_parts<1, TILE_BYTES / 2>(a.sc, g, b1, part, tile + TILE_BYTES / 2, [&](int grp8, const float (&o)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 + 8 * grp8 + e] = o[e];
             });
@@ -553,8 +699,11 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             for (int e = 24; e < 32; ++e) v[e] = 0.f;
             write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return v[q]; });
             ring_prime<P_C>(wl, ring);
+            MS6_STAMP(9);
             __syncthreads();
+            MS6_STAMP(10);
             layer_s<P_C, 2, 2, true>(wl, actz, lane_i, ring, acc);
+            MS6_STAMP(11);
         }
 #ifdef MS6_TAP
 #define MS6_DUMP(LAYER, MT_)                                                                                              \
@@ -569,15 +718,20 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
 #endif
         MS6_DUMP(0, 2)
         publish_s(actz, lane_i, wave, acc);
+        MS6_STAMP(12);
         // ---- fc_1, fc_2
         init_bias<2>(pk + P_B1, 2 * wave, hi, acc);
         layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc);
+        MS6_STAMP(13);
         MS6_DUMP(1, 2)
         publish_s(actz, lane_i, wave, acc);
+        MS6_STAMP(14);
         init_bias<2>(pk + P_B2, 2 * wave, hi, acc);
         layer_s<P_L2, 2, 4, true>(wl, actz, lane_i, ring, acc);
+        MS6_STAMP(15);
         MS6_DUMP(2, 2)
         publish_s(actz, lane_i, wave, acc);  // acc now holds relu(h3)
+        MS6_STAMP(16);
         // ---- alpha_fc: partial dot product over this wave's 64 features, finished by the owner lanes
         {
 #pragma unroll
@@ -602,8 +756,26 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         // ---- the colour head's linear part as ONE layer (feature_fc . latent_fc . view_fc folded at pack time, bias: second
         // block of nb_mlp_latent_bias): one tile per wave, K phase over fc_2's outputs, then over the encodings
         init_bias<1>(pk + P_LB, wave, hi, acc);
-        layer_s<P_VG, 1, 4, true>(wl, actz, lane_i, ring, acc);
+        MS6_STAMP(17);
+        layer_s<P_VG, 1, 4, false>(wl, actz, lane_i, ring, acc);
+        MS6_STAMP(18);
         __syncthreads();
+        MS6_STAMP(19);
+        // the upper halves of the activation buffers are free until the next step's fc_0 is published: request the next
+        // step's level-3 tile now (in flight under the encodings, the last MFMA phase, the heads and the compositing)
+        const f32x4 ro = rec[0], rd = rec[1];  // ox oy oz near | dx dy dz far
+        const float z_next = (s + 1 < S) ? z_at(s + 1, ro.w, rd.w) : 0.f;
+        const float px = __fadd_rn(ro.x, __fmul_rn(rd.x, z_cur));
+        const float py = __fadd_rn(ro.y, __fmul_rn(rd.y, z_cur));
+        const float pz = __fadd_rn(ro.z, __fmul_rn(rd.z, z_cur));
+        {
+            const float nx_ = __fadd_rn(ro.x, __fmul_rn(rd.x, z_next)), ny_ = __fadd_rn(ro.y, __fmul_rn(rd.y, z_next)),
+                        nz_ = __fadd_rn(ro.z, __fmul_rn(rd.z, z_next));
+            g = grid_coords(a.sc, nx_, ny_, nz_);
+            wb = wave_box16(g);
+            tile_dma<3, TILE_BYTES>(a.sc, vox_box<3>(a.sc, wb), lane_i, lds_tile);
+        }
+        ring_prime<P_VP>(wl, ring);  // behind the DMA (vmcnt retires in order), ahead of the encodings that cover its latency
         {
             // encodings: lane (sample, axis a = part < 3) fills half-block (part >> 1, part & 1); part 3 writes zeros
             const float xa = part == 0 ? px : (part == 1 ? py : pz);
@@ -611,19 +783,37 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             const float keep = part < 3 ? 1.f : 0.f;
             float e[32];
             e[0] = xa;
+#ifdef MS6_ABL_NOPE
+#pragma unroll
+            for (int k = 0; k < 20; ++k) e[1 + k] = xa * (float)k;
+#else
 #pragma unroll
             for (int k = 0; k < 10; ++k) {
                 e[1 + 2 * k] = sin_rev(t * (double)(1 << k));
                 e[2 + 2 * k] = sin_rev(t * (double)(1 << k) + 0.25);
             }
+#endif
+            {
+                // the view direction's encodings are constant along the ray; recomputed (8 v_sin) rather than carried
+                const f32x4 rv = rec[2];  // vx vy vz |d|
+                const float va = part == 0 ? rv.x : (part == 1 ? rv.y : rv.z);
+                const double tv = (double)va * NB_INV_2PI;
+                e[21] = va;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) e[21 + k] = vpe[k];
+                for (int k = 0; k < 4; ++k) {
+                    e[22 + 2 * k] = sin_rev(tv * (double)(1 << k));
+                    e[23 + 2 * k] = sin_rev(tv * (double)(1 << k) + 0.25);
+                }
+            }
             e[30] = 0.f;
             e[31] = 0.f;
             write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return e[q] * keep; });
         }
+        MS6_STAMP(20);
         __syncthreads();
+        MS6_STAMP(21);
         layer_s<P_VP, 1, 2, false>(wl, actz, lane_i, ring, acc);
+        MS6_STAMP(22);
         MS6_DUMP(3, 1)
         // ---- rgb_fc partial sums over this wave's 32 view features
         {
@@ -645,7 +835,9 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
                     if (hi == 0) reinterpret_cast<float *>(actz + SCR_C)[(ch * 64 + n * 32 + (lane_i & 31)) * 4 + wave] = sc;
                 }
         }
+        MS6_STAMP(23);
         __syncthreads();
+        MS6_STAMP(24);
         // ---- owner lanes: finish the heads, composite
         float out[4];
         {
@@ -658,16 +850,33 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             }
         }
         float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
-        dist = __fmul_rn(dist, dn);
+        dist = __fmul_rn(dist, rec[2].w);
+        RayAccum ra;
+        {
+            const f32x4 c0 = rec[3], c1 = rec[4];
+            ra.T = c0.x; ra.cr = c0.y; ra.cg = c0.z; ra.cb = c0.w; ra.depth = c1.x; ra.accw = c1.y;
+        }
         const float w = ra.add(out, z_cur, dist);
+        if (part == 0) {
+            f32x4 *recw = reinterpret_cast<f32x4 *>(actz + RAY_OFF) + sample * (RAY_FLOATS / 4);
+            recw[3] = f32x4{ra.T, ra.cr, ra.cg, ra.cb};
+            recw[4] = f32x4{ra.depth, ra.accw, 0.f, 0.f};
+        }
         wstore.push(a, ray, s, S, part, valid, w);
-#ifndef MS6_TAP
+        MS6_STAMP(25);
+#if !defined(MS6_TAP) && !defined(MS6_TIMING)
         if (valid && part == 0 && a.raw)
             *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
 #endif
         z_cur = z_next;
     }
-    if (valid && part == 0) ra.store(a, ray);
+    if (valid && part == 0) {
+        const f32x4 *rec = reinterpret_cast<const f32x4 *>(lds + RAY_OFF) + sample * (RAY_FLOATS / 4);
+        const f32x4 c0 = rec[3], c1 = rec[4];
+        RayAccum ra;
+        ra.T = c0.x; ra.cr = c0.y; ra.cg = c0.z; ra.cb = c0.w; ra.depth = c1.x; ra.accw = c1.y;
+        ra.store(a, ray);
+    }
 }
 
 // ---------------------------------------------------------------- weight stream packing

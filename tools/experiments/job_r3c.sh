@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+mkdir -p gpurun_out/r3c
+NB_LIB_PATH=$PWD/neuralbody_amd/lib/libnb_hip_ms6TIMING.so python tools/experiments/ms6_phase_times.py > gpurun_out/r3c/phases_2wg.log 2>&1
+cat gpurun_out/r3c/phases_2wg.log
+NB_LIB_PATH=$PWD/neuralbody_amd/lib/libnb_hip_ms6TIMING_ONEWG.so python tools/experiments/ms6_phase_times.py > gpurun_out/r3c/phases_1wg.log 2>&1
+cat gpurun_out/r3c/phases_1wg.log
