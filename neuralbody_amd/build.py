@@ -21,6 +21,12 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.
          "-Wno-unused-result"] + os.environ.get("NB_EXTRA_FLAGS", "").split()
 
 
+# per-file flags.  nb_march_ms6.hip: hipcc's SLP vectoriser packs the gather's and the heads' scalar fp32 FMAs into v_pk_fma_f32,
+# which on gfx950 costs an order of magnitude more issue time than the two v_fma_f32 it replaces (MI355X_MICROARCH.md,
+# "price of one filler": +22 cycles per v_pk_fma_f32) and needs aligned register pairs (33 spilled registers with, 0 without)
+FILE_FLAGS = {"nb_march_ms6.hip": ["-fno-slp-vectorize"]}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -33,6 +39,7 @@ def _digest():
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -58,7 +65,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src)[:-4] + SUFFIX + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + FILE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         if verbose:
             print("[nb build]", " ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

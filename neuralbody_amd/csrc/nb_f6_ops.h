@@ -72,7 +72,9 @@ __device__ __forceinline__ void make_operands6(Get get, f16x8 (&xh)[2 * NG], i32
             }
             const unsigned h = cvt_pk_f16(v0, v1);
             hv[i] = h;
-            m = fmaxf(m, fmaxf(fabsf(v0), fabsf(v1)));
+            // ONE v_max3_f32 with |.| source modifiers: written as fmaxf(m, fmaxf(fabsf(v0), fabsf(v1))) hipcc canonicalises
+            // both inputs first (a v_max_f32 x, |x|, |x| each): three instructions per value pair instead of one
+            asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(v0), "v"(v1));
             const float r0 = rem16<0>(v0, h), r1 = rem16<1>(v1, h);
             if (i < 8) {
                 ra[2 * i] = r0;

@@ -74,6 +74,7 @@ constexpr int ACT6_OFF = ACT16_BYTES;          // [block 4][form 2: heads, remai
 constexpr int ACT6_BYTES = 4 * 2 * 2 * F6_BYTES;  // 32 KiB
 constexpr int TILE_BYTES = 8192;               // voxel tile of the gather, per wave: in the halves of both regions that fc_0's
                                                // 128-wide K phases leave free (chunks 8..15, blocks 2..3)
+constexpr int TILE_L0 = 3072;                  // levels 0 and 1 share a tile: 24 + 20 voxels (boxes of 4 x 4 pixel blocks: p99 27 / 18)
 constexpr int SCR_A = ACT6_OFF + ACT6_BYTES;   // alpha_fc partial sums [64 samples][4 waves] floats
 constexpr int SCR_C = SCR_A + 1024;            // rgb_fc partial sums [3][64][4] floats
 // small fp32 parameters staged once per workgroup (LDS reads are counted on lgkmcnt: a global load at the head of a layer
@@ -84,11 +85,12 @@ constexpr int P_B0 = 0, P_B1 = 256, P_B2 = 512, P_AW = 768, P_RW = 1024, P_AB = 
 // state).  It lives here and not in registers: with 256 registers per wave hipcc spills ~70 long-lived per-ray values to
 // scratch, and every reload is a memory round trip behind an `s_waitcnt vmcnt` (tools/experiments/ms6_phase_times.py)
 constexpr int RAY_OFF = PRM_OFF + P_SIZE * 4, RAY_FLOATS = 20;
+constexpr int TV_OFF = RAY_OFF + 64 * RAY_FLOATS * 4, TV_MAX = 240;  // t_vals (if_clight_renderer.py:13) of marches with <= TV_MAX samples
 static_assert(RAY_OFF % 16 == 0, "16-byte aligned records");
 #ifdef MS6_ONEWG
-constexpr int LDS_BYTES = RAY_OFF + 64 * RAY_FLOATS * 4 + 16384;  // experiment: one workgroup per CU
+constexpr int LDS_BYTES = TV_OFF + TV_MAX * 4 + 16384;  // experiment: one workgroup per CU
 #else
-constexpr int LDS_BYTES = RAY_OFF + 64 * RAY_FLOATS * 4;
+constexpr int LDS_BYTES = TV_OFF + TV_MAX * 4;
 static_assert(LDS_BYTES <= 81920, "two workgroups per CU");
 #endif
 __device__ __forceinline__ int tile_off(int wave) { return wave < 2 ? 8 * CH_BYTES + wave * TILE_BYTES : ACT6_OFF + 2 * 4 * F6_BYTES + (wave - 2) * TILE_BYTES; }
@@ -331,6 +333,14 @@ __device__ __forceinline__ float red_max16(float v) {
     return v;
 }
 
+// a * b + c on the full-rate 24-bit multiplier (v_mul_lo_u32 runs at a quarter of the rate; hipcc turns __mul24 of a sum back
+// into it).  b: wave-uniform (SGPR), |a|, |b| < 2^23
+__device__ __forceinline__ int mad24s(int a, int b_uniform, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+
 // unnorm_clamped (nb_march_common.h) with the level's (float)(size - 1) and (float)size + 1 as scalar kernel arguments
 __device__ __forceinline__ float unnorm_s(float gcoord, float fm1, float fp1) {
     const float i = __fmul_rn(__fdiv_rn(__fadd_rn(gcoord, 1.f), 2.f), fm1);
@@ -383,18 +393,20 @@ __device__ __forceinline__ void tile_dma(const SceneDev &sc, const VoxBox &b, in
     // the previous tile's reads have returned (their values were consumed), but say so
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (pieces > LIMIT / 16) return;  // wave-uniform: the blend reads the corners from global memory
-    const float rcp_xy = 1.f / (float)(nx * ny), rcp_x = 1.f / (float)nx;
+    const float rcp_xy = __builtin_amdgcn_rcpf((float)(nx * ny)), rcp_x = __builtin_amdgcn_rcpf((float)nx);  // v + 0.5 absorbs 1 ulp
     const float *vol = sc.vol[L];
+    const int lin0 = (b.zlo * H + b.ylo) * W + b.xlo;  // scalar
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
         if (it * 64 < pieces) {  // wave-uniform
             const int p = min(it * 64 + lane, pieces - 1);
             const int v = p / PC, q = p % PC;
+            // 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 are full rate, v_mul_lo_u32 is not): every factor is < 2^12
             const int vz = (int)(((float)v + 0.5f) * rcp_xy);
-            const int r = v - vz * nx * ny;
+            const int r = mad24s(vz, -(nx * ny), v);
             const int vy = (int)(((float)r + 0.5f) * rcp_x);
-            const int vx = r - vy * nx;
-            const unsigned lin = (unsigned)(((b.zlo + vz) * H + (b.ylo + vy)) * W + (b.xlo + vx));
+            const int vx = mad24s(vy, -nx, r);
+            const unsigned lin = (unsigned)mad24s(vz, H * W, mad24s(vy, W, vx + lin0));  // < 2^24 voxels per level
             const unsigned voff = (lin * C + q * 4) * 4u;  // byte offset: the largest volume is 104 MB
             const unsigned dst = lds_tile + it * 1024;
             asm volatile(
@@ -441,33 +453,54 @@ __device__ __forceinline__ void gather_parts(const SceneDev &sc, const GridCoord
         cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
     }
     if (pieces <= LIMIT / 16) {  // wave-uniform: the wave's voxel box is in its tile
+        // byte offset of corner (dx, dy, dz) inside the tile = ox[dx] + oy[dy] + oz[dz]: per-axis offsets of the clamped
+        // indices (a corner outside the box has weight 0 and may read any row), 24-bit multiplies
+        int ox[2], oy[2], oz[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            ox[d] = (min(max(x0 + d, b.xlo), b.xhi) - b.xlo) * (C * 4) + part * (QC * 4);
+            oy[d] = mad24s(min(max(y0 + d, b.ylo), b.yhi) - b.ylo, nx * (C * 4), 0);
+            oz[d] = mad24s(min(max(z0 + d, b.zlo), b.zhi) - b.zlo, nx * ny * (C * 4), 0);
+        }
         int co[8];
 #pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const int xx = x0 + (corner & 1), yy = y0 + ((corner >> 1) & 1), zz = z0 + (corner >> 2);
-            const int xc = min(max(xx, b.xlo), b.xhi), yc = min(max(yy, b.ylo), b.yhi), zc = min(max(zz, b.zlo), b.zhi);
-            co[corner] = ((((zc - b.zlo) * ny + (yc - b.ylo)) * nx + (xc - b.xlo)) * C + part * QC) * 4;
-        }
+        for (int corner = 0; corner < 8; ++corner) co[corner] = ox[corner & 1] + oy[(corner >> 1) & 1] + oz[corner >> 2];
+        // corner-major: all of the lane's quads of corner c + 1 are read while corner c is blended into QC independent
+        // accumulators (quad-major, 8 corner reads then their 32 dependent FMAs, left every LDS round trip exposed:
+        // ~50 cycles per ds_read_b128).  Same summation order per channel as the reference's corner order.
+        constexpr int NQ = QC / 4, NB = NQ < 4 ? NQ : 4;  // quads per lane, and per pass (register budget: 12 NB registers)
 #pragma unroll
-        for (int grp = 0; grp < QC / 8; ++grp) {  // 8 channels at a time
-            float o8[8];
+        for (int q0 = 0; q0 < NQ; q0 += NB) {
+            f32x4 acc4[NB], r[2][NB];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int corner = 0; corner < 8; ++corner) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + co[corner] + (2 * grp + h) * 16);
-                    a.x = fmaf(cw[corner], v.x, a.x);
-                    a.y = fmaf(cw[corner], v.y, a.y);
-                    a.z = fmaf(cw[corner], v.z, a.z);
-                    a.w = fmaf(cw[corner], v.w, a.w);
-                }
-                o8[4 * h + 0] = a.x;
-                o8[4 * h + 1] = a.y;
-                o8[4 * h + 2] = a.z;
-                o8[4 * h + 3] = a.w;
+            for (int k = 0; k < NB; ++k) {
+                acc4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                r[0][k] = *reinterpret_cast<const f32x4 *>(buf + co[0] + (q0 + k) * 16);
             }
-            sink(grp, o8);
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) {
+                if (corner + 1 < 8) {
+#pragma unroll
+                    for (int k = 0; k < NB; ++k)
+                        r[(corner + 1) & 1][k] = *reinterpret_cast<const f32x4 *>(buf + co[corner + 1] + (q0 + k) * 16);
+                }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const f32x4 v = r[corner & 1][k];
+                    acc4[k].x = fmaf(cw[corner], v.x, acc4[k].x);
+                    acc4[k].y = fmaf(cw[corner], v.y, acc4[k].y);
+                    acc4[k].z = fmaf(cw[corner], v.z, acc4[k].z);
+                    acc4[k].w = fmaf(cw[corner], v.w, acc4[k].w);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < NB || k < 1; k += 2) {
+                if constexpr (NB >= 2) {
+                    const float o8[8] = {acc4[k].x, acc4[k].y, acc4[k].z, acc4[k].w, acc4[k + 1].x, acc4[k + 1].y, acc4[k + 1].z, acc4[k + 1].w};
+                    sink((q0 + k) / 2, o8);
+                }
+            }
         }
     } else {  // rays far apart (small images, random rays): read the corners from global memory
         const float *cpb[8];
@@ -574,11 +607,14 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         rec[4] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const float *tr = a.t_rand ? a.t_rand + ray * S : nullptr;
+    // a global load here would sit in the depth loop behind an s_waitcnt vmcnt: the table is staged in LDS
+    const bool tv_lds = S <= TV_MAX;
+    auto tval = [&](int s) -> float { return tv_lds ? reinterpret_cast<const float *>(lds + TV_OFF)[s] : a.t_vals[s]; };
     auto z_at = [&](int s, float near, float far) -> float {
-        const float zc = z_lin(near, far, a.t_vals[s]);
+        const float zc = z_lin(near, far, tval(s));
         if (!tr) return zc;
-        const float lower = s == 0 ? zc : 0.5f * __fadd_rn(zc, z_lin(near, far, a.t_vals[s - 1]));
-        const float upper = s == S - 1 ? zc : 0.5f * __fadd_rn(z_lin(near, far, a.t_vals[s + 1]), zc);
+        const float lower = s == 0 ? zc : 0.5f * __fadd_rn(zc, z_lin(near, far, tval(s - 1)));
+        const float upper = s == S - 1 ? zc : 0.5f * __fadd_rn(z_lin(near, far, tval(s + 1)), zc);
         return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), tr[s]));
     };
 
@@ -596,6 +632,8 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             else v = a.lb[256 + i - P_LB];  // bias of the folded view layer (nb_mlp_latent_bias, second block)
             prm[i] = v;
         }
+        if (tv_lds)
+            for (int i = threadIdx.x; i < S; i += 256) reinterpret_cast<float *>(lds + TV_OFF)[i] = a.t_vals[i];
         __syncthreads();
     }
     const __amdgpu_buffer_rsrc_t wrsrc =
@@ -672,8 +710,8 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
                 asm volatile("" : "+v"(hb.xl), "+v"(hb.xx));
 #endif
                 MS6_STAMP(29);
-                tile_dma<0, TILE_BYTES / 2>(a.sc, b0, lane_i, lds_tile);
-                tile_dma<1, TILE_BYTES / 2>(a.sc, b1, lane_i, lds_tile + TILE_BYTES / 2);
+                tile_dma<0, TILE_L0>(a.sc, b0, lane_i, lds_tile);
+                tile_dma<1, TILE_BYTES - TILE_L0>(a.sc, b1, lane_i, lds_tile + TILE_L0);
                 MS6_STAMP(30);
                 store_halfblock(actz, part >> 1, part & 1, sn, ss, hb);
             }
@@ -687,11 +725,11 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             __syncthreads();
             MS6_STAMP(8);
             tile_wait();
-            gather_parts<0, TILE_BYTES / 2>(a.sc, g, b0, part, tile, [&](int grp8, const float (&o)[8]) {
+            gather_parts<0, TILE_L0>(a.sc, g, b0, part, tile, [&](int grp8, const float (&o)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
             });
-            gather_parts<1, TILE_BYTES / 2>(a.sc, g, b1, part, tile + TILE_BYTES / 2, [&](int grp8, const float (&o)[8]) {
+            gather_parts<1, TILE_BYTES - TILE_L0>(a.sc, g, b1, part, tile + TILE_L0, [&](int grp8, const float (&o)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 + 8 * grp8 + e] = o[e];
             });
@@ -736,20 +774,20 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         {
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float sa = 0.f;
+                float s4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent chains
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const f32x4 *aw = reinterpret_cast<const f32x4 *>(pk + P_AW + hi * 128 + 16 * (2 * wave + m));
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const f32x4 w4 = aw[q4];
-                        sa = fmaf(w4.x, acc[m][n][4 * q4 + 0], sa);
-                        sa = fmaf(w4.y, acc[m][n][4 * q4 + 1], sa);
-                        sa = fmaf(w4.z, acc[m][n][4 * q4 + 2], sa);
-                        sa = fmaf(w4.w, acc[m][n][4 * q4 + 3], sa);
+                        s4[0] = fmaf(w4.x, acc[m][n][4 * q4 + 0], s4[0]);
+                        s4[1] = fmaf(w4.y, acc[m][n][4 * q4 + 1], s4[1]);
+                        s4[2] = fmaf(w4.z, acc[m][n][4 * q4 + 2], s4[2]);
+                        s4[3] = fmaf(w4.w, acc[m][n][4 * q4 + 3], s4[3]);
                     }
                 }
-                sa = add_halves(sa);
+                float sa = add_halves((s4[0] + s4[1]) + (s4[2] + s4[3]));
                 if (hi == 0) reinterpret_cast<float *>(actz + SCR_A)[(n * 32 + (lane_i & 31)) * 4 + wave] = sa;
             }
         }
@@ -822,16 +860,16 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
                     const f32x4 *rw = reinterpret_cast<const f32x4 *>(pk + P_RW + (ch * 2 + hi) * 64 + 16 * wave);
-                    float sc = 0.f;
+                    float c4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const f32x4 w4 = rw[q4];
-                        sc = fmaf(w4.x, relu1(acc[0][n][4 * q4 + 0]), sc);
-                        sc = fmaf(w4.y, relu1(acc[0][n][4 * q4 + 1]), sc);
-                        sc = fmaf(w4.z, relu1(acc[0][n][4 * q4 + 2]), sc);
-                        sc = fmaf(w4.w, relu1(acc[0][n][4 * q4 + 3]), sc);
+                        c4[0] = fmaf(w4.x, relu1(acc[0][n][4 * q4 + 0]), c4[0]);
+                        c4[1] = fmaf(w4.y, relu1(acc[0][n][4 * q4 + 1]), c4[1]);
+                        c4[2] = fmaf(w4.z, relu1(acc[0][n][4 * q4 + 2]), c4[2]);
+                        c4[3] = fmaf(w4.w, relu1(acc[0][n][4 * q4 + 3]), c4[3]);
                     }
-                    sc = add_halves(sc);
+                    float sc = add_halves((c4[0] + c4[1]) + (c4[2] + c4[3]));
                     if (hi == 0) reinterpret_cast<float *>(actz + SCR_C)[(ch * 64 + n * 32 + (lane_i & 31)) * 4 + wave] = sc;
                 }
         }
