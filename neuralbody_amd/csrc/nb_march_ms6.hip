@@ -150,6 +150,57 @@ template <bool RELU, class Get>
 __device__ __forceinline__ void write_halfblock(char *act, int b, int kh, int n, int slot, Get get) {
     store_halfblock(act, b, kh, n, slot, convert_halfblock<RELU>(get));
 }
+// the same conversion cut into 16 value-pair slices + a finish, for work that rides in the shadow of another phase's MFMAs
+struct Conv6 {
+    u32x16 hv;
+    f32x16 ra, rb;
+    float m;
+};
+template <int I>
+__device__ __forceinline__ void conv6_pair(Conv6 &c, float v0, float v1) {  // values 2 I, 2 I + 1 of the half-block
+    if constexpr (I == 0) c.m = 0.f;
+    const unsigned h = cvt_pk_f16(v0, v1);
+    c.hv[I] = h;
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(c.m) : "v"(v0), "v"(v1));
+    const float r0 = rem16<0>(v0, h), r1 = rem16<1>(v1, h);
+    if constexpr (I < 8) {
+        c.ra[2 * I] = r0;
+        c.ra[2 * I + 1] = r1;
+    } else {
+        c.rb[2 * (I - 8)] = r0;
+        c.rb[2 * (I - 8) + 1] = r1;
+    }
+}
+__device__ __forceinline__ HalfBlock conv6_finish(const Conv6 &c) {
+    HalfBlock h;
+    h.eb = block_exponent(c.m);
+    cvt_block6(c.hv, c.ra, c.rb, h.eb, h.xx, h.xl);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h.xh[j] = __builtin_bit_cast(f16x8, u32x4{c.hv[4 * j], c.hv[4 * j + 1], c.hv[4 * j + 2], c.hv[4 * j + 3]});
+    return h;
+}
+
+// sin and cos of 2 pi x 2^K for the positional encodings (embedder.py:26-36) without fp64: t = x / (2 pi) as an unevaluated
+// sum th + tl of two floats (error ~2^-48 |t|), u = th 2^K exact, fract(u) exact, and the hardware sine takes revolutions.
+// Against the fp64 reduction of nb_march_common.h: <= 2e-7 absolute (v_fract_f32 clamps just below 1 for tiny negative u).
+struct Rev2 {
+    float th, tl;
+};
+__device__ __forceinline__ Rev2 rev2(float x) {
+    constexpr float C_HI = 0.15915494f, C_LO = (float)(NB_INV_2PI - (double)0.15915494f);
+    Rev2 r;
+    r.th = x * C_HI;
+    r.tl = fmaf(x, C_HI, -r.th) + x * C_LO;
+    return r;
+}
+template <int K>
+__device__ __forceinline__ void sincos_rev2(const Rev2 &t, float &sn, float &cs) {
+    constexpr float P2 = (float)(1 << K);
+    const float u = t.th * P2;
+    sn = __builtin_amdgcn_sinf(fmaf(t.tl, P2, __builtin_amdgcn_fractf(u)));
+    cs = __builtin_amdgcn_sinf(fmaf(t.tl, P2, __builtin_amdgcn_fractf(u + 0.25f)));
+}
 
 // ---------------------------------------------------------------- one layer phase of this wave
 struct WRing {
@@ -240,8 +291,14 @@ __device__ __forceinline__ void read_b(const char *b16, const char *b6, BOps &x)
         }
     }
 }
-template <int P0, int MT, int NB, bool AHEAD>
-__device__ __forceinline__ void layer_s(const WSrc &wl, const char *act, int lane, WRing &ring, f32x16 (&acc)[2][2]) {
+struct NoFill {
+    template <class T>
+    __device__ __forceinline__ void operator()(T) const {}
+};
+// FILL: independent VALU work cut into 6 NB slices; slice t is issued right behind the MFMAs of step t (VALU instructions of
+// the SAME wave execute under its MFMAs; another wave's do not: profiles/r03_ms6_coexec.md)
+template <int P0, int MT, int NB, bool AHEAD, class Fill = NoFill>
+__device__ __forceinline__ void layer_s(const WSrc &wl, const char *act, int lane, WRing &ring, f32x16 (&acc)[2][2], Fill fill = Fill()) {
     constexpr int PPB = 8 * MT;  // pieces per block
     constexpr int PEND = P0 + NB * PPB;
     constexpr int NT = 6 * NB;
@@ -278,6 +335,7 @@ __device__ __forceinline__ void layer_s(const WSrc &wl, const char *act, int lan
                 }
             });
         }
+        fill(tc);
         __builtin_amdgcn_sched_barrier(0);
     });
     // pin the end of the accumulator chains HERE: MFMAs are pure, and hipcc otherwise sinks the tail of a phase past the
@@ -550,6 +608,61 @@ struct WeightStore4 {
     }
 };
 
+// Heads and compositing of ONE finished depth step for this lane's sample, in slices (measured: behind the MFMAs of the next
+// step's first phase they cost MORE than exposed — exp / divide chains and LDS round trips do not hide): raw2outputs (nerf_net_utils.py:19-46) exactly as RayAccum::add, state in the LDS ray record.
+struct CompState {
+    float out[4], dist, w, sig_r, sig_g, sig_b;
+    RayAccum ra;
+};
+template <int T>
+__device__ __forceinline__ void composite_slice(CompState &c, const char *actz, const float *pk, int sample, int part, float z_step,
+                                                float z_after, bool last, const MarchArgs &a, long long ray, int sidx, int S, bool valid,
+                                                WeightStore4 &wstore) {
+    const f32x4 *rec = reinterpret_cast<const f32x4 *>(actz + RAY_OFF) + sample * (RAY_FLOATS / 4);
+    if constexpr (T == 0) {
+        const f32x4 pa = *reinterpret_cast<const f32x4 *>(actz + SCR_A + sample * 16);
+        c.out[3] = ((pa.x + pa.y) + (pa.z + pa.w)) + pk[P_AB];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const f32x4 pc = *reinterpret_cast<const f32x4 *>(actz + SCR_C + (ch * 64 + sample) * 16);
+            c.out[ch] = ((pc.x + pc.y) + (pc.z + pc.w)) + pk[P_RB + ch];
+        }
+    } else if constexpr (T == 1) {
+        const float d = last ? 1e10f : __fsub_rn(z_after, z_step);
+        c.dist = __fmul_rn(d, rec[2].w);
+        const f32x4 c0 = rec[3], c1 = rec[4];
+        c.ra.T = c0.x; c.ra.cr = c0.y; c.ra.cg = c0.z; c.ra.cb = c0.w; c.ra.depth = c1.x; c.ra.accw = c1.y;
+    } else if constexpr (T == 2) {
+        const float sig = fmaxf(c.out[3], 0.f);
+        const float alpha = 1.f - expf(-sig * c.dist);
+        c.w = alpha * c.ra.T;
+        c.ra.T = c.ra.T * (__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
+    } else if constexpr (T == 3) {
+        c.sig_r = 1.f / (1.f + expf(-c.out[0]));
+    } else if constexpr (T == 4) {
+        c.sig_g = 1.f / (1.f + expf(-c.out[1]));
+    } else if constexpr (T == 5) {
+        c.sig_b = 1.f / (1.f + expf(-c.out[2]));
+    } else if constexpr (T == 6) {
+        c.ra.cr = fmaf(c.w, c.sig_r, c.ra.cr);
+        c.ra.cg = fmaf(c.w, c.sig_g, c.ra.cg);
+        c.ra.cb = fmaf(c.w, c.sig_b, c.ra.cb);
+        c.ra.depth = fmaf(c.w, z_step, c.ra.depth);
+        c.ra.accw += c.w;
+        if (part == 0) {
+            f32x4 *recw = reinterpret_cast<f32x4 *>(const_cast<char *>(actz) + RAY_OFF) + sample * (RAY_FLOATS / 4);
+            recw[3] = f32x4{c.ra.T, c.ra.cr, c.ra.cg, c.ra.cb};
+            recw[4] = f32x4{c.ra.depth, c.ra.accw, 0.f, 0.f};
+        }
+    } else if constexpr (T == 7) {
+        wstore.push(a, ray, sidx, S, part, valid, c.w);
+#if !defined(MS6_TAP) && !defined(MS6_TIMING)
+        if (valid && part == 0 && a.raw)
+            *reinterpret_cast<f32x4 *>(a.raw + (ray * S + sidx) * 4) = f32x4{c.out[0], c.out[1], c.out[2], c.out[3]};
+#endif
+    }
+}
+
 // view_fc column of encoding slot `slot` (0..31) of axis a: [x, (sin, cos)(x 2^k) k<10, v, (sin, cos)(v 2^k) k<4, 0, 0]; -1 = zero pad
 __host__ __device__ inline int pe_slot_col(int a, int slot) {
     if (a >= 3 || slot >= 30) return -1;
@@ -759,7 +872,45 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         MS6_STAMP(12);
         // ---- fc_1, fc_2
         init_bias<2>(pk + P_B1, 2 * wave, hi, acc);
-        layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc);
+        // The positional encodings of this step (lane (sample, axis a = part < 3): x_a, (sin, cos)(x_a 2^k) k < 10, v_a, (sin, cos)
+        // (v_a 2^k) k < 4, two zeros; part 3: zeros) and their conversion into operands ride behind fc_1's MFMAs, one slice per
+        // MFMA step; the finished half-block waits in registers until the view layer has released the activation buffers.
+        Conv6 pec;
+        {
+            const f32x4 ro = rec[0], rd = rec[1], rv = rec[2];  // ox oy oz near | dx dy dz far | vx vy vz |d|
+            const float keep = part < 3 ? 1.f : 0.f;
+            const float xa = part == 0 ? __fadd_rn(ro.x, __fmul_rn(rd.x, z_cur))
+                                       : (part == 1 ? __fadd_rn(ro.y, __fmul_rn(rd.y, z_cur)) : __fadd_rn(ro.z, __fmul_rn(rd.z, z_cur)));
+            const float va = part == 0 ? rv.x : (part == 1 ? rv.y : rv.z);
+            Rev2 tx, tv;
+            float e[32];
+            auto pe_fill = [&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                if constexpr (t == 0) {
+                    tx = rev2(xa);
+                    tv = rev2(va);
+                    e[0] = xa;
+                    e[21] = va;
+                    e[30] = 0.f;
+                    e[31] = 0.f;
+                } else if constexpr (t <= 10) {
+#ifdef MS6_ABL_NOPE
+                    e[2 * t - 1] = xa * (float)t;
+                    e[2 * t] = xa + (float)t;
+#else
+                    sincos_rev2<t - 1>(tx, e[2 * t - 1], e[2 * t]);
+#endif
+                } else if constexpr (t <= 14) {
+                    sincos_rev2<t - 11>(tv, e[2 * t], e[2 * t + 1]);
+                } else if constexpr (t >= 16) {
+                    constexpr int i = t - 16;
+                    conv6_pair<2 * i>(pec, e[4 * i] * keep, e[4 * i + 1] * keep);
+                    conv6_pair<2 * i + 1>(pec, e[4 * i + 2] * keep, e[4 * i + 3] * keep);
+                }
+            };
+            layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc, pe_fill);
+        }
+        const HalfBlock peh = conv6_finish(pec);
         MS6_STAMP(13);
         MS6_DUMP(1, 2)
         publish_s(actz, lane_i, wave, acc);
@@ -803,9 +954,6 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         // step's level-3 tile now (in flight under the encodings, the last MFMA phase, the heads and the compositing)
         const f32x4 ro = rec[0], rd = rec[1];  // ox oy oz near | dx dy dz far
         const float z_next = (s + 1 < S) ? z_at(s + 1, ro.w, rd.w) : 0.f;
-        const float px = __fadd_rn(ro.x, __fmul_rn(rd.x, z_cur));
-        const float py = __fadd_rn(ro.y, __fmul_rn(rd.y, z_cur));
-        const float pz = __fadd_rn(ro.z, __fmul_rn(rd.z, z_cur));
         {
             const float nx_ = __fadd_rn(ro.x, __fmul_rn(rd.x, z_next)), ny_ = __fadd_rn(ro.y, __fmul_rn(rd.y, z_next)),
                         nz_ = __fadd_rn(ro.z, __fmul_rn(rd.z, z_next));
@@ -814,39 +962,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             tile_dma<3, TILE_BYTES>(a.sc, vox_box<3>(a.sc, wb), lane_i, lds_tile);
         }
         ring_prime<P_VP>(wl, ring);  // behind the DMA (vmcnt retires in order), ahead of the encodings that cover its latency
-        {
-            // encodings: lane (sample, axis a = part < 3) fills half-block (part >> 1, part & 1); part 3 writes zeros
-            const float xa = part == 0 ? px : (part == 1 ? py : pz);
-            const double t = (double)xa * NB_INV_2PI;
-            const float keep = part < 3 ? 1.f : 0.f;
-            float e[32];
-            e[0] = xa;
-#ifdef MS6_ABL_NOPE
-#pragma unroll
-            for (int k = 0; k < 20; ++k) e[1 + k] = xa * (float)k;
-#else
-#pragma unroll
-            for (int k = 0; k < 10; ++k) {
-                e[1 + 2 * k] = sin_rev(t * (double)(1 << k));
-                e[2 + 2 * k] = sin_rev(t * (double)(1 << k) + 0.25);
-            }
-#endif
-            {
-                // the view direction's encodings are constant along the ray; recomputed (8 v_sin) rather than carried
-                const f32x4 rv = rec[2];  // vx vy vz |d|
-                const float va = part == 0 ? rv.x : (part == 1 ? rv.y : rv.z);
-                const double tv = (double)va * NB_INV_2PI;
-                e[21] = va;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    e[22 + 2 * k] = sin_rev(tv * (double)(1 << k));
-                    e[23 + 2 * k] = sin_rev(tv * (double)(1 << k) + 0.25);
-                }
-            }
-            e[30] = 0.f;
-            e[31] = 0.f;
-            write_halfblock<false>(actz, part >> 1, part & 1, sn, ss, [&](int q) { return e[q] * keep; });
-        }
+        store_halfblock(actz, part >> 1, part & 1, sn, ss, peh);  // the encodings converted behind fc_1
         MS6_STAMP(20);
         __syncthreads();
         MS6_STAMP(21);
@@ -877,35 +993,11 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         __syncthreads();
         MS6_STAMP(24);
         // ---- owner lanes: finish the heads, composite
-        float out[4];
         {
-            const f32x4 pa = *reinterpret_cast<const f32x4 *>(actz + SCR_A + sample * 16);
-            out[3] = ((pa.x + pa.y) + (pa.z + pa.w)) + pk[P_AB];
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const f32x4 pc = *reinterpret_cast<const f32x4 *>(actz + SCR_C + (ch * 64 + sample) * 16);
-                out[ch] = ((pc.x + pc.y) + (pc.z + pc.w)) + pk[P_RB + ch];
-            }
+            CompState cs;
+            sfor<0, 8>([&](auto tc) { composite_slice<decltype(tc)::value>(cs, actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore); });
         }
-        float dist = (s + 1 < S) ? __fsub_rn(z_next, z_cur) : 1e10f;
-        dist = __fmul_rn(dist, rec[2].w);
-        RayAccum ra;
-        {
-            const f32x4 c0 = rec[3], c1 = rec[4];
-            ra.T = c0.x; ra.cr = c0.y; ra.cg = c0.z; ra.cb = c0.w; ra.depth = c1.x; ra.accw = c1.y;
-        }
-        const float w = ra.add(out, z_cur, dist);
-        if (part == 0) {
-            f32x4 *recw = reinterpret_cast<f32x4 *>(actz + RAY_OFF) + sample * (RAY_FLOATS / 4);
-            recw[3] = f32x4{ra.T, ra.cr, ra.cg, ra.cb};
-            recw[4] = f32x4{ra.depth, ra.accw, 0.f, 0.f};
-        }
-        wstore.push(a, ray, s, S, part, valid, w);
         MS6_STAMP(25);
-#if !defined(MS6_TAP) && !defined(MS6_TIMING)
-        if (valid && part == 0 && a.raw)
-            *reinterpret_cast<f32x4 *>(a.raw + (ray * S + s) * 4) = f32x4{out[0], out[1], out[2], out[3]};
-#endif
         z_cur = z_next;
     }
     if (valid && part == 0) {
