@@ -172,6 +172,24 @@ class Network(nn.Module):
         self._packed_have = set()
         self._t_vals = {}
 
+    # the packed blobs and their keys (storages!) are caches of the parameters: they are neither copied nor pickled
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={})
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            setattr(new, k, copy.deepcopy(v, memo))
+        for m in new.modules():
+            m.__dict__.pop("_nb_packed16", None)
+        return new
+
     # ------------------------------------------------------------------ packed decoder weights
     def _mlp_param_dict(self):
         d = {}
@@ -258,19 +276,18 @@ class Network(nn.Module):
         return [v.permute(3, 0, 1, 2)[None] for v in vols]
 
     def calculate_density(self, wpts, feature_volume, sp_input):
-        scene = self.make_scene(feature_volume, sp_input)
-        n_batch = wpts.shape[0]
-        if n_batch != 1:
+        if wpts.shape[0] != 1:
             raise NotImplementedError("batch size 1 only")
+        scene = self.make_scene(feature_volume, sp_input)
         p = wpts.reshape(-1, 3).float().contiguous()
         out = ops.decode_points(scene, self.packed_weights(self._point_precision()), None, p, None, density_only=True,
                                 precision=self._point_precision())
         return out.view(1, -1, 1)
 
     def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
-        scene = self.make_scene(feature_volume, sp_input)
         if wpts.shape[0] != 1:
             raise NotImplementedError("batch size 1 only")
+        scene = self.make_scene(feature_volume, sp_input)
         p = wpts.reshape(-1, 3).float().contiguous()
         v = viewdir.reshape(-1, 3).float().contiguous()
         lb = self.latent_bias(sp_input["latent_index"])

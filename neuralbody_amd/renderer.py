@@ -70,11 +70,12 @@ class Renderer:
         frame from the same batch tensors does not stall the launch queue on every view; a DataLoader loop, which makes fresh
         tensors per frame, syncs once per frame like the reference."""
         c = getattr(self, "_out_sh_cache", None)
-        if c is not None and c[0] is t and c[1] == t._version:
+        token = getattr(self, "_frame_token", None)  # set by render(): a caller that rewrites out_sh in place through a raw pointer
+        if c is not None and c[0] is t and c[1] == (t._version, token):
             return list(c[2])
         out_sh, _ = torch.max(t, dim=0)
         val = out_sh.tolist()
-        self._out_sh_cache = (t, t._version, val)
+        self._out_sh_cache = (t, (t._version, token), val)
         return list(val)
 
     # -- if_clight_renderer.py:54-60
@@ -86,37 +87,50 @@ class Renderer:
         return raw_decoder(wpts, viewdir)
 
     # -- if_clight_renderer.py:62-92 through the Network API + nb_composite (unfused, for subclasses)
-    def get_pixel_value(self, ray_o, ray_d, near, far, feature_volume, sp_input, batch):
-        if self.cfg.raw_noise_std != 0.0:
-            raise NotImplementedError("raw_noise_std != 0 (every shipped config uses 0)")
+    def get_pixel_value(self, ray_o, ray_d, near, far, feature_volume, sp_input, batch, raw_noise=None):
+        """raw_noise: standard-normal tensor [B, n_pixel, N_samples] used instead of torch.randn when cfg.raw_noise_std > 0
+        (nerf_net_utils.py:31-35), the same way `t_rand` replaces the stratified jitter's torch.rand."""
         wpts, z_vals = self.get_sampling_points(ray_o, ray_d, near, far)
         viewdir = ray_d / torch.norm(ray_d, dim=2, keepdim=True)
         raw_decoder = lambda x_point, viewdir_val: self.net.calculate_density_color(  # noqa: E731
             x_point, viewdir_val, feature_volume, sp_input)
         wpts_raw = self.get_density_color(wpts, viewdir, raw_decoder)
         n_batch, n_pixel, n_sample = wpts.shape[:3]
-        raw = wpts_raw.reshape(-1, n_sample, 4).contiguous()
+        raw = self._add_raw_noise(wpts_raw.reshape(-1, n_sample, 4), raw_noise).contiguous()
         rgb, disp, acc, weights, depth = ops.composite(raw, z_vals.reshape(-1, n_sample).contiguous(),
                                                        ray_d.reshape(-1, 3).contiguous(), self.cfg.white_bkgd)
         return {"rgb_map": rgb.view(n_batch, n_pixel, -1), "disp_map": disp.view(n_batch, n_pixel),
                 "acc_map": acc.view(n_batch, n_pixel), "weights": weights.view(n_batch, n_pixel, -1),
                 "depth_map": depth.view(n_batch, n_pixel)}
 
+    def _add_raw_noise(self, raw, raw_noise):
+        """raw [n, S, 4] -> the same with sigma + randn * raw_noise_std (nerf_net_utils.py:31-35); identity when the std is 0."""
+        std = float(self.cfg.raw_noise_std)
+        if std == 0.0:
+            return raw
+        noise = torch.randn(raw.shape[:2], device=raw.device) if raw_noise is None else raw_noise.reshape(raw.shape[:2]).to(raw)
+        raw = raw.clone()
+        raw[..., 3] += noise * std
+        return raw
+
     # -- if_clight_renderer.py:94-122
-    def render(self, batch, t_rand=None, want_raw=False, ray_range=None, feature_volume=None):
+    def render(self, batch, t_rand=None, want_raw=False, ray_range=None, feature_volume=None, raw_noise=None):
         """ray_range = (begin, end) renders a contiguous slice of the rays (multi-GPU sharding).
         feature_volume: volumes of a previous `net.encode_sparse_voxels` of the SAME frame (same coord, out_sh, weights):
         the encoder is then skipped — novel-view loops render many views of one frame (NovelViewRenderer.reuse_volumes)."""
-        if self.cfg.raw_noise_std != 0.0:
-            raise NotImplementedError("raw_noise_std != 0 (every shipped config uses 0)")
         ray_o, ray_d, near, far = batch["ray_o"], batch["ray_d"], batch["near"], batch["far"]
         n_batch, n_pixel = ray_o.shape[:2]
         if n_batch != 1:
-            raise NotImplementedError("batch size 1 only (every shipped config renders/trains with batch 1)")
+            raise NotImplementedError(
+                "batch size 1 only: the reference's own Network pairs ONE set of 6890 vertex codes with the coordinates of the "
+                "whole batch (latent_xyzc.py:35-36: features [6890, 16], indices [B * 6890, 4]), which spconv rejects for B > 1 — "
+                "every shipped config renders and trains with batch size 1")
         if torch.is_grad_enabled() and ray_range is None and any(p.requires_grad for p in self.net.parameters()):
             # training step (lib/train/trainers/if_nerf_clight.py:18-36): differentiable HIP path
             from . import training
 
+            if self.cfg.raw_noise_std != 0.0:
+                raise NotImplementedError("raw_noise_std != 0 on the differentiable path (every shipped config trains with 0)")
             if feature_volume is not None or want_raw or self.make_cull(batch) is not None:
                 raise NotImplementedError("the differentiable path renders all samples of the batch from its own encoder pass: "
                                           "feature_volume / want_raw / sample culling are inference-only (wrap the call in "
@@ -124,6 +138,7 @@ class Renderer:
             if self.cfg.perturb > 0.0 and self.net.training and t_rand is None:
                 t_rand = torch.rand((n_batch, n_pixel, self.cfg.N_samples), device=ray_o.device)
             return training.render_train(self, batch, t_rand)
+        self._frame_token = batch.get("frame_token")
         sp_input = self.prepare_sp_input(batch)
         if feature_volume is None:
             feature_volume = self.net.encode_sparse_voxels(sp_input)
@@ -136,9 +151,19 @@ class Renderer:
             tr = None
         ray_order = self._tile_order(batch, n_pixel, b, e)
         cull = self.make_cull(batch)
+        noisy = self.cfg.raw_noise_std != 0.0
         ret = self.net.render_rays(ray_o[0, b:e].contiguous(), ray_d[0, b:e].contiguous(), near[0, b:e].contiguous(),
                                    far[0, b:e].contiguous(), feature_volume, sp_input, self.cfg.N_samples, t_rand=tr,
-                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw, ray_order=ray_order, cull=cull)
+                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw or noisy, ray_order=ray_order, cull=cull)
+        if noisy:
+            # raw_noise_std > 0 (nerf_net_utils.py:31-35; no shipped config): the march delivers `raw`, the noise is added to the
+            # densities and the rays are composited again by nb_composite with the z values of the same sampling
+            _, z_vals = self.get_sampling_points(ray_o[:, b:e], ray_d[:, b:e], near[:, b:e], far[:, b:e],
+                                                 t_rand=None if tr is None else tr[None])
+            raw = self._add_raw_noise(ret["raw"], None if raw_noise is None else raw_noise[0, b:e]).contiguous()
+            rgb, disp, acc, weights, depth = ops.composite(raw, z_vals[0].contiguous(), ray_d[0, b:e].contiguous(), self.cfg.white_bkgd)
+            ret = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": weights, "depth_map": depth,
+                   **({"raw": raw} if want_raw else {})}
         return {k: v[None] for k, v in ret.items()}
 
     def make_cull(self, batch):
@@ -164,7 +189,11 @@ class Renderer:
                 full = self._order_full = {}
             key = (int(H), int(W), b, e, str(mask.device))
             if key not in full:
+                while len(full) >= 8:  # a handful of geometries / ray ranges per process; callers that vary them must not grow it
+                    full.pop(next(iter(full)))
                 full[key] = ops.tile_order(torch.arange(b, e, device=mask.device), int(W))
+            else:
+                full[key] = full.pop(key)  # most recently used last
             return full[key]
         cached = getattr(self, "_order_cache", None)
         token = batch.get("frame_token")

@@ -228,13 +228,13 @@ def calculate_density_color(sd, wpts, viewdir, feature_volume, sp, voxel_size=(0
 
 
 # ----------------------------------------------------------------------------- a13
-def raw2outputs(raw, z_vals, rays_d, white_bkgd=False):
-    """lib/networks/renderer/nerf_net_utils.py:6-51 with raw_noise_std = 0."""
+def raw2outputs(raw, z_vals, rays_d, white_bkgd=False, noise=None):
+    """lib/networks/renderer/nerf_net_utils.py:6-51; `noise` = randn * raw_noise_std (:31-35), None for raw_noise_std = 0."""
     dists = z_vals[..., 1:] - z_vals[..., :-1]
     dists = torch.cat([dists, torch.full_like(dists[..., :1], 1e10)], -1)
     dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
     rgb = torch.sigmoid(raw[..., :3])
-    alpha = 1.0 - torch.exp(-F.relu(raw[..., 3]) * dists)
+    alpha = 1.0 - torch.exp(-F.relu(raw[..., 3] + (0.0 if noise is None else noise)) * dists)
     weights = alpha * torch.cumprod(
         torch.cat([torch.ones((alpha.shape[0], 1)).to(alpha), 1.0 - alpha + 1e-10], -1), -1)[:, :-1]
     rgb_map = torch.sum(weights[..., None] * rgb, -2)

@@ -264,14 +264,81 @@ def run_train_step():
     print("train step: loss %.6f ->" % float(loss), path, "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_trained():
+    """TRAINED["steps"] optimisation steps of the UNMODIFIED reference (NetworkWrapper.forward = render + masked MSE,
+    lib/train/trainers/if_nerf_clight.py:18-36; the loop body of lib/train/trainers/trainer.py:46-53: zero_grad, backward,
+    clip_grad_value_(40), Adam step with the shipped lr 5e-4) on CPU, then the reference's render of the whole view in run.py's
+    mode.  The fixture carries the optimised parameters, so the GPU tests can put the HIP path through weights that came out
+    of an optimiser instead of an initialiser."""
+    ns = rh.load()
+    T = scenes.TRAINED
+    r, sd, body, batch, cam, _ = scenes.build(T["base"])
+    K, R, Tt, H, W = cam
+    cfg = ns.cfg
+    cfg.N_samples, cfg.white_bkgd, cfg.raw_noise_std = r["n_samples"], bool(r["white_bkgd"]), 0.0
+    net = rh.make_reference_network(sd, train_mode=True)
+    wrapper = ns.NetworkWrapper(net)
+    params = [p for n, p in net.named_parameters() if n.startswith(scenes.TRAINED_PREFIXES)]
+    assert sum(p.numel() for p in params) < 600000
+    opt = torch.optim.Adam(params, lr=T["lr"])
+    target = scenes.trained_target(H, W, batch["mask_at_box"][0])
+    n_rays = batch["ray_o"].shape[1]
+    rs = np.random.RandomState(T["seed"])
+    gen = torch.Generator().manual_seed(T["seed"])
+    real_rand = torch.rand
+    losses = []
+    cfg.perturb = 1.0
+    try:
+        torch.rand = lambda *a, **k: real_rand(*a, generator=gen, **k)  # if_clight_renderer.py:22, made reproducible
+        for step in range(T["steps"]):
+            pick = np.sort(rs.choice(n_rays, T["n_rand"], replace=False))
+            b = dict(batch)
+            for k in ("ray_o", "ray_d", "near", "far"):
+                b[k] = batch[k][:, pick]
+            b["mask_at_box"] = np.ones((1, T["n_rand"]), bool)
+            b["rgb"] = target[pick][None]
+            tb = rh.torch_batch(b)
+            ret, loss, stats, _ = wrapper(tb)
+            opt.zero_grad()
+            loss = loss.mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_value_(net.parameters(), 40)
+            opt.step()
+            losses.append(float(loss))
+            if step % 25 == 0:
+                print("  trained fixture: step %d loss %.5f" % (step, losses[-1]), flush=True)
+    finally:
+        torch.rand = real_rand
+    cfg.perturb = 0.0
+    ren = rh.make_reference_renderer(net)
+    with torch.no_grad():
+        out = ren.render(rh.torch_batch(batch))
+    g = {k: v.numpy() for k, v in out.items()}
+    g["loss_history"] = np.array(losses, np.float32)
+    sd_after = {k: v.detach().numpy() for k, v in net.state_dict().items()}
+    moved = 0.0
+    for k, v in sd_after.items():
+        if k.startswith(scenes.TRAINED_PREFIXES):
+            g["param/" + k] = v.astype(np.float32)
+            moved = max(moved, float(np.abs(v - sd[k]).max()))
+        elif not k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            assert np.array_equal(v, sd[k]), "frozen parameter %s moved" % k
+    path = os.path.join(OUT, "scene_small_trained.npz")
+    np.savez_compressed(path, **g)
+    print("trained: loss %.4f -> %.4f, largest parameter move %.3f ->" % (losses[0], np.mean(losses[-10:]), moved), path,
+          "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh", "novel"]
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh", "novel", "trained"]
     for n in names:
         if n == "raygen":
             run_raygen()
         elif n == "train":
             run_train_step()
+        elif n == "trained":
+            run_trained()
         elif n == "mesh":
             run_mesh()
         elif n == "novel":

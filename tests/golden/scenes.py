@@ -82,6 +82,31 @@ def build_train():
     return r, sd, batch, t_rand
 
 
+# "trained-like" weights: the reference's NetworkWrapper + Adam run for TRAINED["steps"] steps on the `small`
+# scene against a smooth synthetic target image; the decoder MLP, the per-frame latent codes and the vertex codes are optimised
+# (the parameters whose distribution the six-bit cross terms are sensitive to: 542 k floats, stored in the fixture), the sparse
+# convolutions keep their seed-0 values (3.8 M floats: they would make the fixture 17 MB).
+TRAINED = dict(base="small", steps=300, n_rand=256, lr=5e-4, seed=11)
+TRAINED_PREFIXES = ("fc_0.", "fc_1.", "fc_2.", "alpha_fc.", "feature_fc.", "latent_fc.", "view_fc.", "rgb_fc.", "latent.", "c.")
+
+
+def trained_target(H, W, mask):
+    """Smooth RGB target over the image (values in [0.1, 0.9]) for the rays inside the box mask: [n_rays, 3]."""
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32) / H, np.arange(W, dtype=np.float32) / W, indexing="ij")
+    img = np.stack([0.5 + 0.4 * np.sin(6.0 * xx + 1.0), 0.5 + 0.4 * np.cos(5.0 * yy - 0.5), 0.5 + 0.4 * np.sin(4.0 * (xx + yy))], -1)
+    return img.reshape(-1, 3)[mask.reshape(-1)].astype(np.float32)
+
+
+def build_trained(trained_params):
+    """`small` with the optimised parameters of tests/golden/scene_small_trained.npz patched in -> same tuple as build()."""
+    r, sd, body, batch, cam, t_rand = build(TRAINED["base"])
+    sd = dict(sd)
+    for k, v in trained_params.items():
+        assert k in sd and sd[k].shape == v.shape, k
+        sd[k] = v
+    return r, sd, body, batch, cam, t_rand
+
+
 def grad_probe_indices(shape, n=GRAD_PROBES, seed=5):
     size = int(np.prod(shape)) if len(shape) else 1
     return np.random.RandomState(seed + size % 1000).randint(0, size, n)

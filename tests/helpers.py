@@ -7,7 +7,8 @@ import torch
 from tests.golden import scenes
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-RGB_TOL = 1e-4  # BASELINE.json north_star: <= 1e-4 RGB L-inf against the reference renderer
+RGB_TOL = 5e-5  # BASELINE.json north_star asks <= 1e-4 RGB L-inf against the reference renderer; every arithmetic is held to half of it
+# (measured worst case over the fixtures: 1.3e-5)
 from neuralbody_amd.network import DEFAULT_PRECISION  # noqa: E402,F401  (the arithmetic Renderer.render uses by default)
 
 

@@ -32,24 +32,32 @@ def _check(size, n_samples, n_check, precision):
         ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=n_samples, training=True,
                          feature_volume=[v.detach().float().cpu().contiguous() for v in vols])
     # The last sample of a ray has the interval 1e10 (raw2outputs, nerf_net_utils.py:28): its alpha is 0 or 1 by the SIGN of its
-    # density.  A ray whose last density is within bench.ILL_SIGMA of zero is ill-conditioned for ANY arithmetic (one of the 4096
-    # bench rays has sigma_last = 2.3e-4); such rays are left out, and there must be very few of them.
+    # density.  A ray whose last density is within bench.ILL_SIGMA of zero can flip under any arithmetic; it then moves by at
+    # most T_last (the transmittance in front of the last sample).  Such rays are NOT dropped: they must be few, each must stay
+    # inside its own flip bound, and the arithmetics with fp32-class density error must reproduce them like any other ray.
     sigma_last = ref["raw"][0].reshape(n_check, n_samples, 4)[:, -1, 3]
+    t_last = (1.0 - ref["weights"][0][:, :-1].sum(1)).numpy()
     ok = (sigma_last.abs() >= bench.ILL_SIGMA)
-    assert int((~ok).sum()) <= n_check // 200, "too many ill-conditioned rays: %d" % int((~ok).sum())
+    assert int((~ok).sum()) <= n_check * bench.ILL_MAX_FRACTION, "too many ill-conditioned rays: %d" % int((~ok).sum())
     okd = ok.to(dev)
     seld = sel.to(dev)[okd]
     okn = ok.numpy()
+    all_err = np.abs(out["rgb_map"][0, sel.to(dev)].cpu().numpy() - ref["rgb_map"][0].numpy()).max(1)
+    for i in np.nonzero(~okn)[0]:
+        bound = H.RGB_TOL if precision in ("f32", "bf16x3") and abs(float(sigma_last[i])) > 2e-5 else float(t_last[i]) + H.RGB_TOL
+        assert all_err[i] <= bound, "ill-conditioned ray %d: err %.3e > %.3e (sigma_last %.2e, T_last %.2e)" % (
+            i, all_err[i], bound, float(sigma_last[i]), t_last[i])
     err = H.assert_close(out["rgb_map"][0, seld].cpu().numpy(), ref["rgb_map"][0].numpy()[okn], H.RGB_TOL, "rgb_map", rel=False)
     H.assert_close(out["acc_map"][0, seld].cpu().numpy(), ref["acc_map"][0].numpy()[okn], 2e-4, "acc_map")
     H.assert_close(out["weights"][0, seld].cpu().numpy(), ref["weights"][0].numpy()[okn], 2e-4, "weights")
     H.assert_close(out["depth_map"][0, seld].cpu().numpy(), ref["depth_map"][0].numpy()[okn], 2e-4, "depth_map")
     assert float(ref["rgb_map"].max() - ref["rgb_map"].min()) > 0.1, "degenerate view"
-    print("%dx%dx%d %s: rgb L-inf of %d rays vs oracle %.2e (%d ill-conditioned rays left out)" % (size, size, n_samples, precision, int(ok.sum()), err, int((~ok).sum())))
+    print("%dx%dx%d %s: rgb L-inf of %d rays vs oracle %.2e; over all %d rays %.2e (%d ill-conditioned, each inside its flip bound)" % (
+        size, size, n_samples, precision, int(ok.sum()), err, n_check, float(all_err.max()), int((~ok).sum())))
     return err
 
 
-@pytest.mark.parametrize("precision", ["f16f6", "f16f8", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f16f6", "f16f6r", "f16f8", "bf16x3", "f32"])
 def test_headline_view_512x512x64_train_mode(precision):
     _check(512, 64, 4096, precision)
 

@@ -182,6 +182,61 @@ def test_encoder_split_fp16_convolutions_match_the_fp32_kernels(training, monkey
         assert err <= 2e-5, err
 
 
+# ------------------------------------------------------------------------------------------- raw_noise_std
+@pytest.mark.parametrize("precision", ["f32", "f16f6"])
+def test_raw_noise_std_matches_the_reference_formula(precision):
+    """cfg.raw_noise_std > 0 (nerf_net_utils.py:31-35; no shipped config sets it): sigma + randn * std before the relu.  The
+    noise tensor is passed explicitly (like t_rand) so that the oracle composites the same realisation."""
+    from oracle import neuralbody_oracle as orc
+
+    r, sd, body, batch, cam, _ = scenes.build("small_dense")
+    net = H.make_network(sd, DEV, True, precision)
+    rend = H.make_renderer(net, r)
+    rend.cfg.raw_noise_std = 0.7
+    n, S = batch["ray_o"].shape[1], r["n_samples"]
+    noise = torch.randn(1, n, S, generator=torch.Generator().manual_seed(5))
+    bd = H.device_batch(batch, DEV)
+    with torch.no_grad():
+        out = rend.render(bd, raw_noise=noise.to(DEV))
+        clean = orc.render(orc.tensor_state_dict(sd), batch, n_samples=S, training=True, white_bkgd=r["white_bkgd"])
+        tb = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in batch.items()}
+        _, z = orc.get_sampling_points(tb["ray_o"], tb["ray_d"], tb["near"], tb["far"], S)
+        ref = orc.raw2outputs(clean["raw"].reshape(n, S, 4), z.reshape(n, S), tb["ray_d"].reshape(n, 3), r["white_bkgd"],
+                              noise=noise[0] * 0.7)
+    torch.cuda.synchronize()
+    H.assert_close(out["rgb_map"][0].cpu().numpy(), ref[0].numpy(), 1e-4, "rgb_map with noise", rel=False)
+    H.assert_close(out["acc_map"][0].cpu().numpy(), ref[2].numpy(), 2e-4, "acc_map with noise")
+    assert float((ref[0] - clean["rgb_map"][0]).abs().max()) > 1e-2, "the noise must matter in this scene"
+
+
+# ------------------------------------------------------------------------------------------- trained weights
+@pytest.mark.parametrize("precision", PRECISIONS + ["auto"])
+def test_render_with_trained_weights_matches_reference(precision):
+    """Every other fixture uses freshly initialised weights.  scene_small_trained.npz comes from 300 Adam steps of the
+    reference's own NetworkWrapper (tests/golden/make_golden.py::run_trained): the decoder, the latent codes and the vertex
+    codes have an optimiser's distribution, which is what the six-bit block scales and the 'auto' fallback threshold of the
+    default arithmetic must survive."""
+    g = np.load(os.path.join(H.GOLDEN, "scene_small_trained.npz"))
+    params = {k[len("param/"):]: g[k] for k in g.files if k.startswith("param/")}
+    assert float(g["loss_history"][-10:].mean()) < 0.05 * float(g["loss_history"][0]), "the fixture did not train"
+    r, sd, body, batch, cam, _ = scenes.build_trained(params)
+    net = H.make_network(sd, DEV, True, precision)
+    rend = H.make_renderer(net, r)
+    with torch.no_grad():
+        out = rend.render(H.device_batch(batch, DEV))
+    torch.cuda.synchronize()
+    err = H.assert_close(out["rgb_map"].cpu().numpy(), g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    H.assert_close(out["acc_map"].cpu().numpy(), g["acc_map"], 2e-4, "acc_map")
+    H.assert_close(out["weights"].cpu().numpy(), g["weights"], 2e-4, "weights")
+    H.assert_close(out["depth_map"].cpu().numpy(), g["depth_map"], 2e-4, "depth_map")
+    extra = ""
+    if precision == "auto":
+        frac = ops.six_bit_small_fraction(net.packed_weights("f16f6")).cpu().numpy()
+        extra = " (auto -> %s, six-bit small fraction per layer %s)" % (net.march_precision(), np.round(frac, 3))
+    print("trained/%s: rgb L-inf vs reference %.2e%s" % (precision, err, extra))
+    assert float(g["rgb_map"].max() - g["rgb_map"].min()) > 0.2, "fixture is degenerate"
+
+
 # ------------------------------------------------------------------------------------------- march
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ALL)

@@ -37,6 +37,22 @@ def _close(a, b, tol=TOL, name=""):
     assert (err / scale).max(initial=0.0) <= tol, (name, float((err / scale).max()))
 
 
+def test_oracle_render_with_trained_weights_matches_reference_golden(golden_dir):
+    """The fixture made by 300 Adam steps of the reference's NetworkWrapper (make_golden.py::run_trained): the oracle renders
+    the same image from the stored parameters."""
+    g = np.load(os.path.join(golden_dir, "scene_small_trained.npz"))
+    params = {k[len("param/"):]: g[k] for k in g.files if k.startswith("param/")}
+    assert sum(v.size for v in params.values()) > 500000
+    r, sd, body, batch, cam, _ = scenes.build_trained(params)
+    with torch.no_grad():
+        out = orc.render(orc.tensor_state_dict(sd), batch, n_samples=r["n_samples"], training=True, white_bkgd=r["white_bkgd"])
+    for k in ("rgb_map", "acc_map", "weights", "depth_map"):
+        _close(out[k].numpy(), g[k], tol=2e-5, name=k)
+    # the optimiser moved the decoder: its weights no longer look like the initialiser's
+    base = scenes.build(scenes.TRAINED["base"])[1]
+    assert float(np.abs(params["fc_1.weight"] - base["fc_1.weight"]).max()) > 0.02
+
+
 @pytest.mark.parametrize("name", list(scenes.SCENES))
 def test_oracle_render_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, "scene_%s.npz" % name))

@@ -1,4 +1,6 @@
-"""Host-side logic of Renderer that needs no GPU: the ray tile order and the out_sh read-back cache."""
+"""Host-side logic of Renderer that needs no GPU: the ray tile order, the out_sh read-back cache, and the refusals of what the
+HIP path does not implement (each must raise, with a message that says why, before any device work)."""
+import pytest
 import torch
 
 from neuralbody_amd import ops
@@ -23,6 +25,8 @@ def test_tile_order_of_a_full_coverage_view_needs_no_mask_readback():
     assert torch.equal(torch.sort(full.long()).values, torch.arange(n))
     tile = full[:32].long()
     assert int((tile // W).max() - (tile // W).min()) == 3 and int((tile % W).max() - (tile % W).min()) == 7
+    for half in (full[:16].long(), full[16:32].long()):  # every 16 slots: one 4 x 4 pixel block (the M-split march's gather unit)
+        assert int((half // W).max() - (half // W).min()) == 3 and int((half % W).max() - (half % W).min()) == 3
     again = r._tile_order({"mask_at_box": torch.ones(1, n, dtype=torch.bool)}, n, 0, n)  # another mask tensor, same geometry
     assert again is full
     part = r._tile_order({"mask_at_box": torch.ones(1, n, dtype=torch.bool)}, n, 64, 320)  # a rank's share of the rays
@@ -52,3 +56,57 @@ def test_out_sh_is_read_once_per_tensor_version():
     t[0, 0] = 128                                            # in-place write bumps the version: read again
     assert r._host_out_sh(t) == [128, 352, 192]
     assert r._host_out_sh(t.clone()) == [128, 352, 192]      # another tensor object: read again (and cached in turn)
+
+
+# ------------------------------------------------------------------ refusals (one test per NotImplementedError)
+def _batch(n_batch=1, n=64):
+    z = lambda *sh: torch.zeros(*sh)  # noqa: E731
+    return {"ray_o": z(n_batch, n, 3), "ray_d": torch.ones(n_batch, n, 3), "near": z(n_batch, n), "far": torch.ones(n_batch, n),
+            "coord": torch.zeros(n_batch, 10, 3, dtype=torch.int32), "out_sh": torch.tensor([[32, 32, 32]] * n_batch, dtype=torch.int32),
+            "bounds": z(n_batch, 2, 3), "R": torch.eye(3)[None].repeat(n_batch, 1, 1), "Th": z(n_batch, 1, 3),
+            "latent_index": torch.zeros(n_batch, dtype=torch.long)}
+
+
+def test_other_encoding_resolutions_are_refused():
+    with pytest.raises(NotImplementedError, match="xyz_res=10, view_res=4"):
+        Network(num_train_frame=3, xyz_res=8)
+    with pytest.raises(NotImplementedError, match="346 inputs"):
+        Network(num_train_frame=3, view_res=6)
+    with pytest.raises(ValueError, match="precision must be"):
+        Network(num_train_frame=3, precision="fp8")
+
+
+def test_batch_size_above_one_is_refused_with_the_reason():
+    """The reference's own Network cannot run B > 1 either (latent_xyzc.py:35-36 pairs 6890 feature rows with B * 6890
+    coordinates); our refusal names that line instead of failing somewhere inside the encoder."""
+    r = _renderer(8, 8)
+    with torch.no_grad():
+        with pytest.raises(NotImplementedError, match="latent_xyzc.py:35-36"):
+            r.render(_batch(n_batch=2))
+    net = r.net
+    with pytest.raises(NotImplementedError, match="batch size 1 only"):
+        net.encode_sparse_voxels({"coord": torch.zeros(20, 4, dtype=torch.int32), "out_sh": [32, 32, 32], "batch_size": 2})
+    vols = [torch.zeros(1, c, 2, 2, 2) for c in (32, 64, 128, 128)]
+    sp2 = {"R": torch.eye(3)[None].repeat(2, 1, 1), "Th": torch.zeros(2, 1, 3), "bounds": torch.zeros(2, 2, 3), "out_sh": [32, 32, 32],
+           "latent_index": torch.zeros(2, dtype=torch.long)}
+    with pytest.raises(NotImplementedError, match="batch size 1 only"):
+        net.make_scene([v[0].permute(1, 2, 3, 0).contiguous() for v in vols], sp2)
+    sp1 = dict(sp2, R=torch.eye(3)[None], Th=torch.zeros(1, 1, 3), bounds=torch.zeros(1, 2, 3))
+    with pytest.raises(NotImplementedError, match="batch size 1 only"):
+        net.calculate_density(torch.zeros(2, 5, 3), None, sp1) if False else net.calculate_density_color(
+            torch.zeros(2, 5, 3), torch.zeros(2, 5, 3), None, None)
+
+
+def test_the_differentiable_path_refuses_what_it_does_not_differentiate():
+    """Training goes through training.RenderFunction (one autograd.Function around the whole render); inference-only options
+    are refused up front instead of silently returning tensors without gradients."""
+    r = _renderer(8, 8)
+    b = _batch()
+    assert torch.is_grad_enabled() and any(p.requires_grad for p in r.net.parameters())
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        r.render(b, want_raw=True)
+    with pytest.raises(NotImplementedError, match="inference-only"):
+        r.render(b, feature_volume=[None])
+    r.cfg.raw_noise_std = 1.0
+    with pytest.raises(NotImplementedError, match="raw_noise_std != 0 on the differentiable path"):
+        r.render(b)
