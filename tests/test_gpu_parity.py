@@ -231,6 +231,8 @@ def test_render_with_trained_weights_matches_reference(precision):
     H.assert_close(out["depth_map"].cpu().numpy(), g["depth_map"], 2e-4, "depth_map")
     extra = ""
     if precision == "auto":
+        from neuralbody_amd import ops
+
         frac = ops.six_bit_small_fraction(net.packed_weights("f16f6")).cpu().numpy()
         extra = " (auto -> %s, six-bit small fraction per layer %s)" % (net.march_precision(), np.round(frac, 3))
     print("trained/%s: rgb L-inf vs reference %.2e%s" % (precision, err, extra))
