@@ -482,7 +482,9 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
     if (n == 0) return NB_OK;
     NB_REQUIRE(wpts && raw_out, "nb_decode_points: NULL wpts / raw_out");
     NB_REQUIRE(density_only || (viewdir && latent_bias), "nb_decode_points: viewdir / latent_bias required");
-    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3, "nb_decode_points: precision %d", precision);
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_F16F6, "nb_decode_points: precision %d",
+               precision);
+    NB_REQUIRE(!(dbg && precision == NB_PREC_F16F6), "nb_decode_points: NB_PREC_F16F6 has no activation tap (use NB_PREC_F32)");
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
     a.pk = packed;
@@ -494,6 +496,7 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
     a.dbg = dbg;
     const dim3 grid(nb_ceil_div(n, 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (precision == NB_PREC_F16F6) return nbm::launch_points_ms6(a, density_only, ms6_stream_off(), st);
     if (precision == NB_PREC_BF16X3) {
         if (!a.lb) a.lb = packed + OFF_B2;  // density only: the (unused) colour head still needs a readable bias
         return nbm::launch_points_bf16(a, density_only, st);

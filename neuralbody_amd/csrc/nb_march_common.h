@@ -684,6 +684,7 @@ int launch_march_bf16(const MarchArgs &a, hipStream_t st);
 long long ms6_stream_floats();
 int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
 int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st);
+int launch_points_ms6(MarchArgs a, int density_only, long long stream_off, hipStream_t st);
 // fp16 + scaled-8-bit march (nb_march_f16.hip)
 long long f16_stream_floats();
 int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);

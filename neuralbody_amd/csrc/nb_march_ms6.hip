@@ -693,7 +693,12 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 // MS6_TAP (debug builds): workgroup 0 dumps, at depth step 0, every layer's accumulators as [layer][feature][sample]
 // fp32 into a.raw instead of the raw output (fc_0, fc_1, fc_2 pre-activation: 3 x 256 x 64; folded view layer: 128 x 64) —
 // tools/experiments/ms6_tap_check.py compares them with nb_decode_points' fp32 activation tap
+// MODE 0: rays (nb_march).  MODE 1 / 2: explicit points (nb_decode_points, raw [n,4] / density [n,1]): a point with its view
+// direction is a one-sample "ray" (origin = the point, direction = the view direction taken as given, z = 0) whose decoder
+// output is stored instead of composited; MODE 2 stops behind alpha_fc.
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const char *stream) {
+    constexpr bool POINTS = MODE != 0, DENSITY_ONLY = MODE == 2;
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char *act = lds;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -702,15 +707,26 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
     const int sample = 16 * wave + os;            // 0..63 inside the workgroup
     const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
     long long ray = (long long)grp * 64 + sample;
-    const bool valid = ray < a.n_rays;
-    if (!valid) ray = a.n_rays - 1;
-    if (a.ray_order) ray = a.ray_order[ray];
-    const int S = a.n_samples;
-    const float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
-    const float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
-    const float near = a.near[ray], far = a.far[ray];
-    const float dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-    const float vx = dx / dn, vy = dy / dn, vz = dz / dn;
+    const long long n_units = POINTS ? a.n_pts : a.n_rays;
+    const bool valid = ray < n_units;
+    if (!valid) ray = n_units - 1;
+    if (!POINTS && a.ray_order) ray = a.ray_order[ray];
+    const int S = POINTS ? 1 : a.n_samples;
+    float ox, oy, oz, dx, dy, dz, near, far, dn, vx, vy, vz;
+    if constexpr (POINTS) {
+        ox = a.wpts[ray * 3 + 0], oy = a.wpts[ray * 3 + 1], oz = a.wpts[ray * 3 + 2];
+        dx = DENSITY_ONLY ? 0.f : a.viewdir[ray * 3 + 0], dy = DENSITY_ONLY ? 0.f : a.viewdir[ray * 3 + 1];
+        dz = DENSITY_ONLY ? 1.f : a.viewdir[ray * 3 + 2];
+        near = far = 0.f;
+        dn = 1.f;
+        vx = dx, vy = dy, vz = dz;  // latent_xyzc.py:113 embeds the direction it is handed
+    } else {
+        ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
+        dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
+        near = a.near[ray], far = a.far[ray];
+        dn = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        vx = dx / dn, vy = dy / dn, vz = dz / dn;
+    }
     if (part == 0) {
         f32x4 *rec = reinterpret_cast<f32x4 *>(lds + RAY_OFF) + sample * (RAY_FLOATS / 4);
         rec[0] = f32x4{ox, oy, oz, near};
@@ -719,11 +735,12 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         rec[3] = f32x4{1.f, 0.f, 0.f, 0.f};
         rec[4] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float *tr = a.t_rand ? a.t_rand + ray * S : nullptr;
+    const float *tr = (!POINTS && a.t_rand) ? a.t_rand + ray * S : nullptr;
     // a global load here would sit in the depth loop behind an s_waitcnt vmcnt: the table is staged in LDS
-    const bool tv_lds = S <= TV_MAX;
+    const bool tv_lds = !POINTS && S <= TV_MAX;
     auto tval = [&](int s) -> float { return tv_lds ? reinterpret_cast<const float *>(lds + TV_OFF)[s] : a.t_vals[s]; };
     auto z_at = [&](int s, float near, float far) -> float {
+        if constexpr (POINTS) return 0.f;
         const float zc = z_lin(near, far, tval(s));
         if (!tr) return zc;
         const float lower = s == 0 ? zc : 0.5f * __fadd_rn(zc, z_lin(near, far, tval(s - 1)));
@@ -742,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             else if (i < P_AB) v = a.pk[F_OFF_RW + i - P_RW];
             else if (i < P_RB) v = a.pk[F_OFF_AB + i - P_AB];
             else if (i < P_LB) v = a.pk[F_OFF_RB + i - P_RB];
-            else v = a.lb[256 + i - P_LB];  // bias of the folded view layer (nb_mlp_latent_bias, second block)
+            else v = DENSITY_ONLY ? 0.f : a.lb[256 + i - P_LB];  // bias of the folded view layer (nb_mlp_latent_bias, second block)
             prm[i] = v;
         }
         if (tv_lds)
@@ -908,9 +925,11 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
                     conv6_pair<2 * i + 1>(pec, e[4 * i + 2] * keep, e[4 * i + 3] * keep);
                 }
             };
-            layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc, pe_fill);
+            if constexpr (DENSITY_ONLY) layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc);
+            else layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc, pe_fill);
         }
-        const HalfBlock peh = conv6_finish(pec);
+        HalfBlock peh;
+        if constexpr (!DENSITY_ONLY) peh = conv6_finish(pec);
         MS6_STAMP(13);
         MS6_DUMP(1, 2)
         publish_s(actz, lane_i, wave, acc);
@@ -919,7 +938,16 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         layer_s<P_L2, 2, 4, true>(wl, actz, lane_i, ring, acc);
         MS6_STAMP(15);
         MS6_DUMP(2, 2)
-        publish_s(actz, lane_i, wave, acc);  // acc now holds relu(h3)
+        if constexpr (DENSITY_ONLY) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = relu1(acc[m][n][r]);
+        } else {
+            publish_s(actz, lane_i, wave, acc);  // acc now holds relu(h3)
+        }
         MS6_STAMP(16);
         // ---- alpha_fc: partial dot product over this wave's 64 features, finished by the owner lanes
         {
@@ -942,6 +970,8 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
                 if (hi == 0) reinterpret_cast<float *>(actz + SCR_A)[(n * 32 + (lane_i & 31)) * 4 + wave] = sa;
             }
         }
+        float z_next = 0.f;
+        if constexpr (!DENSITY_ONLY) {
         // ---- the colour head's linear part as ONE layer (feature_fc . latent_fc . view_fc folded at pack time, bias: second
         // block of nb_mlp_latent_bias): one tile per wave, K phase over fc_2's outputs, then over the encodings
         init_bias<1>(pk + P_LB, wave, hi, acc);
@@ -953,8 +983,8 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         // the upper halves of the activation buffers are free until the next step's fc_0 is published: request the next
         // step's level-3 tile now (in flight under the encodings, the last MFMA phase, the heads and the compositing)
         const f32x4 ro = rec[0], rd = rec[1];  // ox oy oz near | dx dy dz far
-        const float z_next = (s + 1 < S) ? z_at(s + 1, ro.w, rd.w) : 0.f;
-        {
+        z_next = (s + 1 < S) ? z_at(s + 1, ro.w, rd.w) : 0.f;
+        if constexpr (!POINTS) {
             const float nx_ = __fadd_rn(ro.x, __fmul_rn(rd.x, z_next)), ny_ = __fadd_rn(ro.y, __fmul_rn(rd.y, z_next)),
                         nz_ = __fadd_rn(ro.z, __fmul_rn(rd.z, z_next));
             g = grid_coords(a.sc, nx_, ny_, nz_);
@@ -989,18 +1019,27 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
                     if (hi == 0) reinterpret_cast<float *>(actz + SCR_C)[(ch * 64 + n * 32 + (lane_i & 31)) * 4 + wave] = sc;
                 }
         }
+        }
         MS6_STAMP(23);
         __syncthreads();
         MS6_STAMP(24);
-        // ---- owner lanes: finish the heads, composite
+        // ---- owner lanes: finish the heads; composite (rays) or hand the decoder output over (points)
         {
             CompState cs;
-            sfor<0, 8>([&](auto tc) { composite_slice<decltype(tc)::value>(cs, actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore); });
+            if constexpr (POINTS) {
+                composite_slice<0>(cs, actz, pk, sample, part, z_cur, z_next, true, a, ray, s, S, valid, wstore);
+                if (valid && part == 0) {
+                    if constexpr (DENSITY_ONLY) a.raw_out[ray] = cs.out[3];
+                    else *reinterpret_cast<f32x4 *>(a.raw_out + ray * 4) = f32x4{cs.out[0], cs.out[1], cs.out[2], cs.out[3]};
+                }
+            } else {
+                sfor<0, 8>([&](auto tc) { composite_slice<decltype(tc)::value>(cs, actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore); });
+            }
         }
         MS6_STAMP(25);
         z_cur = z_next;
     }
-    if (valid && part == 0) {
+    if (!POINTS && valid && part == 0) {
         const f32x4 *rec = reinterpret_cast<const f32x4 *>(lds + RAY_OFF) + sample * (RAY_FLOATS / 4);
         const f32x4 c0 = rec[3], c1 = rec[4];
         RayAccum ra;
@@ -1113,9 +1152,19 @@ int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off,
 
 int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st) {
     a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 64);
-    hipLaunchKernelGGL(nb_march_ms6_kernel, dim3(a.n_wave_groups), dim3(256), 0, st, a,
+    hipLaunchKernelGGL(nb_march_ms6_kernel<0>, dim3(a.n_wave_groups), dim3(256), 0, st, a,
                        reinterpret_cast<const char *>(a.pk + stream_off));
     NB_CHECK_LAUNCH("nb_march_ms6_kernel");
+    return NB_OK;
+}
+
+// nb_decode_points on the same kernel: every point a one-sample ray whose decoder output is stored instead of composited
+int launch_points_ms6(MarchArgs a, int density_only, long long stream_off, hipStream_t st) {
+    a.n_wave_groups = (int)nb_ceil_div(a.n_pts, 64);
+    const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
+    if (density_only) hipLaunchKernelGGL(nb_march_ms6_kernel<2>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    else hipLaunchKernelGGL(nb_march_ms6_kernel<1>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    NB_CHECK_LAUNCH("nb_march_ms6_kernel (points)");
     return NB_OK;
 }
 

@@ -200,9 +200,15 @@ class Network(nn.Module):
         return d
 
     def _point_precision(self):
-        """nb_decode_points has two kernel families (exact fp32, split bf16); the march-only arithmetics ('f16f6',
-        'f16f6r', 'f16f8') decode stand-alone points with the split-bf16 kernels."""
-        return "bf16x3" if self.precision in ("auto", "f16f6r", "f16f8", "f16f6") else self.precision
+        """Arithmetic of nb_decode_points (stand-alone points: calculate_density, calculate_density_color, get_pixel_value,
+        RendererMesh): exact fp32, split bf16, or — the default — the march's f16f6 arithmetic on the same M-split kernel
+        (every point a one-sample ray).  'f16f8' and 'f16f6r' exist as march organisations only: their points take split bf16,
+        and so do the points of an 'auto' network whose weights made the march fall back to 'f16f8'."""
+        if self.precision in ("f32", "bf16x3", "f16f6"):
+            return self.precision
+        if self.precision == "auto":
+            return "f16f6" if self.march_precision() == "f16f6" else "bf16x3"
+        return "bf16x3"
 
     def march_precision(self):
         """Arithmetic of the fused march.  'auto' = 'f16f6' (cross terms in six bits, the fastest) unless the weights have

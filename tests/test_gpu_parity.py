@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ALL = list(scenes.SCENES)
 PRECISIONS = ["f32", "bf16x3", "f16f6r", "f16f8", "f16f6"]  # nb_march kernel families
-POINT_PRECISIONS = ["f32", "bf16x3"]  # nb_decode_points kernel families (the f16 arithmetics are march-only)
+POINT_PRECISIONS = ["f32", "bf16x3", "f16f6"]  # nb_decode_points kernel families (the f16 arithmetics are march-only)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -77,16 +77,20 @@ def test_decode_points_stages_against_oracle(precision):
         dens = orc.calculate_density(sdt, w, vols, sp_cpu)[0]
     scene = net.make_scene(vols_dev, sp)
     lb = net.latent_bias(bd["latent_index"])
-    out, dbg = ops.decode_points(scene, net.packed_weights(), lb, w[0].to(DEV).contiguous(), v[0].to(DEV).contiguous(),
-                                 debug=True, precision=precision)
+    tap = precision != "f16f6"  # the f16f6 point decoder is the march kernel (every point a one-sample ray): no activation tap
+    res = ops.decode_points(scene, net.packed_weights(precision), lb, w[0].to(DEV).contiguous(), v[0].to(DEV).contiguous(),
+                            debug=tap, precision=precision)
+    out, dbg = res if tap else (res, None)
     torch.cuda.synchronize()
-    dbg = dbg.cpu().numpy()
-    H.assert_close(dbg[:, :352], feat.numpy(), 2e-5, "trilinear features")
     assert np.abs(feat.numpy()).max() > 0.1 and (np.abs(feat.numpy()).sum(1) == 0).any()
     # raw logits reach |20| with the synthetic alpha_fc x20 / rgb_fc x8 gains; the split-bf16 path carries ~2^-16
     # relative error per GEMM term (dropped lo.lo product), the fp32 path only summation-order noise
     tol_h, tol_raw = (1e-4, 2e-4) if precision == "f32" else (3e-4, 1e-3)
-    e_h = H.assert_close(dbg[:, 864:1120], h3[0].T.numpy(), tol_h, "fc_2 output")
+    e_h = float("nan")
+    if tap:
+        dbg = dbg.cpu().numpy()
+        H.assert_close(dbg[:, :352], feat.numpy(), 2e-5, "trilinear features")
+        e_h = H.assert_close(dbg[:, 864:1120], h3[0].T.numpy(), tol_h, "fc_2 output")
     e_raw = H.assert_close(out.cpu().numpy(), raw.numpy(), tol_raw, "raw (rgb logits, sigma)")
     print("%s: fc_2 err %.2e, raw err %.2e (rel. to max(1,|ref|))" % (precision, e_h, e_raw))
     # public API paths
@@ -97,10 +101,10 @@ def test_decode_points_stages_against_oracle(precision):
     assert dens_api.shape == (1, w.shape[1], 1)
     H.assert_close(dens_api[0].cpu().numpy(), dens.numpy(), tol_raw, "calculate_density")
     # ragged size: n not a multiple of 32, and n == 0
-    part = ops.decode_points(scene, net.packed_weights(), lb, w[0, :77].to(DEV).contiguous(), v[0, :77].to(DEV).contiguous(),
+    part = ops.decode_points(scene, net.packed_weights(precision), lb, w[0, :77].to(DEV).contiguous(), v[0, :77].to(DEV).contiguous(),
                              precision=precision)
     assert torch.equal(part, out[:77])
-    empty = ops.decode_points(scene, net.packed_weights(), lb, w[0, :0].to(DEV).contiguous(), v[0, :0].to(DEV).contiguous(),
+    empty = ops.decode_points(scene, net.packed_weights(precision), lb, w[0, :0].to(DEV).contiguous(), v[0, :0].to(DEV).contiguous(),
                               precision=precision)
     assert empty.shape == (0, 4)
 
@@ -506,7 +510,9 @@ def test_density_cube_matches_reference(precision, monkeypatch):
         cube = rend.density_cube(bd)
     torch.cuda.synchronize()
     assert cube.is_cuda and tuple(cube.shape) == g["cube"].shape
-    err = H.assert_close(cube.cpu().numpy(), g["cube"], 2e-4, "cube")
+    # densities reach |20|; 'f16f6' carries ~4e-4 of absolute density error (its measured sigma error, bench.ILL_SIGMA), the
+    # exact and split-bf16 decoders stay below 2e-4
+    err = H.assert_close(cube.cpu().numpy(), g["cube"], 1e-3 if precision == "f16f6" else 2e-4, "cube")
     # the iso-surface decision marching cubes makes is the same everywhere except within the tolerance of the threshold
     ours, ref = cube.cpu().numpy() > 5.0, g["cube"] > 5.0
     assert np.array_equal(ours[np.abs(g["cube"] - 5.0) > 1e-2], ref[np.abs(g["cube"] - 5.0) > 1e-2])
