@@ -238,8 +238,8 @@ def train_bench(args, dev):
     return ({"metric": "train_step_ms", "value": dt * 1e3, "unit": "ms", "higher_is_better": False, "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "rays_per_step": 1024, "samples_per_ray": args.samples,
                       "ray_samples_per_sec": 1024 * args.samples / dt, "final_loss": float(loss.detach()),
-                      "config": {"workload": "synthetic training step: 1024 random rays, forward + backward (decoder via rocBLAS "
-                                             "GEMMs + HIP kernels, encoder HIP kernels) + clip_grad_value_(40) + Adam"}})
+                      "config": {"workload": "synthetic training step: 1024 random rays, forward + backward (decoder GEMMs and encoder "
+                                             "kernels all in libnb_hip.so, no vendor BLAS) + clip_grad_value_(40) + Adam"}})
 
 
 def turntable_bench(args, dev):
@@ -286,10 +286,37 @@ def extras(args, dev):
     tt = turntable_bench(a, dev)
     a.steps, a.warmup = 6, 2
     tr = train_bench(a, dev)
-    return {"turntable_ms_per_view": tt["ms_per_view"], "turntable_rays_per_sec": tt["rays_per_sec"],
-            "train_step_ms": tr["value"], "train_ray_samples_per_sec": tr["ray_samples_per_sec"],
-            "note": "8 spiral views (512x512x64, each view: nb_raygen + encoder + march + nb_image_assemble) / 6 training steps "
-                    "(1024 random rays x 64 jittered samples, forward + backward + clip + Adam)"}
+    ex = {"turntable_ms_per_view": tt["ms_per_view"], "turntable_rays_per_sec": tt["rays_per_sec"],
+          "train_step_ms": tr["value"], "train_ray_samples_per_sec": tr["ray_samples_per_sec"],
+          "note": "8 spiral views (512x512x64, each view: nb_raygen + encoder + march + nb_image_assemble) / 6 training steps "
+                  "(1024 random rays x 64 jittered samples, forward + backward + clip + Adam); *_ms_per_view / *_march_ms: the timed "
+                  "view of this run rendered with the other arithmetics (3 steps each), roofline fraction of each against ITS peak"}
+    # the same view in the reference's own precision (exact fp32 MFMA) and on the other organisations of the default arithmetic:
+    # the record then holds a reference-precision number and an A/B of the kernels from ONE box
+    from neuralbody_amd import ops
+
+    for prec in ("f32", "f16f6r", "bf16x3"):
+        if prec == (args.precision or "f16f6"):
+            continue
+        sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, prec)
+        with torch.no_grad():
+            rend.render(bd)
+            torch.cuda.synchronize()
+            ops.MARCH_EVENTS = []
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                rend.render(bd)
+            e1.record()
+            torch.cuda.synchronize()
+            ev, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
+        march = float(np.mean([x.elapsed_time(y) for x, y in ev]))
+        peak = PRECISION_INFO[prec][3]
+        ex["%s_ms_per_view" % prec] = e0.elapsed_time(e1) / 3
+        ex["%s_march_ms" % prec] = march
+        ex["%s_roofline_frac" % prec] = FLOP_PER_SAMPLE * n_rays * args.samples / (march * 1e-3) / 1e12 / peak
+        del net, rend
+    return ex
 
 
 def main():
@@ -344,13 +371,20 @@ def main():
     poses = build_poses(dev, body, bd, H, W)
     from neuralbody_amd.parallel import render_sharded
 
+    gather_events = []
+
     def step(i):
         b = poses[(i + rank) % len(poses)]
         if args.scaling == "strong":
             return render_sharded(rend, b, dist.group.WORLD if dist is not None else None)["rgb_map"][0]
         out = rend.render(b)
         if dist is not None:
-            return all_gather_tiles(out["rgb_map"][0], dist.group.WORLD)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            tiles = all_gather_tiles(out["rgb_map"][0], dist.group.WORLD)
+            g1.record()
+            gather_events.append((g0, g1))
+            return tiles
         return out["rgb_map"][0]
 
     with torch.no_grad():
@@ -362,6 +396,7 @@ def main():
         torch.cuda.synchronize()
         ops.MARCH_EVENTS = []
         step_events = []
+        del gather_events[:]
         t0 = time.perf_counter()
         for i in range(args.steps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -378,10 +413,18 @@ def main():
     march_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
     step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    per_rank = None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # what every rank spent in its march launches and in the RCCL all-gather of the RGB tiles (HIP events on its stream)
+        ag_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else float("nan")
+        mine = torch.tensor([march_ms, ag_ms, step_ms[len(step_ms) // 2]], dtype=torch.float64, device=dev)
+        allr = torch.empty(world * 3, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        per_rank = [{"rank": r, "march_ms": float(allr[3 * r]), "allgather_ms": float(allr[3 * r + 1]), "median_step_ms": float(allr[3 * r + 2])}
+                    for r in range(world)]
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
@@ -431,6 +474,8 @@ def main():
                              "(<0.1%% of the launch time at 8 TB/s)"
                              % (rays_per_launch * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.march_precision().startswith("bf16") else "")},
     }
+    if per_rank is not None:
+        result["per_rank"] = per_rank
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         par = parity_check(sd, net, rend, poses[1], S)
         result["parity_linf"] = par["linf"]

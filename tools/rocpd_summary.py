@@ -21,7 +21,10 @@ def main(path, extra=""):
                      "max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     print("# rocprofv3 --kernel-trace --stats summary (%s)%s\n" % (path.split("/")[-1], extra))
-    print("| kernel | calls | total ms | avg us | min us | max us | % | VGPR | AGPR | SGPR | scratch B | LDS B | grid x wg |")
+    print("Registers as rocprofv3 records them: on gfx950 the `VGPR` column is the ALLOCATION of the unified file (architectural + "
+          "accumulation registers, in granules of 8) and `accum_vgpr_count` comes back 0 — the AGPR share of a kernel is in its "
+          "code object (`hipcc -Rpass-analysis=kernel-resource-usage`), not in the trace.\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % | VGPR+AGPR (alloc) | accum (as reported) | SGPR | scratch B | LDS B | grid x wg |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for n, cnt, tot, avg, mn, mx, vg, ag, sg, sc, lds, gx, wx in rows:
         print("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.2f | %s | %s | %s | %s | %s | %sx%s |" % (
