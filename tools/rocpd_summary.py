@@ -21,10 +21,10 @@ def main(path, extra=""):
                      "max(grid_x), max(workgroup_x) from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     print("# rocprofv3 --kernel-trace --stats summary (%s)%s\n" % (path.split("/")[-1], extra))
-    print("Registers as rocprofv3 records them: on gfx950 the `VGPR` column is the ALLOCATION of the unified file (architectural + "
-          "accumulation registers, in granules of 8) and `accum_vgpr_count` comes back 0 — the AGPR share of a kernel is in its "
-          "code object (`hipcc -Rpass-analysis=kernel-resource-usage`), not in the trace.\n")
-    print("| kernel | calls | total ms | avg us | min us | max us | % | VGPR+AGPR (alloc) | accum (as reported) | SGPR | scratch B | LDS B | grid x wg |")
+    print("Register columns are what rocprofv3 records per dispatch.  On gfx950 `accum_vgpr_count` comes back 0 and `vgpr_count` does not "
+          "include the accumulation registers a kernel addresses as a[..] (nb_march_f6_kernel: 240 here, 256 VGPR + ~215 AGPR in its "
+          "code object): the authoritative numbers are the code object's (`hipcc -Rpass-analysis=kernel-resource-usage`).\n")
+    print("| kernel | calls | total ms | avg us | min us | max us | % | VGPR (as reported) | AGPR (as reported) | SGPR | scratch B | LDS B | grid x wg |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for n, cnt, tot, avg, mn, mx, vg, ag, sg, sc, lds, gx, wx in rows:
         print("| %s | %d | %.3f | %.1f | %.1f | %.1f | %.2f | %s | %s | %s | %s | %s | %sx%s |" % (
