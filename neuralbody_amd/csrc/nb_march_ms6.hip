@@ -27,6 +27,8 @@
 // (heads) / interleaved position (remainders) of the lane's bf6 operands of block b.  Weights are packed to match.
 #include "nb_f6_ops.h"
 
+#include <cstdlib>
+
 using namespace nbm;
 
 namespace {
@@ -38,6 +40,10 @@ namespace {
 #define NB_MS6_RING 8
 #endif
 constexpr int S_R = NB_MS6_RING;  // register ring depth in pieces
+#ifndef NB_MS6_LAG
+#define NB_MS6_LAG 7
+#endif
+constexpr int PAIR_LAG = NB_MS6_LAG;  // of the 14 barrier intervals of a depth step
 __host__ __device__ constexpr int phase_pieces(int nb, int mt) { return nb * mt * 8; }
 constexpr int N_PH = 7;
 // fc_0 in three K phases of 128 (pyramid level 3 | level 2 | levels 0 and 1 + 8 zero slots per lane), fc_1, fc_2,
@@ -218,6 +224,14 @@ __device__ __forceinline__ i32x4 load_piece(const WSrc &wl, int p) {
 #ifdef MS6_ABL_NOW
     return i32x4{(int)wl.voff, p, 0, 0};
 #endif
+#ifdef MS6_ABL_NOW2  // no weight traffic at all: finite stand-in values (fp16 6e-5; six-bit scale word 127 = 2^0)
+    int c0 = 0x04040404, c2 = 127;
+    asm volatile("" : "+v"(c0), "+v"(c2));
+    return i32x4{c0, c0, c2, 0};
+#endif
+#ifdef MS6_ABL_NOW3  // every load hits the same KiB: the L1 delivers, L2 is out of the picture
+    p = 0;
+#endif
     const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(wl.rsrc, wl.voff, (p % P_TOTAL) * 1024, 0);
     return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
 }
@@ -240,12 +254,22 @@ __device__ __forceinline__ f32x16 mfma16(const i32x4 a, const i32x4 b, const f32
 #ifdef MS6_ABL_NOM
     return c;
 #endif
+#ifdef MS6_ABL_NOM2  // operands still loaded and consumed (one VALU instruction)
+    f32x16 r = c;
+    r[0] = __int_as_float(__float_as_int(r[0]) ^ (a.x & b.x & 1));
+    return r;
+#endif
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 // A: fp6 e2m3 (cbsz 2), 24 B of data + the lane's E8M0 scale in register 6; B: bf6 e3m2 (blgp 3), same layout
 __device__ __forceinline__ f32x16 mfma6(const i32x8 a, const i32x8 b, const f32x16 c) {
 #ifdef MS6_ABL_NOM
     return c;
+#endif
+#if defined(MS6_ABL_NOM2) || defined(MS6_ABL_NOM6)
+    f32x16 r = c;
+    r[0] = __int_as_float(__float_as_int(r[0]) ^ (a[0] & b[0] & a[6] & b[6] & a[5] & b[5] & 1));
+    return r;
 #endif
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 3, 0, a[6], 0, b[6]);
 }
@@ -277,6 +301,9 @@ struct BOps {
 template <int T>
 __device__ __forceinline__ void read_b(const char *b16, const char *b6, BOps &x) {
     constexpr int b = T / 6, j = T % 6, buf = T & 1;
+#ifdef MS6_ABL_NOB  // B operands read for the first block of a phase only
+    if constexpr (T >= 6) return;
+#endif
     if constexpr (j < 4) {
         constexpr int c = 4 * b + j;
         x.m[buf][0] = *reinterpret_cast<const i32x4 *>(b16 + c * CH_BYTES);
@@ -696,16 +723,22 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 // MODE 0: rays (nb_march).  MODE 1 / 2: explicit points (nb_decode_points, raw [n,4] / density [n,1]): a point with its view
 // direction is a one-sample "ray" (origin = the point, direction = the view direction taken as given, z = 0) whose decoder
 // output is stored instead of composited; MODE 2 stops behind alpha_fc.
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const char *stream) {
+template <int MODE, bool PAIR>
+__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void nb_march_ms6_kernel(MarchArgs a, const char *stream) {
     constexpr bool POINTS = MODE != 0, DENSITY_ONLY = MODE == 2;
-    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    __shared__ __attribute__((aligned(16))) char lds_all[PAIR ? 2 * LDS_BYTES : LDS_BYTES];
+    static_assert(!PAIR || 2 * LDS_BYTES <= 163840, "both groups' LDS in one CU");
+    // PAIR: two 4-wave groups (one wave of each per SIMD) march 64 rays each in their own LDS half, group 1 running PAIR_LAG
+    // barrier intervals behind group 0 so that one group's MFMA phases coincide with the other's VALU phases
+    const int group = PAIR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
+    char *lds = lds_all + group * LDS_BYTES;
     char *act = lds;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tid = threadIdx.x & 255;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
     const int hi = lane >> 5;
     const int os = lane & 15, part = lane >> 4;  // owner role
     const int sample = 16 * wave + os;            // 0..63 inside the workgroup
-    const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
+    const int grp = PAIR ? 2 * xcd_remap(blockIdx.x, a.n_wave_groups) + group : xcd_remap(blockIdx.x, a.n_wave_groups);
     long long ray = (long long)grp * 64 + sample;
     const long long n_units = POINTS ? a.n_pts : a.n_rays;
     const bool valid = ray < n_units;
@@ -750,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
 
     {
         float *prm = reinterpret_cast<float *>(lds + PRM_OFF);
-        for (int i = threadIdx.x; i < P_SIZE; i += 256) {
+        for (int i = tid; i < P_SIZE; i += 256) {
             float v;
             if (i < P_B1) v = a.pk[F_OFF_B0 + i - P_B0];
             else if (i < P_B2) v = a.pk[F_OFF_B1 + i - P_B1];
@@ -763,9 +796,11 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             prm[i] = v;
         }
         if (tv_lds)
-            for (int i = threadIdx.x; i < S; i += 256) reinterpret_cast<float *>(lds + TV_OFF)[i] = a.t_vals[i];
+            for (int i = tid; i < S; i += 256) reinterpret_cast<float *>(lds + TV_OFF)[i] = a.t_vals[i];
         __syncthreads();
     }
+    if (PAIR && group)
+        for (int i = 0; i < PAIR_LAG; ++i) __syncthreads();
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(stream) + (size_t)wave * P_TOTAL * 1024, 0, P_TOTAL * 1024, 0x00020000);
     WRing ring;
@@ -792,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         f32x16 acc[2][2];
         const int sn = sample >> 5, ss = sample & 31;  // N tile and column of this lane's sample
 #ifdef MS6_TIMING
-        unsigned *tbuf = (blockIdx.x < 32 && wave == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + ((size_t)blockIdx.x * S + s) * 32 : nullptr;
+        unsigned *tbuf = (blockIdx.x < 32 && wave == 0 && group == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + ((size_t)blockIdx.x * S + s) * 32 : nullptr;
 #endif
         MS6_STAMP(0);
 
@@ -875,7 +910,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         }
 #ifdef MS6_TAP
 #define MS6_DUMP(LAYER, MT_)                                                                                              \
-    if (blockIdx.x == 0 && s == 0 && a.raw) {                                                                             \
+    if (blockIdx.x == 0 && group == 0 && s == 0 && a.raw) {                                                                            \
         for (int m = 0; m < (MT_); ++m)                                                                                   \
             for (int n = 0; n < 2; ++n)                                                                                   \
                 for (int r = 0; r < 16; ++r)                                                                              \
@@ -1039,6 +1074,8 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         MS6_STAMP(25);
         z_cur = z_next;
     }
+    if (PAIR && !group)
+        for (int i = 0; i < PAIR_LAG; ++i) __syncthreads();
     if (!POINTS && valid && part == 0) {
         const f32x4 *rec = reinterpret_cast<const f32x4 *>(lds + RAY_OFF) + sample * (RAY_FLOATS / 4);
         const f32x4 c0 = rec[3], c1 = rec[4];
@@ -1151,8 +1188,20 @@ int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off,
 }
 
 int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st) {
+#ifdef MS6_ONEWG
+    constexpr bool pair = false;
+#else
+    static const bool pair = !(getenv("NB_MS6_PAIR") && getenv("NB_MS6_PAIR")[0] == '0');
+#endif
+    if constexpr (LDS_BYTES * 2 <= 163840) if (pair) {
+        a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 128);
+        hipLaunchKernelGGL((nb_march_ms6_kernel<0, true>), dim3(a.n_wave_groups), dim3(512), 0, st, a,
+                           reinterpret_cast<const char *>(a.pk + stream_off));
+        NB_CHECK_LAUNCH("nb_march_ms6_kernel");
+        return NB_OK;
+    }
     a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 64);
-    hipLaunchKernelGGL(nb_march_ms6_kernel<0>, dim3(a.n_wave_groups), dim3(256), 0, st, a,
+    hipLaunchKernelGGL((nb_march_ms6_kernel<0, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a,
                        reinterpret_cast<const char *>(a.pk + stream_off));
     NB_CHECK_LAUNCH("nb_march_ms6_kernel");
     return NB_OK;
@@ -1162,8 +1211,8 @@ int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st) {
 int launch_points_ms6(MarchArgs a, int density_only, long long stream_off, hipStream_t st) {
     a.n_wave_groups = (int)nb_ceil_div(a.n_pts, 64);
     const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
-    if (density_only) hipLaunchKernelGGL(nb_march_ms6_kernel<2>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
-    else hipLaunchKernelGGL(nb_march_ms6_kernel<1>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    if (density_only) hipLaunchKernelGGL((nb_march_ms6_kernel<2, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    else hipLaunchKernelGGL((nb_march_ms6_kernel<1, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     NB_CHECK_LAUNCH("nb_march_ms6_kernel (points)");
     return NB_OK;
 }
