@@ -54,8 +54,8 @@ PRECISION_INFO = {
     # the same with the cross terms in 6 bits: a K=64 fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA
     # (profiles/r02_probe_mxrate.log), so it is counted as one (a quarter of its flops)
     "f16f6r": ("f16+f6", "nb_march_f6_kernel", (520 + 272) * 32768 / 32.0, 2500.0),
-    # the same arithmetic, M-split workgroups (the default): 4 waves x 408 MFMAs per 64 samples (fc_0's K padded to 384, the
-    # encodings' to 128)
+    # the same arithmetic, M-split workgroups (round 3; opt-in for marches, the kernel behind nb_decode_points): 4 waves x 408
+    # MFMAs per 64 samples (fc_0's K padded to 384, the encodings' to 128)
     "f16f6": ("f16+f6", "nb_march_ms6_kernel", 4 * 408 * 32768 / 64.0, 2500.0),
 }
 
@@ -295,8 +295,8 @@ def extras(args, dev):
     # the record then holds a reference-precision number and an A/B of the kernels from ONE box
     from neuralbody_amd import ops
 
-    for prec in ("f32", "f16f6r", "bf16x3"):
-        if prec == (args.precision or "f16f6"):
+    for prec in ("f32", "f16f6", "bf16x3"):
+        if prec == (args.precision or "f16f6r"):
             continue
         sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, prec)
         with torch.no_grad():
@@ -454,13 +454,15 @@ def main():
                    "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                                   "bf16x3": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
                                             "v_mfma_f32_32x32x16_bf16, fp32 accumulate",
-                                  "f16f6r": "the f16f6 arithmetic on the ring organisation (round 2's default kernel)",
+                                  "f16f6r": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
+                                            "terms in 6 bits (fp6 e2m3 weights, bf6 e3m2 activations, E8M0 scales per 32 K) on "
+                                            "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; ring organisation (one wave per "
+                                            "SIMD, weights through an LDS ring)",
                                   "f16f8": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
                                            "terms in 8 bits (fp8 e4m3 weights, bf8 e5m2 activations) on "
                                            "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate",
-                                  "f16f6": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
-                                           "terms in 6 bits (fp6 e2m3 weights, bf6 e3m2 activations, E8M0 scales per 32 K) on "
-                                           "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate"}[net.march_precision()],
+                                  "f16f6": "the f16f6r arithmetic on the M-split organisation (round 3: four waves share 64 rays, "
+                                           "activations in LDS, weights streamed from L2; 2-4 % slower than the ring)"}[net.march_precision()],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,

@@ -15,8 +15,13 @@ constexpr int N_PE = 45;
 //   [ F 352 | h1 256 | h2 256 | h3 256 | G 256 (latent_fc output) | V 128 (view_fc, post relu) | PE 90 | pad ]
 constexpr int TAP_F = 0, TAP_H1 = 352, TAP_H2 = 608, TAP_H3 = 864, TAP_G = 1120, TAP_V = 1376, TAP_PE = 1504, TAP_WIDTH = 1600;
 
-// relu as one v_med3_f32: fmaxf on an MFMA result makes hipcc insert a canonicalising v_max_f32 x, x, x first
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_inff()); }
+// relu as ONE v_max_f32: written as fmaxf (or as fmed3(x, 0, inf), which hipcc folds back into a max) the compiler first
+// canonicalises the MFMA result with a v_max_f32 x, x, x of its own: two instructions per value in every publish
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 
 // feature row (within a 32-row tile) held by accumulator register r of a lane with half index hi
 __host__ __device__ constexpr int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }

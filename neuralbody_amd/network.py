@@ -207,11 +207,12 @@ class Network(nn.Module):
         if self.precision in ("f32", "bf16x3", "f16f6"):
             return self.precision
         if self.precision == "auto":
-            return "f16f6" if self.march_precision() == "f16f6" else "bf16x3"
+            return "f16f6" if self.march_precision() == "f16f6r" else "bf16x3"
         return "bf16x3"
 
     def march_precision(self):
-        """Arithmetic of the fused march.  'auto' = 'f16f6' (cross terms in six bits, the fastest) unless the weights have
+        """Arithmetic of the fused march.  'auto' = 'f16f6r' (cross terms in six bits on the ring kernel: 2-4 % faster than
+        the M-split organisation 'f16f6' on every box measured, profiles/r03_march_kernels.md) unless the weights have
         blocks fp6 cannot hold: more than SIX_BIT_MAX_SMALL of a layer's non-zero weights below 1/8 of their block maximum
         (normally distributed weights: ~0.2; the wide-dynamic-range stress case of tools/experiments/precision_sweep.py:
         ~0.75, where six-bit weights triple the error) — then 'f16f8'.  Decided once per weight version (one 5-float
@@ -221,7 +222,7 @@ class Network(nn.Module):
         packed = self.packed_weights("f16f6")
         if self._auto is None or self._auto[0] is not self._packed_key:
             worst = float(ops.six_bit_small_fraction(packed).max())
-            self._auto = (self._packed_key, "f16f6" if worst <= SIX_BIT_MAX_SMALL else "f16f8", worst)
+            self._auto = (self._packed_key, "f16f6r" if worst <= SIX_BIT_MAX_SMALL else "f16f8", worst)
         return self._auto[1]
 
     def packed_weights(self, precision=None):
@@ -229,6 +230,8 @@ class Network(nn.Module):
         arithmetics asked for since the last change are (re)written — a training step repacks every iteration and only
         ever decodes with 'f32'."""
         need = {self.march_precision(), self._point_precision()} if precision is None else {precision}
+        if "f16f6" in need:
+            need.discard("f16f6r")  # the 'f16f6' section holds both weight streams (ring and M-split)
         d = self._mlp_param_dict()
         # keyed on the parameters' storages, which the entry keeps alive (so an address cannot be recycled under the
         # key), and on their version counters (optimizer steps and load_state_dict write in place)
@@ -239,10 +242,10 @@ class Network(nn.Module):
         if self._packed is None or not same:
             self._packed = ops.mlp_pack(d, self._packed, precisions=need)
             self._packed_key = key
-            self._packed_have = set(need) | {"f32"}
+            self._packed_have = set(need) | {"f32"} | ({"f16f6r"} if "f16f6" in need else set())
         elif not need <= self._packed_have:
             ops.mlp_pack(d, self._packed, precisions=need - self._packed_have)
-            self._packed_have |= need
+            self._packed_have |= need | ({"f16f6r"} if "f16f6" in need else set())
         return self._packed
 
     def latent_bias(self, latent_index):
