@@ -244,8 +244,8 @@ def train_bench(args, dev):
 
 def turntable_bench(args, dev):
     """Config 2/5 of BASELINE.json in synthetic form: a spiral camera path (gen_path) around the body, every view done
-    as nb_raygen -> Renderer.render (encoder + march) -> nb_image_assemble, i.e. finished images on the device with one
-    4-byte host sync per view.  Informational: prints its own JSON line."""
+    as nb_raygen -> Renderer.render (encoder + march) -> nb_image_assemble, i.e. finished images on the device; the 4-byte ray
+    count of a view is read one view ahead (NovelViewRenderer.render_views).  Informational: prints its own JSON line."""
     from neuralbody_amd import novel_view as nv
     from neuralbody_amd import synthetic as syn
 
@@ -264,8 +264,8 @@ def turntable_bench(args, dev):
         nvr.render_view(K, RT, body["can_bounds"], frame)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for RT in path[args.warmup:]:
-        rays += nvr.render_view(K, RT, body["can_bounds"], frame, bgr=True, scale=255.0)["n_rays"]
+    for view in nvr.render_views(((K, RT, body["can_bounds"], frame) for RT in path[args.warmup:]), bgr=True, scale=255.0):
+        rays += view["n_rays"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return ({"metric": "turntable_views_per_sec", "value": args.steps / dt, "unit": "views/s", "higher_is_better": True,

@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 15
+#define NB_ABI_VERSION 16
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -260,11 +260,13 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
  *   weight dev [3,3,3,Cin,Cout] (spconv 1.x layout); in_rows dev [n_in,Cin];
  *   in_grid dev index grid of the INPUT tensor; out_lin dev [n_out_max] linear voxel index
  *   of each OUTPUT row in the OUTPUT grid; n_out dev [1]; stats dev [2*Cout] fp64 (zeroed
- *   by the call). */
+ *   by the call unless flags has NB_CONV_STATS_ZEROED: the caller cleared it, e.g. one memset for the statistics of all
+ *   17 layers instead of one launch per layer). */
+#define NB_CONV_STATS_ZEROED 1
 int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3],
                 const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max,
                 const int32_t out_dhw[3], int32_t stride, const float *weight, int32_t cin,
-                int32_t cout, float *out_rows, double *stats, void *stream);
+                int32_t cout, float *out_rows, double *stats, int32_t flags, void *stream);
 
 /* BatchNorm1d(eps=1e-3) over active rows + ReLU, in place (latent_xyzc.py:208-274).
  * training != 0: normalise with the batch statistics in `stats` (biased variance), write
@@ -297,7 +299,7 @@ int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_row
 int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *in_grid, const int32_t in_dhw[3],
                   const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3],
                   int32_t stride, const uint16_t *wpacked, int32_t cin, int32_t cout, float *out_rows, double *stats,
-                  void *stream);
+                  int32_t flags, void *stream);
 
 /* ---- encoder backward (training).  Shapes as in the forward calls above. ---- */
 

@@ -434,6 +434,249 @@ __global__ __launch_bounds__(256) void conv16_lds_kernel(const unsigned short *_
     }
 }
 
+// conv16_lds_kernel with TWO offset groups per workgroup (8 waves: waves 0-3 take the even kernel offsets of the 128 rows,
+// waves 4-7 the odd ones, each group with its own double-buffered weight slab; the partial tiles meet in LDS at the end, fixed
+// order).  The mid levels of the SMPL grid (10-29 k rows) give 150-230 workgroups of the kernel above — less than one per
+// CU, one wave per SIMD — and each walks 27 offsets at 2.5-3.7 us apiece for 0.7 us of MFMA work: halving the chain halves
+// the launch, and the second wave per SIMD fills the first one's waits.
+template <int CIN, int COUT, int NT>
+__global__ __launch_bounds__(512) void conv16_lds2_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
+                                                          const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
+                                                          const int *__restrict__ n_out, Dims go, int stride,
+                                                          const bf16x8 *__restrict__ wp, float *__restrict__ out_rows,
+                                                          double *__restrict__ stats) {
+    constexpr int NC = CIN / 16, NTT = COUT / 32;
+    constexpr int NFRAG = NC * NT * 2;        // 1-KiB fragments of one offset's slab: [c][t][head, remainder]
+    constexpr int PER_WAVE = NFRAG / 4;       // DMAs per wave per offset
+    constexpr int NIT = 14;                   // offsets per group (group 1: 13)
+    static_assert(NFRAG % 4 == 0, "slab must split evenly over the four waves of a group");
+    static_assert(2 * 2 * NFRAG * 1024 >= 4 * NT * 64 * 16 * 4, "the partial tiles fit in the slab memory");
+    __shared__ __attribute__((aligned(16))) char slab[2][2][NFRAG * 1024];  // [group][buffer]
+    const int ct = blockIdx.y * NT;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int wv8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wv = wv8 & 3, grp = wv8 >> 2;
+    const int n = *n_out;
+    const int row0 = (blockIdx.x * 4 + wv) * 32;
+    if (blockIdx.x * 128 >= n) return;  // workgroup-uniform: every wave of a live workgroup takes part in the barriers
+    const int row = row0 + i;
+    const bool valid = row < n;
+    const int lin = valid ? out_lin[row] : 0;
+    const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto issue_slab = [&](int o, int buf) {  // this wave's share of offset o's fragments -> slab[grp][buf]
+#pragma unroll
+        for (int q = 0; q < PER_WAVE; ++q) {
+            const int f = wv * PER_WAVE + q;           // local fragment (c, t, part) = ((c * NT) + t) * 2 + part
+            const int c = f / (NT * 2), rest = f % (NT * 2);
+            const bf16x8 *src = wp + (((size_t)o * NC + c) * NTT + ct) * 2 * 64 + (size_t)rest * 64 + lane;
+            __builtin_amdgcn_global_load_lds((nb_gptr_t)src, (nb_lptr_t)(slab[grp][buf] + f * 1024), 16, 0, 0);
+        }
+    };
+    int nbrs[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int o = 2 * k + grp;
+        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
+        int nbr = -1;
+        if (o < 27 && valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
+            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+        nbrs[k] = nbr;
+    }
+    auto load_rows = [&](int nbr, bf16x8 (&ah)[NC], bf16x8 (&al)[NC]) {
+        const size_t r = (size_t)(nbr >= 0 ? nbr : 0) * CIN + 8 * hi;
+        const bf16x8 *ph = reinterpret_cast<const bf16x8 *>(in_split + r);
+        const bf16x8 *pl = reinterpret_cast<const bf16x8 *>(in_split + in_plane + r);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            ah[c] = ph[2 * c];
+            al[c] = pl[2 * c];
+        }
+    };
+    bf16x8 ah[2][NC], al[2][NC];
+    issue_slab(grp, 0);
+    load_rows(nbrs[0], ah[0], al[0]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+        const int o = 2 * k + grp;
+        if (k + 1 < NIT && o + 2 < 27) {
+            issue_slab(o + 2, (k + 1) & 1);  // the other buffer: its last readers passed the barrier that ended iteration k - 1
+            load_rows(nbrs[k + 1], ah[(k + 1) & 1], al[(k + 1) & 1]);
+        }
+        const int nbr = nbrs[k];
+        if (o < 27 && __any(nbr >= 0)) {
+            const bf16x8 *sl = reinterpret_cast<const bf16x8 *>(slab[grp][k & 1]) + lane;
+            bf16x8 zero;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) zero[e] = (nb_h16)0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bf16x8 a_h = nbr >= 0 ? ah[k & 1][c] : zero, a_l = nbr >= 0 ? al[k & 1][c] : zero;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 bh = sl[((c * NT + t) * 2) * 64], bl = sl[((c * NT + t) * 2 + 1) * 64];
+                    acc[t] = NB_MFMA16(a_h, bh, acc[t]);
+                    acc[t] = NB_MFMA16(a_h, bl, acc[t]);
+                    acc[t] = NB_MFMA16(a_l, bh, acc[t]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of the next slab (and the prefetched rows) have landed
+        __syncthreads();                                  // ... everybody's have, and everybody is done reading this one
+    }
+    // the odd group's partial tiles -> LDS (the slabs are dead: the loop ended on a barrier), the even group adds and stores
+    float *part = reinterpret_cast<float *>(&slab[0][0][0]) + (size_t)wv * NT * 16 * 64;
+    if (grp == 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (grp == 1 || row0 >= n) return;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = (ct + t) * 32 + i;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = row0 + tile_row(r, hi);
+            const float v = acc[t][r] + part[(t * 16 + r) * 64 + lane];
+            if (orow < n) {
+                out_rows[(size_t)orow * COUT + co] = v;
+                s += (double)v;
+                ss += (double)v * (double)v;
+            }
+        }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (hi == 0) {
+            atomicAdd(&stats[co], s);
+            atomicAdd(&stats[COUT + co], ss);
+        }
+    }
+}
+
+// The same product with the 27 kernel offsets SPLIT OVER THE NW WAVES of a workgroup (one 32-row x 32-channel tile per
+// workgroup, wave w takes offsets w, w + NW, ...; partial tiles summed through LDS in wave order: deterministic).  On the deep
+// levels a launch has a few hundred to a few thousand rows, i.e. 16-64 workgroups of the kernels above on 256 CUs, and each of
+// them walks 27 offsets at one L2 round trip (index -> row -> MFMA, 2.5-4 us) apiece: 67-116 us per 128-channel layer for
+// ~20 us of MFMA work per wave (profiles/r03_step_timeline.md).  Here the serial chain is ceil(27 / NW) offsets long and the
+// operands of offset k + 1 are re-loaded into the registers offset k has just consumed (rows and weight fragments, chunk by
+// chunk), so every load has a full offset of MFMAs to land.
+template <int CIN, int COUT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv16_ks_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
+                                                           const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
+                                                           const int *__restrict__ n_out, Dims go, int stride,
+                                                           const bf16x8 *__restrict__ wp, float *__restrict__ out_rows,
+                                                           double *__restrict__ stats) {
+    constexpr int NC = CIN / 16, NTT = COUT / 32;
+    constexpr int MAXO = (27 + NW - 1) / NW;
+    __shared__ __attribute__((aligned(16))) float red[NW][16][64];
+    const int ct = blockIdx.y;
+    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = *n_out;
+    const int row0 = blockIdx.x * 32;
+    if (row0 >= n) return;  // workgroup-uniform
+    const int row = row0 + i;
+    const bool valid = row < n;
+    const int lin = valid ? out_lin[row] : 0;
+    const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
+    int nbrs[MAXO];
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) {
+        const int o = wv + NW * k;
+        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
+        int nbr = -1;
+        if (o < 27 && valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
+            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+        nbrs[k] = nbr;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    bf16x8 ah[NC], al[NC], bh[NC], bl[NC];
+    auto load_a = [&](int nbr, int c) {
+        const size_t r = (size_t)(nbr >= 0 ? nbr : 0) * CIN + 8 * hi + 16 * c;
+        ah[c] = *reinterpret_cast<const bf16x8 *>(in_split + r);
+        al[c] = *reinterpret_cast<const bf16x8 *>(in_split + in_plane + r);
+    };
+    auto load_b = [&](int o, int c) {
+        const bf16x8 *w = wp + ((((size_t)o * NC + c) * NTT + ct) * 2) * 64 + lane;
+        bh[c] = w[0];
+        bl[c] = w[64];
+    };
+    if (wv < 27) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            load_a(nbrs[0], c);
+            load_b(wv, c);
+        }
+    }
+    bf16x8 zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (nb_h16)0.f;
+#pragma unroll
+    for (int k = 0; k < MAXO; ++k) {
+        const int o = wv + NW * k;
+        if (o >= 27) break;  // wave-uniform
+        const int nbr = nbrs[k];
+        const bool more = k + 1 < MAXO && o + NW < 27;
+        const bool live = __any(nbr >= 0);  // else: nothing active under this offset for the whole tile
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (live) {
+                const bf16x8 a_h = nbr >= 0 ? ah[c] : zero, a_l = nbr >= 0 ? al[c] : zero;  // row 0 was read for inactive lanes
+                acc = NB_MFMA16(a_h, bh[c], acc);
+                acc = NB_MFMA16(a_h, bl[c], acc);
+                acc = NB_MFMA16(a_l, bh[c], acc);
+            }
+            if (more) {
+                load_a(nbrs[k + 1 < MAXO ? k + 1 : k], c);
+                load_b(o + NW, c);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][r][lane] = acc[r];
+    __syncthreads();
+    // wave w finishes accumulator registers [w RPW, (w + 1) RPW) of the tile: D fragment, lane (j = i, hi) holds channel
+    // ct * 32 + j of rows row0 + tile_row(r, hi)
+    constexpr int RPW = 16 / NW;
+    static_assert(16 % NW == 0, "accumulator registers split evenly over the waves");
+    const int co = ct * 32 + i;
+    double s = 0.0, ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < RPW; ++q) {
+        const int r = wv * RPW + q;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][r][lane];
+        const int orow = row0 + tile_row(r, hi);
+        if (orow < n) {
+            out_rows[(size_t)orow * COUT + co] = v;
+            s += (double)v;
+            ss += (double)v * (double)v;
+        }
+    }
+    s += __shfl_xor(s, 32);
+    ss += __shfl_xor(ss, 32);
+    if (hi == 0) {
+        atomicAdd(&stats[co], s);
+        atomicAdd(&stats[COUT + co], ss);
+    }
+}
+
 // ------------------------------------------------------------------ BatchNorm1d + ReLU (+ .dense())
 __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__ n_rows, int C,
                                const double *__restrict__ stats, const float *__restrict__ gamma,
@@ -561,13 +804,13 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
 
 int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3], const int32_t *out_lin,
                 const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride, const float *weight,
-                int32_t cin, int32_t cout, float *out_rows, double *stats, void *stream) {
+                int32_t cin, int32_t cout, float *out_rows, double *stats, int32_t flags, void *stream) {
     NB_REQUIRE(in_rows && in_grid && in_dhw && out_lin && n_out && out_dhw && weight && out_rows && stats,
                "nb_enc_conv: NULL pointer");
     NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv: stride %d", stride);
     hipStream_t st = (hipStream_t)stream;
     const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]}, go = {out_dhw[0], out_dhw[1], out_dhw[2]};
-    NB_HIP(hipMemsetAsync(stats, 0, 2 * (size_t)cout * sizeof(double), st));
+    if (!(flags & NB_CONV_STATS_ZEROED)) NB_HIP(hipMemsetAsync(stats, 0, 2 * (size_t)cout * sizeof(double), st));
     if (n_out_max <= 0) return NB_OK;
 #define NB_CONV_CASE(CI, CO)                                                                                     \
     if (cin == CI && cout == CO) {                                                                               \
@@ -637,23 +880,50 @@ int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t 
 
 int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *in_grid, const int32_t in_dhw[3],
                   const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride,
-                  const uint16_t *wpacked, int32_t cin, int32_t cout, float *out_rows, double *stats, void *stream) {
+                  const uint16_t *wpacked, int32_t cin, int32_t cout, float *out_rows, double *stats, int32_t flags,
+                  void *stream) {
     NB_REQUIRE(in_split && in_grid && in_dhw && out_lin && n_out && out_dhw && wpacked && out_rows && stats,
                "nb_enc_conv16: NULL pointer");
     NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv16: stride %d", stride);
     NB_REQUIRE(in_rows_cap > 0, "nb_enc_conv16: in_rows_cap %d", in_rows_cap);
     hipStream_t st = (hipStream_t)stream;
     const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]}, go = {out_dhw[0], out_dhw[1], out_dhw[2]};
-    NB_HIP(hipMemsetAsync(stats, 0, 2 * (size_t)cout * sizeof(double), st));
+    if (!(flags & NB_CONV_STATS_ZEROED)) NB_HIP(hipMemsetAsync(stats, 0, 2 * (size_t)cout * sizeof(double), st));
     if (n_out_max <= 0) return NB_OK;
     const long long plane = (long long)in_rows_cap * cin;
     const int row_groups = (int)nb_ceil_div(n_out_max, 128);
+    // small levels (the deepest one of the SMPL grid: ~1.6 k rows): the launch is a handful of workgroups whichever way it is
+    // tiled, so the chain of dependent L2 round trips per workgroup is what counts — offsets split over 8 waves (24 us instead
+    // of 67-98 us per 128-channel layer); larger levels are L2-bandwidth-bound under that tiling (weights per 32 rows)
+    if (n_out_max <= 4096) {
+#define NB_CONV16_KS_CASE(CI, CO)                                                                                           \
+    if (cin == CI && cout == CO) {                                                                                          \
+        hipLaunchKernelGGL((conv16_ks_kernel<CI, CO, 8>), dim3((unsigned)nb_ceil_div(n_out_max, 32), CO / 32), dim3(512), 0, st, \
+                           in_split, plane, in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), \
+                           out_rows, stats);                                                                                \
+        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
+        return NB_OK;                                                                                                       \
+    }
+        NB_CONV16_KS_CASE(32, 32)
+        NB_CONV16_KS_CASE(32, 64)
+        NB_CONV16_KS_CASE(64, 64)
+        NB_CONV16_KS_CASE(64, 128)
+        NB_CONV16_KS_CASE(128, 128)
+#undef NB_CONV16_KS_CASE
+    }
     // channel tiles per wave: all of them when the rows alone fill the chip (4 waves per group, 1024 SIMDs), else one per wave
     // 64- and 128-channel layers: weight slab shared through LDS (measured slower for the 32-channel ones: 35 vs 29 us); all channel tiles per wave when the rows alone give >= 512
     // workgroups, else two per wave (128 x 64-channel workgroups)
 #define NB_CONV16_LDS_CASE(CI, CO)                                                                                          \
     if (cin == CI && cout == CO) {                                                                                           \
         constexpr int NTT = CO / 32;                                                                                        \
+        if (row_groups < 512) {                                                                                             \
+            hipLaunchKernelGGL((conv16_lds2_kernel<CI, CO, 2>), dim3(row_groups, NTT / 2), dim3(512), 0, st, in_split, plane, \
+                               in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,  \
+                               stats);                                                                                      \
+            NB_CHECK_LAUNCH("nb_enc_conv16");                                                                               \
+            return NB_OK;                                                                                                   \
+        }                                                                                                                   \
         if (row_groups >= 512 || NTT <= 2)                                                                                  \
             hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, NTT>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, \
                                gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats); \

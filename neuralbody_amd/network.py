@@ -96,6 +96,7 @@ class SparseConvNet(nn.Module):
         fast = save is None and ENC_SPLIT
         layers = [(name, cin, cout, n, stride, j) for name, cin, cout, n, stride in ENCODER_BLOCKS for j in range(n)]
         rows_are_split = False
+        stats_all = torch.zeros((len(layers), 256), dtype=torch.float64, device=dev)  # one fill for every layer's statistics
         for li, (name, cin, cout, n, stride, j) in enumerate(layers):
             block = getattr(self, name)
             conv, bn = block[3 * j], block[3 * j + 1]
@@ -105,10 +106,10 @@ class SparseConvNet(nn.Module):
                 out_grid, out_lin, n_out, n_out_max, out_dhw = grid, rows_lin, n_rows, n_max, dhw
             if rows_are_split:
                 new_rows, stats = ops.enc_conv16(rows, grid, dhw, out_lin, n_out, n_out_max, out_dhw, stride,
-                                                 self._packed16(conv), cin, cout)
+                                                 self._packed16(conv), cin, cout, stats=stats_all[li, :2 * cout])
             else:
                 new_rows, stats = ops.enc_conv(rows, grid, dhw, out_lin, n_out, n_out_max, out_dhw, stride,
-                                               conv.weight.detach())
+                                               conv.weight.detach(), stats=stats_all[li, :2 * cout])
             dense = None
             if name in DENSE_AFTER and j == n - 1:
                 dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
@@ -152,6 +153,7 @@ class Network(nn.Module):
         if self.precision not in ("auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6"):
             raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'f16f6r', 'f16f8' or 'f16f6'")
         self._auto = None  # (weight key, chosen arithmetic) of precision 'auto'
+        self._lb_cache = None  # (latent_index tensor, versions, bias) of latent_bias()
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -175,7 +177,7 @@ class Network(nn.Module):
     # the packed blobs and their keys (storages!) are caches of the parameters: they are neither copied nor pickled
     def __getstate__(self):
         st = dict(self.__dict__)
-        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={})
+        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None)
         return st
 
     def __deepcopy__(self, memo):
@@ -251,11 +253,25 @@ class Network(nn.Module):
     def latent_bias(self, latent_index):
         """Per-frame bias of the merged feature_fc/latent_fc layer (latent_xyzc.py:108-111)."""
         w = self.latent.weight.detach()
-        if not isinstance(latent_index, torch.Tensor):
+        # The bias is a function of the frame's latent row and four layers' parameters: kept per (latent_index tensor, its
+        # version, the parameters' versions) — a view loop re-renders one frame, and the three launches it takes (index_select,
+        # copy, nb_mlp_latent_bias: ~40 us) sit between the encoder and the march.  The entry holds the index tensor itself,
+        # so its address cannot be recycled under the key; a training step bumps the versions and misses.
+        d = None
+        if isinstance(latent_index, torch.Tensor):
+            d = self._mlp_param_dict()
+            vers = (latent_index._version, w._version, w.data_ptr()) + tuple((t.data_ptr(), t._version) for t in d.values())
+            old = self._lb_cache
+            if old is not None and old[0] is latent_index and old[1] == vers:
+                return old[2]
+        else:
             latent_index = torch.tensor([int(latent_index)])
         idx = latent_index.reshape(-1)[:1].long().to(w.device)
         row = w.index_select(0, idx)[0].contiguous()
-        return ops.mlp_latent_bias(self._mlp_param_dict(), row)
+        lb = ops.mlp_latent_bias(self._mlp_param_dict(), row)
+        if d is not None:
+            self._lb_cache = (latent_index, vers, lb)
+        return lb
 
     # ------------------------------------------------------------------ scene description
     def make_scene(self, feature_volume, sp_input):

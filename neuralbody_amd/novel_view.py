@@ -154,17 +154,57 @@ class NovelViewRenderer:
             self._vol_key = (src, ver)
         return self._vols
 
-    def view_batch(self, K, RT, can_bounds, frame):
-        """image_rays on device + the frame's sp_input fields -> the batch dict Renderer.render consumes.
-        `frame`: dict with device tensors coord [1,V,3] i32, out_sh [1,3] i32, bounds [1,2,3], R [1,3,3], Th [1,*,3],
-        latent_index [1] (+ the mask-culling keys for the _mmsk/_msk renderers)."""
+    def _launch_rays(self, K, RT, can_bounds):
+        """nb_raygen of one view + an asynchronous 4-byte copy of its ray count into pinned host memory; the event marks the
+        copy, so waiting for it does not wait for anything enqueued later (render_views enqueues it a whole view ahead)."""
         RT = np.asarray(RT, np.float64)
-        ray_o, ray_d, near, far, mask, n_rays = ops.raygen(self.H, self.W, K, RT[:3, :3], RT[:3, 3], can_bounds, self.device)
-        n = int(n_rays.item())  # the one host sync per view: the march is launched over exactly n rays
+        rays = ops.raygen(self.H, self.W, K, RT[:3, :3], RT[:3, 3], can_bounds, self.device)
+        slot = self._count_slot = (getattr(self, "_count_slot", -1) + 1) % 4
+        if getattr(self, "_count_host", None) is None:
+            pin = self.device.type == "cuda"
+            self._count_host = [torch.empty(1, dtype=torch.int32, pin_memory=pin) for _ in range(4)]
+        host = self._count_host[slot]
+        host.copy_(rays[5], non_blocking=True)
+        ev = None
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+        return rays, host, ev
+
+    @staticmethod
+    def _finish_batch(launched, frame):
+        (ray_o, ray_d, near, far, mask, _), host, ev = launched
+        if ev is not None:
+            ev.synchronize()
+        n = int(host[0])  # the march is launched over exactly n rays
         batch = dict(frame)
         batch.update(ray_o=ray_o[None, :n], ray_d=ray_d[None, :n], near=near[None, :n], far=far[None, :n],
                      mask_at_box=mask[None])
         return batch
+
+    def view_batch(self, K, RT, can_bounds, frame):
+        """image_rays on device + the frame's sp_input fields -> the batch dict Renderer.render consumes.
+        `frame`: dict with device tensors coord [1,V,3] i32, out_sh [1,3] i32, bounds [1,2,3], R [1,3,3], Th [1,*,3],
+        latent_index [1] (+ the mask-culling keys for the _mmsk/_msk renderers).  One 4-byte host read per view (the ray
+        count); a single call waits for everything enqueued before it — loops over views should use render_views."""
+        return self._finish_batch(self._launch_rays(K, RT, can_bounds), frame)
+
+    def render_views(self, views, bgr=False, scale=1.0):
+        """Generator over finished views with the ray generation running ONE VIEW AHEAD: view k + 1's nb_raygen and the copy
+        of its ray count are enqueued before view k's encoder and march, so the host learns the count while the previous
+        march is still running and never drains the queue (the per-call render_view waits for the previous march before it
+        can enqueue the next view's ~110 encoder launches).  `views`: iterable of (K, RT, can_bounds, frame)."""
+        it = iter(views)
+        cur = next(it, None)
+        launched = None if cur is None else self._launch_rays(cur[0], cur[1], cur[2])
+        while cur is not None:
+            batch = self._finish_batch(launched, cur[3])
+            nxt = next(it, None)
+            if nxt is not None:
+                launched = self._launch_rays(nxt[0], nxt[1], nxt[2])
+            with torch.no_grad():
+                yield self._render_batch(batch, bgr, scale, None)
+            cur = nxt
 
     def render_view(self, K, RT, can_bounds, frame, bgr=False, scale=1.0, t_rand=None):
         """-> dict(img [H,W,3], depth [H,W], mask_at_box [H,W] uint8, n_rays) — device tensors."""
@@ -172,7 +212,9 @@ class NovelViewRenderer:
             return self._render_view(K, RT, can_bounds, frame, bgr, scale, t_rand)
 
     def _render_view(self, K, RT, can_bounds, frame, bgr, scale, t_rand):
-        batch = self.view_batch(K, RT, can_bounds, frame)
+        return self._render_batch(self.view_batch(K, RT, can_bounds, frame), bgr, scale, t_rand)
+
+    def _render_batch(self, batch, bgr, scale, t_rand):
         n = batch["ray_o"].shape[1]
         if n == 0:
             out = {"rgb_map": torch.zeros((1, 0, 3), device=self.device), "depth_map": torch.zeros((1, 0), device=self.device)}

@@ -235,9 +235,9 @@ def enc_voxelize(coord, dhw):
     n = coord.shape[0]
     dev = coord.device
     grid = torch.empty([int(s) for s in dhw], dtype=torch.int32, device=dev)
-    rows_vert = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
-    rows_lin = torch.zeros(max(n, 1), dtype=torch.int32, device=dev)
-    n_rows = torch.zeros(1, dtype=torch.int32, device=dev)
+    m = max(n, 1)
+    buf = torch.zeros(2 * m + 1, dtype=torch.int32, device=dev)  # one fill
+    rows_vert, rows_lin, n_rows = buf[:m], buf[m:2 * m], buf[2 * m:]
     scratch = scan_scratch(n, dev)
     check(_lib.lib().nb_enc_voxelize(ptr(coord), n, _i3(dhw), ptr(grid), ptr(rows_vert), ptr(rows_lin), ptr(n_rows),
                                      ptr(scratch), _stream()), "nb_enc_voxelize")
@@ -257,8 +257,8 @@ def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None):
     nvox = out_dhw[0] * out_dhw[1] * out_dhw[2]
     n_out_max = max(min(8 * int(n_in_max), nvox), 1)
     out_grid = torch.empty(out_dhw, dtype=torch.int32, device=dev)
-    out_lin = torch.zeros(n_out_max, dtype=torch.int32, device=dev)
-    n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+    buf = torch.zeros(n_out_max + 1, dtype=torch.int32, device=dev)  # one fill
+    out_lin, n_out = buf[:n_out_max], buf[n_out_max:]
     if scratch is None:
         scratch = scan_scratch(nvox, dev)
     check(_lib.lib().nb_enc_downsample_index(ptr(in_lin), ptr(n_in), int(n_in_max), _i3(in_dhw), _i3(out_dhw),
@@ -267,8 +267,9 @@ def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None):
     return out_grid, out_lin, n_out, n_out_max, out_dhw
 
 
-def enc_conv(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, weight):
-    """nb_enc_conv -> (out_rows [n_out_max, Cout], stats [2*Cout] fp64)."""
+def enc_conv(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, weight, stats=None):
+    """nb_enc_conv -> (out_rows [n_out_max, Cout], stats [2*Cout] fp64).  `stats`: a ZEROED fp64 [2*Cout] buffer of the
+    caller's (the encoder clears the statistics of all its layers with one fill) — else the call allocates and clears one."""
     _req(weight, torch.float32, (3, 3, 3, None, None), "conv weight")
     cin, cout = int(weight.shape[3]), int(weight.shape[4])
     _req(in_rows, torch.float32, (None, cin), "in_rows")
@@ -279,9 +280,13 @@ def enc_conv(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, strid
         raise ValueError("out_lin shorter than n_out_max")
     dev = in_rows.device
     out_rows = torch.empty((max(int(n_out_max), 1), cout), dtype=torch.float32, device=dev)
-    stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    flags = 0 if stats is None else 1  # NB_CONV_STATS_ZEROED
+    if stats is None:
+        stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    else:
+        _req(stats, torch.float64, (2 * cout,), "stats")
     check(_lib.lib().nb_enc_conv(ptr(in_rows), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out), int(n_out_max),
-                                 _i3(out_dhw), int(stride), ptr(weight), cin, cout, ptr(out_rows), ptr(stats),
+                                 _i3(out_dhw), int(stride), ptr(weight), cin, cout, ptr(out_rows), ptr(stats), flags,
                                  _stream()), "nb_enc_conv")
     return out_rows, stats
 
@@ -318,8 +323,9 @@ def enc_conv_pack16(weight):
     return packed
 
 
-def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, wpacked, cin, cout):
-    """nb_enc_conv16 on split rows (int16 [2, cap, Cin]: fp16 heads | remainders) -> (out_rows fp32, stats fp64)."""
+def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, wpacked, cin, cout, stats=None):
+    """nb_enc_conv16 on split rows (int16 [2, cap, Cin]: fp16 heads | remainders) -> (out_rows fp32, stats fp64); `stats` as
+    in enc_conv."""
     _req(in_split, torch.int16, (2, None, cin), "in_split")
     _req(wpacked, torch.int16, (27 * cin * cout * 2,), "wpacked")
     _req(in_grid, torch.int32, tuple(int(s) for s in in_dhw), "in_grid")
@@ -329,10 +335,14 @@ def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, st
         raise ValueError("out_lin shorter than n_out_max")
     dev = in_split.device
     out_rows = torch.empty((max(int(n_out_max), 1), cout), dtype=torch.float32, device=dev)
-    stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    flags = 0 if stats is None else 1  # NB_CONV_STATS_ZEROED
+    if stats is None:
+        stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
+    else:
+        _req(stats, torch.float64, (2 * cout,), "stats")
     check(_lib.lib().nb_enc_conv16(ptr(in_split), int(in_split.shape[1]), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out),
                                    int(n_out_max), _i3(out_dhw), int(stride), ptr(wpacked), cin, cout, ptr(out_rows),
-                                   ptr(stats), _stream()), "nb_enc_conv16")
+                                   ptr(stats), flags, _stream()), "nb_enc_conv16")
     return out_rows, stats
 
 

@@ -51,8 +51,12 @@ class Renderer:
     def prepare_sp_input(self, batch):
         sp_input = {}
         sh = batch["coord"].shape
-        idx = [torch.full([sh[1]], i) for i in range(sh[0])]
-        idx = torch.cat(idx).to(batch["coord"])
+        # built on the coordinates' device: the reference makes these on the host and copies them over, and a copy from
+        # pageable host memory makes the launch thread wait for everything already enqueued (the previous view's march) —
+        # the encoder's ~90 launches then cannot be enqueued under it (tools/experiments/cpu_ahead.py: 18.2 ms of host time
+        # per render() instead of 1.5)
+        idx = [torch.full([sh[1]], i, dtype=batch["coord"].dtype, device=batch["coord"].device) for i in range(sh[0])]
+        idx = torch.cat(idx)
         coord = batch["coord"].view(-1, sh[-1])
         sp_input["coord"] = torch.cat([idx[:, None], coord], dim=1)
         sp_input["out_sh"] = self._host_out_sh(batch["out_sh"])

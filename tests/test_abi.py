@@ -21,7 +21,7 @@ def test_library_exports_every_header_symbol(lib):
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.nb_abi_version() == _lib.ABI_VERSION == 15
+    assert lib.nb_abi_version() == _lib.ABI_VERSION == 16
 
 
 def test_sizes_and_struct_layout(lib):
@@ -63,7 +63,7 @@ def test_error_codes_without_touching_a_device(lib):
     rc = lib.nb_composite(None, None, None, 4, 0, 0, None, None, None, None, None, None)
     assert rc == -1
     rc = lib.nb_enc_conv(None, None, (C.c_int32 * 3)(1, 1, 1), None, None, 0, (C.c_int32 * 3)(1, 1, 1), 1, None, 16,
-                         16, None, None, None)
+                         16, None, None, 0, None)
     assert rc == -1
 
 

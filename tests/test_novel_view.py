@@ -171,3 +171,11 @@ def test_novel_view_loop_matches_oracle(precision):
         assert torch.equal(again["img"], out["img"]) and torch.equal(again["depth"], out["depth"])
         checked += 1
     assert checked >= 2, "the spiral must see the body"
+    # the look-ahead generator (ray generation one view ahead of the march) yields the per-call images, in order
+    singles = [nvr.render_view(K0, RT, body["can_bounds"], frame) for RT in path]
+    ahead = list(nvr.render_views((K0, RT, body["can_bounds"], frame) for RT in path))
+    assert len(ahead) == len(singles) == 5
+    for a, b in zip(ahead, singles):
+        assert a["n_rays"] == b["n_rays"] and torch.equal(a["img"], b["img"]) and torch.equal(a["depth"], b["depth"])
+        assert torch.equal(a["mask_at_box"], b["mask_at_box"])
+    assert list(nvr.render_views(iter(()))) == []
