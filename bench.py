@@ -19,7 +19,7 @@ same without the rays whose last sample's density is within ILL_SIGMA of zero, w
 `--scaling strong` shards ONE view's rays over the ranks (parallel.render_sharded) instead of one view per rank.
 
 The JSON line also carries
-  roofline     — the dominant kernel (nb_march_f6_kernel by default; --precision picks the others): algorithmic MLP
+  roofline     — the dominant kernel (nb_march_ms6_kernel by default; --precision picks the others): algorithmic MLP
                  flops (859 904 per ray-sample) / its average launch duration measured with HIP
                  events inside the timed region, against the dense MFMA peak of the arithmetic its main product runs on
                  (2.5 PFLOP/s for the fp16 / bf16 paths, 157.3 TFLOP/s for exact fp32); `executed_frac` = the MFMA work the
@@ -54,7 +54,7 @@ PRECISION_INFO = {
     # the same with the cross terms in 6 bits: a K=64 fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA
     # (profiles/r02_probe_mxrate.log), so it is counted as one (a quarter of its flops)
     "f16f6r": ("f16+f6", "nb_march_f6_kernel", (520 + 272) * 32768 / 32.0, 2500.0),
-    # the same arithmetic, M-split workgroups (round 3; opt-in for marches, the kernel behind nb_decode_points): 4 waves x 408
+    # the same arithmetic, M-split workgroups (round 3, the default and the kernel behind nb_decode_points): 4 waves x 408
     # MFMAs per 64 samples (fc_0's K padded to 384, the encodings' to 128)
     "f16f6": ("f16+f6", "nb_march_ms6_kernel", 4 * 408 * 32768 / 64.0, 2500.0),
 }
@@ -295,8 +295,8 @@ def extras(args, dev):
     # the record then holds a reference-precision number and an A/B of the kernels from ONE box
     from neuralbody_amd import ops
 
-    for prec in ("f32", "f16f6", "bf16x3"):
-        if prec == (args.precision or "f16f6r"):
+    for prec in ("f32", "f16f6r", "bf16x3"):
+        if prec == (args.precision or "f16f6"):
             continue
         sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, prec)
         with torch.no_grad():
@@ -462,7 +462,7 @@ def main():
                                            "terms in 8 bits (fp8 e4m3 weights, bf8 e5m2 activations) on "
                                            "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate",
                                   "f16f6": "the f16f6r arithmetic on the M-split organisation (round 3: four waves share 64 rays, "
-                                           "activations in LDS, weights streamed from L2; 2-4 % slower than the ring)"}[net.march_precision()],
+                                           "activations in LDS, weights streamed from L2, two workgroups per CU)"}[net.march_precision()],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,

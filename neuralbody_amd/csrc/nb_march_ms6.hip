@@ -1,23 +1,28 @@
-// nb_march_ms6.hip — the default march kernel (NB_PREC_F16F6) for gfx950: the "f16f6" arithmetic of nb_march_f16.hip
+// nb_march_ms6.hip — the "M-split" organisation of the f16f6 march for gfx950 (NB_PREC_F16F6; round 3) and the kernel behind
+// nb_decode_points: the arithmetic of nb_march_f16.hip
 //
 //     W.X  ~=  W_h.X_h                               v_mfma_f32_32x32x16_f16            (products exact, fp32 accumulate)
 //            + fp6(W_h).bf6(X_l) + fp6(W_l).bf6(X_h)  v_mfma_scale_f32_32x32x64_f8f6f4   (K = 64, E8M0 block scales)
 //
-// (feature_fc, latent_fc and view_fc folded into one layer) on the "M-split" workgroup organisation, chosen from the
-// counters of the ring kernel (profiles/r02_march_pmc.md: matrix pipe 0.34 busy, one wave per SIMD, every 2-KiB weight
-// record feeding 1-2 MFMAs of a wave at the price of two LDS reads, a counted wait and half an LDS-DMA piece):
+// (feature_fc, latent_fc and view_fc folded into one layer) with the output features of every layer split over the waves
+// of a workgroup, built from the counters of the ring kernel (profiles/r02_march_pmc.md: matrix pipe 0.34 busy, one wave
+// per SIMD, every 2-KiB weight record feeding 1-2 MFMAs of a wave at the price of two LDS reads, a counted wait and half an
+// LDS-DMA piece):
 //
 //   * a workgroup (4 waves) marches 64 rays = two 32-sample N tiles; wave w owns a QUARTER OF EVERY LAYER'S OUTPUT
 //     FEATURES for all 64 samples, so a weight fragment feeds 2 MFMAs and comes straight from L2 into a register ring
-//     (plain global_load_dwordx4, no LDS-DMA, no page barriers);
+//     (buffer loads, no LDS-DMA, no page barriers);
 //   * activations live in LDS as ready-made B operands (fp16 heads by K=16 chunk, the two bf6 forms with their E8M0
 //     scale by K=64 block) and are rewritten in place after every layer; the two output tiles of wave w ARE K block w of
 //     the next layer, so the run-time block scale (max over 32 values of a lane) stays lane-local exactly as in the ring
 //     kernel, and every lane publishes into its own fragment slot;
-//   * <= 256 registers and 68 KiB of LDS: TWO workgroups per CU.  A wave is either in an MFMA phase or in a VALU phase
-//     (gather, encodings, conversions, heads); with two independent workgroups per SIMD one's VALU phases run in the
-//     matrix-pipe gaps of the other (tools/experiments/probe_coissue.hip: a partner's VALU work hides whenever the matrix
-//     wave is not issuing back to back).
+//   * <= 256 registers and 80 KiB of LDS: TWO workgroups per CU, whose phases overlap (two unsynchronised workgroups take
+//     57 k cycles per depth step for both, one alone 54 k).
+//
+// Measured (profiles/r03_march_kernels.md): 8 % fewer cycles than the ring kernel and 2-4 % MORE time — streaming every
+// wave's weight slice from L2 once per 64 samples (17 KiB per sample) costs 15 % of the clock under the board's power cap.
+// The ring kernel therefore stays the default march; this one serves nb_decode_points (every point a one-sample ray) and
+// precision 'f16f6'.
 //
 // Per-sample work (ray set-up, trilinear gather, positional encoding, compositing) is done by "owner" lanes: wave w,
 // lane l owns sample 16 w + (l & 15) and, of that sample, channel quarter / axis `part` = l >> 4.
@@ -26,8 +31,6 @@
 // element e of it sits in fp16 chunk 4 b + e / 8 at B-fragment lane kg = kh, register element e % 8, and at element e
 // (heads) / interleaved position (remainders) of the lane's bf6 operands of block b.  Weights are packed to match.
 #include "nb_f6_ops.h"
-
-#include <cstdlib>
 
 using namespace nbm;
 
@@ -40,10 +43,6 @@ namespace {
 #define NB_MS6_RING 8
 #endif
 constexpr int S_R = NB_MS6_RING;  // register ring depth in pieces
-#ifndef NB_MS6_LAG
-#define NB_MS6_LAG 7
-#endif
-constexpr int PAIR_LAG = NB_MS6_LAG;  // of the 14 barrier intervals of a depth step
 __host__ __device__ constexpr int phase_pieces(int nb, int mt) { return nb * mt * 8; }
 constexpr int N_PH = 7;
 // fc_0 in three K phases of 128 (pyramid level 3 | level 2 | levels 0 and 1 + 8 zero slots per lane), fc_1, fc_2,
@@ -723,22 +722,17 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 // MODE 0: rays (nb_march).  MODE 1 / 2: explicit points (nb_decode_points, raw [n,4] / density [n,1]): a point with its view
 // direction is a one-sample "ray" (origin = the point, direction = the view direction taken as given, z = 0) whose decoder
 // output is stored instead of composited; MODE 2 stops behind alpha_fc.
-template <int MODE, bool PAIR>
-__global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void nb_march_ms6_kernel(MarchArgs a, const char *stream) {
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const char *stream) {
     constexpr bool POINTS = MODE != 0, DENSITY_ONLY = MODE == 2;
-    __shared__ __attribute__((aligned(16))) char lds_all[PAIR ? 2 * LDS_BYTES : LDS_BYTES];
-    static_assert(!PAIR || 2 * LDS_BYTES <= 163840, "both groups' LDS in one CU");
-    // PAIR: two 4-wave groups (one wave of each per SIMD) march 64 rays each in their own LDS half, group 1 running PAIR_LAG
-    // barrier intervals behind group 0 so that one group's MFMA phases coincide with the other's VALU phases
-    const int group = PAIR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) : 0;
-    char *lds = lds_all + group * LDS_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char *act = lds;
-    const int tid = threadIdx.x & 255;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 3);
+    const int tid = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int hi = lane >> 5;
     const int os = lane & 15, part = lane >> 4;  // owner role
     const int sample = 16 * wave + os;            // 0..63 inside the workgroup
-    const int grp = PAIR ? 2 * xcd_remap(blockIdx.x, a.n_wave_groups) + group : xcd_remap(blockIdx.x, a.n_wave_groups);
+    const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
     long long ray = (long long)grp * 64 + sample;
     const long long n_units = POINTS ? a.n_pts : a.n_rays;
     const bool valid = ray < n_units;
@@ -799,8 +793,6 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void nb_march_ms6_k
             for (int i = tid; i < S; i += 256) reinterpret_cast<float *>(lds + TV_OFF)[i] = a.t_vals[i];
         __syncthreads();
     }
-    if (PAIR && group)
-        for (int i = 0; i < PAIR_LAG; ++i) __syncthreads();
     const __amdgpu_buffer_rsrc_t wrsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(stream) + (size_t)wave * P_TOTAL * 1024, 0, P_TOTAL * 1024, 0x00020000);
     WRing ring;
@@ -827,7 +819,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void nb_march_ms6_k
         f32x16 acc[2][2];
         const int sn = sample >> 5, ss = sample & 31;  // N tile and column of this lane's sample
 #ifdef MS6_TIMING
-        unsigned *tbuf = (blockIdx.x < 32 && wave == 0 && group == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + ((size_t)blockIdx.x * S + s) * 32 : nullptr;
+        unsigned *tbuf = (blockIdx.x < 32 && wave == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + ((size_t)blockIdx.x * S + s) * 32 : nullptr;
 #endif
         MS6_STAMP(0);
 
@@ -910,7 +902,7 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void nb_march_ms6_k
         }
 #ifdef MS6_TAP
 #define MS6_DUMP(LAYER, MT_)                                                                                              \
-    if (blockIdx.x == 0 && group == 0 && s == 0 && a.raw) {                                                                            \
+    if (blockIdx.x == 0 && s == 0 && a.raw) {                                                                            \
         for (int m = 0; m < (MT_); ++m)                                                                                   \
             for (int n = 0; n < 2; ++n)                                                                                   \
                 for (int r = 0; r < 16; ++r)                                                                              \
@@ -1074,8 +1066,6 @@ __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void nb_march_ms6_k
         MS6_STAMP(25);
         z_cur = z_next;
     }
-    if (PAIR && !group)
-        for (int i = 0; i < PAIR_LAG; ++i) __syncthreads();
     if (!POINTS && valid && part == 0) {
         const f32x4 *rec = reinterpret_cast<const f32x4 *>(lds + RAY_OFF) + sample * (RAY_FLOATS / 4);
         const f32x4 c0 = rec[3], c1 = rec[4];
@@ -1188,20 +1178,8 @@ int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off,
 }
 
 int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st) {
-#ifdef MS6_ONEWG
-    constexpr bool pair = false;
-#else
-    static const bool pair = !(getenv("NB_MS6_PAIR") && getenv("NB_MS6_PAIR")[0] == '0');
-#endif
-    if constexpr (LDS_BYTES * 2 <= 163840) if (pair) {
-        a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 128);
-        hipLaunchKernelGGL((nb_march_ms6_kernel<0, true>), dim3(a.n_wave_groups), dim3(512), 0, st, a,
-                           reinterpret_cast<const char *>(a.pk + stream_off));
-        NB_CHECK_LAUNCH("nb_march_ms6_kernel");
-        return NB_OK;
-    }
     a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 64);
-    hipLaunchKernelGGL((nb_march_ms6_kernel<0, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a,
+    hipLaunchKernelGGL(nb_march_ms6_kernel<0>, dim3(a.n_wave_groups), dim3(256), 0, st, a,
                        reinterpret_cast<const char *>(a.pk + stream_off));
     NB_CHECK_LAUNCH("nb_march_ms6_kernel");
     return NB_OK;
@@ -1211,8 +1189,8 @@ int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st) {
 int launch_points_ms6(MarchArgs a, int density_only, long long stream_off, hipStream_t st) {
     a.n_wave_groups = (int)nb_ceil_div(a.n_pts, 64);
     const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
-    if (density_only) hipLaunchKernelGGL((nb_march_ms6_kernel<2, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
-    else hipLaunchKernelGGL((nb_march_ms6_kernel<1, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    if (density_only) hipLaunchKernelGGL(nb_march_ms6_kernel<2>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    else hipLaunchKernelGGL(nb_march_ms6_kernel<1>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     NB_CHECK_LAUNCH("nb_march_ms6_kernel (points)");
     return NB_OK;
 }

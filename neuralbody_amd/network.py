@@ -209,12 +209,13 @@ class Network(nn.Module):
         if self.precision in ("f32", "bf16x3", "f16f6"):
             return self.precision
         if self.precision == "auto":
-            return "f16f6" if self.march_precision() == "f16f6r" else "bf16x3"
+            return "f16f6" if self.march_precision() == "f16f6" else "bf16x3"
         return "bf16x3"
 
     def march_precision(self):
-        """Arithmetic of the fused march.  'auto' = 'f16f6r' (cross terms in six bits on the ring kernel: 2-4 % faster than
-        the M-split organisation 'f16f6' on every box measured, profiles/r03_march_kernels.md) unless the weights have
+        """Arithmetic of the fused march.  'auto' = 'f16f6' (cross terms in six bits on the M-split kernel: within 3 % of the
+        ring kernel 'f16f6r' on the fastest boxes of the pool and 10 % ahead of it on the slow-memory ones, among them the
+        driver's bench box — profiles/r03_march_kernels.md) unless the weights have
         blocks fp6 cannot hold: more than SIX_BIT_MAX_SMALL of a layer's non-zero weights below 1/8 of their block maximum
         (normally distributed weights: ~0.2; the wide-dynamic-range stress case of tools/experiments/precision_sweep.py:
         ~0.75, where six-bit weights triple the error) — then 'f16f8'.  Decided once per weight version (one 5-float
@@ -224,7 +225,7 @@ class Network(nn.Module):
         packed = self.packed_weights("f16f6")
         if self._auto is None or self._auto[0] is not self._packed_key:
             worst = float(ops.six_bit_small_fraction(packed).max())
-            self._auto = (self._packed_key, "f16f6r" if worst <= SIX_BIT_MAX_SMALL else "f16f8", worst)
+            self._auto = (self._packed_key, "f16f6" if worst <= SIX_BIT_MAX_SMALL else "f16f8", worst)
         return self._auto[1]
 
     def packed_weights(self, precision=None):

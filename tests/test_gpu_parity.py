@@ -267,14 +267,14 @@ def test_march_on_oracle_volumes_matches_reference(name, precision):
 
 
 def test_auto_precision_picks_six_bits_unless_the_weight_blocks_are_wide():
-    """Network(precision='auto') = 'f16f6r' for ordinary weights and 'f16f8' when a layer's (row, 32 K) blocks span a wide
+    """Network(precision='auto') = 'f16f6' for ordinary weights and 'f16f8' when a layer's (row, 32 K) blocks span a wide
     dynamic range (the statistic nb_mlp_pack_sections leaves behind the f16f6 stream, nb_mlp_six_bit_stats_offset)."""
     from neuralbody_amd import ops
     from neuralbody_amd.network import SIX_BIT_MAX_SMALL
 
     sd = syn.make_weights(3, num_train_frame=7)
     net = H.make_network(sd, DEV, True, "auto")
-    assert net.march_precision() == "f16f6r"
+    assert net.march_precision() == "f16f6"
     frac = ops.six_bit_small_fraction(net.packed_weights("f16f6")).cpu().numpy()
     print("share of weights below 1/8 of their block maximum, per layer:", np.round(frac, 3))
     assert frac.shape == (4,) and (frac > 0.05).all() and (frac < 0.35).all()
@@ -290,7 +290,7 @@ def test_auto_precision_picks_six_bits_unless_the_weight_blocks_are_wide():
     assert float(ops.six_bit_small_fraction(net2.packed_weights("f16f6")).max()) > SIX_BIT_MAX_SMALL
     # the choice follows the weights: loading the ordinary ones back flips it
     net2.load_state_dict(net.state_dict())
-    assert net2.march_precision() == "f16f6r"
+    assert net2.march_precision() == "f16f6"
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

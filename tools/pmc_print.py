@@ -5,6 +5,6 @@ import sys
 for path in sys.argv[1:]:
     c = sqlite3.connect(path)
     rows = c.execute("select counter_name, kernel_name, sum(value), count(*), avg(duration) from counters_collection "
-                     "group by 1, 2 order by 3 desc limit 12").fetchall()
+                     "group by 1, 2 order by 3 desc limit 80").fetchall()
     for n, k, v, cnt, dur in rows:
         print("%s | %s | sum %.6g | dispatches %d | avg dur %.3f ms" % (n, k.replace("(anonymous namespace)::", "")[:60], v, cnt, dur / 1e6))
