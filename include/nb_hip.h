@@ -205,7 +205,11 @@ int nb_composite_bwd(const float *raw, const float *z_vals, const float *ray_d, 
 
 /* Row-major fp32 GEMM C[m,n] = alpha * op(A) op(B) + beta * C on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
  * fp32): the backward of the Conv1d(k=1) layers (latent_xyzc.py:99-121).  lda/ldb/ldc are row strides.  op(A) = A^T
- * (trans_a) is the weight-gradient form dW = dY^T X (split over the long row dimension, fp32 atomics, op(B) = B only). */
+ * (trans_a) is the weight-gradient form dW = dY^T X (split over the long row dimension, fp32 atomics, op(B) = B only:
+ * trans_a && trans_b is refused with NB_EINVAL, no caller of the path needs it).  Summation order: the trans_a form and the
+ * colsum epilogue of nb_gemm_fused accumulate with fp32 atomics, so weight / bias gradients are reproducible to rounding
+ * (~1e-7 relative), not bit for bit, from run to run — like the reference's own cuBLAS / atomics-based backward.  k == 0 is
+ * an empty product: C = beta C (and the epilogue). */
 int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
              const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream);
 /* The same with the epilogues of the backward chain fused (trans_a = 0 only):

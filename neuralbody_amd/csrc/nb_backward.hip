@@ -372,7 +372,7 @@ int nb_composite_bwd(const float *raw, const float *z_vals, const float *ray_d, 
 
 int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
              const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream) {
-    NB_REQUIRE(a && b && c && m >= 0 && n >= 0 && k >= 0, "nb_sgemm: bad argument");
+    NB_REQUIRE(c && (k == 0 || (a && b)) && m >= 0 && n >= 0 && k >= 0, "nb_sgemm: bad argument");
     if (m == 0 || n == 0) return NB_OK;
     return nb_gemm_fused(trans_a, trans_b, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, nullptr, 0, nullptr, stream);
 }
@@ -380,20 +380,26 @@ int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float al
 int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
                   const float *b, int32_t ldb, float beta, float *c, int32_t ldc, const float *mask_y, int32_t ldy,
                   float *colsum, void *stream) {
-    NB_REQUIRE(a && b && c && m >= 0 && n >= 0 && k >= 0, "nb_gemm_fused: bad argument");
+    NB_REQUIRE(c && (k == 0 || (a && b)) && m >= 0 && n >= 0 && k >= 0, "nb_gemm_fused: bad argument");
     if (m == 0 || n == 0) return NB_OK;
     hipStream_t st = (hipStream_t)stream;
     if (trans_a) {
         NB_REQUIRE(!trans_b && !mask_y && !colsum, "nb_gemm_fused: op(A) = A^T is the weight-gradient form (no epilogue, B not transposed)");
         if (beta != 1.f)
             hipLaunchKernelGGL(scale_matrix_kernel, dim3(nb_ceil_div((long long)m * n, 256)), dim3(256), 0, st, c, m, n, ldc, beta);
+        if (k == 0) {
+            NB_CHECK_LAUNCH("scale_matrix_kernel");
+            return NB_OK;
+        }
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(nb_ceil_div(k, 4 * TN_ROWS), nb_ceil_div(m, 32), nb_ceil_div(n, 32)), dim3(256),
                            0, st, a, lda, b, ldb, (long long)k, m, n, alpha, c, ldc);
         NB_CHECK_LAUNCH("gemm_tn_kernel");
         return NB_OK;
     }
     const dim3 grid(nb_ceil_div(m, 128), nb_ceil_div(n, 128)), block(256);
-    const bool aligned = k % 16 == 0 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ldb % 4 == 0 && ((uintptr_t)b % 16) == 0;
+    // k == 0 (an empty product: C = beta C, then the epilogue) goes to the general kernel, whose loop is guarded; the fast
+    // kernel pre-loads its first operand panels before looking at k
+    const bool aligned = k > 0 && k % 16 == 0 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ldb % 4 == 0 && ((uintptr_t)b % 16) == 0;
     if (aligned && trans_b)
         hipLaunchKernelGGL((gemm_rows_fast_kernel<true>), grid, block, 0, st, a, lda, b, ldb, (long long)m, k, n, alpha, beta, c, ldc, mask_y, ldy, colsum);
     else if (aligned)

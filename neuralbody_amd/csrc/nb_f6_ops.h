@@ -15,6 +15,13 @@ typedef _Float16 f16x32 __attribute__((ext_vector_type(32)));
 
 namespace nbm {
 
+// MODE.FP16_OVFL = 1 for the rest of the wave's life: a conversion to fp16 whose input is finite and beyond +-65504
+// SATURATES instead of returning inf (tools/experiments/probe_f16ovfl.hip; v_cvt_pk_f16_f32 has no clamp of its own).  The
+// fp16 head of an activation is the one place where these arithmetics have less range than fp32: without this, one
+// feature or layer output above 65504 turns into inf, inf - inf in the remainder, and a NaN pixel; with it the product is
+// merely inaccurate there.  Costs one scalar instruction per wave.
+__device__ __forceinline__ void saturate_fp16_conversions() { asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1"); }
+
 // fp16 head of two values (round to nearest even) and the exact fp32 remainder x - fp16(x) as ONE v_fma_mix_f32 each
 // (hipcc's own lowering of `x - (float)(_Float16)x` converts every value twice: 9 instead of 5 instructions per pair)
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {

@@ -937,6 +937,7 @@ __device__ __forceinline__ FRing f_ring_begin(const float *pk, const float *lb, 
 // scalars and restores 60 instead of 232 per depth step (v_readlane = VALU issue slots, which this kernel is short of).
 template <bool FULL>
 __global__ __launch_bounds__(256) void F_KERNEL(MarchArgs a, const char *stream) {
+    nbm::saturate_fp16_conversions();
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const FRing rg = f_ring_begin(a.pk, a.lb, stream, lds);
     const int lane = rg.lane, j = lane & 31, hi = lane >> 5;

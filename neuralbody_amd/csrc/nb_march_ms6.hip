@@ -725,6 +725,7 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const char *stream) {
     constexpr bool POINTS = MODE != 0, DENSITY_ONLY = MODE == 2;
+    saturate_fp16_conversions();
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char *act = lds;
     const int tid = threadIdx.x;

@@ -106,6 +106,15 @@ def test_sgemm_relu_colsum():
         np.testing.assert_allclose(out[:, 1:n + 1].cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=2e-4)
         np.testing.assert_allclose(cs.cpu().numpy(), 0.25 + ref.sum(0).float().cpu().numpy(), rtol=1e-4, atol=2e-3)
         assert torch.equal(out[:, 0], C0[:, 0]) and torch.equal(out[:, n + 1], C0[:, n + 1])
+    # k = 0: an empty product — C = beta C (+ the epilogue), in both forms (the fast kernel pre-loaded operand
+    # panels before looking at k)
+    c0 = torch.from_numpy(rs.standard_normal((128, 256)).astype(np.float32)).to(DEV)
+    c = c0.clone()
+    ops.sgemm(torch.zeros((128, 0), device=DEV), torch.zeros((0, 256), device=DEV), out=c, beta=0.5)
+    np.testing.assert_allclose(c.cpu().numpy(), 0.5 * c0.cpu().numpy(), rtol=1e-6)
+    c = c0.clone()
+    ops.sgemm(torch.zeros((0, 128), device=DEV), torch.zeros((0, 256), device=DEV), trans_a=True, out=c, beta=0.5)
+    np.testing.assert_allclose(c.cpu().numpy(), 0.5 * c0.cpu().numpy(), rtol=1e-6)
     y = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
     dy = torch.from_numpy(rs.standard_normal((1001,)).astype(np.float32)).to(DEV)
     ref = torch.where(y > 0, dy, torch.zeros_like(dy))

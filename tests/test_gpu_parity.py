@@ -266,6 +266,31 @@ def test_march_on_oracle_volumes_matches_reference(name, precision):
     assert float(g["rgb_map"].max()) > 0.1, "fixture is degenerate"
 
 
+@pytest.mark.parametrize("precision", ["f16f6", "f16f6r", "f16f8"])
+def test_activations_beyond_fp16_range_saturate_instead_of_turning_into_nan(precision):
+    """the fp16 head of an activation is the one place where the f16 arithmetics have less range than fp32.  With
+    MODE.FP16_OVFL set by the kernels (nb_f6_ops.h) a layer output above 65504 saturates; without it it became inf, the
+    remainder inf - inf, and the pixel NaN.  fc_0 scaled by 3e5 puts h1 far beyond the range: the render must stay finite
+    (it is not accurate there: the product is formed from saturated heads)."""
+    r, sd, body, batch, cam, _ = scenes.build("small")
+    big = dict(sd)
+    big["fc_0.weight"] = (np.array(sd["fc_0.weight"]) * 3e5).astype(np.float32)
+    big["fc_0.bias"] = (np.array(sd["fc_0.bias"]) * 3e5).astype(np.float32)
+    bd = H.device_batch(batch, DEV)
+    outs = {}
+    for prec in (precision, "f32"):
+        net = H.make_network(big, DEV, True, prec)
+        with torch.no_grad():
+            outs[prec] = H.make_renderer(net, r).render(bd)
+    for k in ("rgb_map", "acc_map", "weights", "depth_map"):  # (disp_map is 0 / 0 = nan on empty rays in the reference itself,
+        v = outs[precision][k]                                  # nerf_net_utils.py:44, and WHICH rays are empty changes here)
+        assert torch.isfinite(v).all(), "%s: %s has %d non-finite values" % (precision, k, int((~torch.isfinite(v)).sum()))
+    assert torch.isfinite(outs["f32"]["rgb_map"]).all()
+    ref, got = outs["f32"]["rgb_map"][0], outs[precision]["rgb_map"][0]
+    print("%s with h1 ~ 1e5..1e7: rgb differs from fp32 by %.3g (max), %.3g (median)" % (
+        precision, float((got - ref).abs().max()), float((got - ref).abs().median())))
+
+
 def test_auto_precision_picks_six_bits_unless_the_weight_blocks_are_wide():
     """Network(precision='auto') = 'f16f6' for ordinary weights and 'f16f8' when a layer's (row, 32 K) blocks span a wide
     dynamic range (the statistic nb_mlp_pack_sections leaves behind the f16f6 stream, nb_mlp_six_bit_stats_offset)."""
