@@ -293,13 +293,15 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
  *   nb_enc_conv_pack16: weight dev [3,3,3,Cin,Cout] fp32 -> packed dev, 27*Cin*Cout*2 uint16 (MFMA B-fragment order)
  *   nb_enc_bn_relu_split: nb_enc_bn_relu whose activated rows leave as TWO fp16 planes in rows_split (dev, 2*n_rows_max*c
  *     uint16 = the bytes of an fp32 [n_rows_max, c] matrix: heads, then remainders); `rows` (the raw convolution output) is
- *     only read; dense as in nb_enc_bn_relu
+ *     only read; dense as in nb_enc_bn_relu; rows_out (dev or NULL): the activated rows in fp32 as well (the training
+ *     forward keeps them for nb_enc_bn_relu_bwd / nb_enc_conv_bwd_weight while the next convolution reads the planes)
  *   nb_enc_conv16: in_split = such a pair of planes with in_rows_cap rows each; everything else as nb_enc_conv */
 int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, void *stream);
 int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c,
                          const double *stats, const float *gamma, const float *beta,
                          float *running_mean, float *running_var, int training, float eps, float momentum,
-                         float *batch_stats, const int32_t *rows_lin, float *dense, uint16_t *rows_split, void *stream);
+                         float *batch_stats, const int32_t *rows_lin, float *dense, uint16_t *rows_split, float *rows_out,
+                         void *stream);
 int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *in_grid, const int32_t in_dhw[3],
                   const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3],
                   int32_t stride, const uint16_t *wpacked, int32_t cin, int32_t cout, float *out_rows, double *stats,

@@ -683,7 +683,8 @@ __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__
                                const float *__restrict__ beta, float *__restrict__ rmean,
                                float *__restrict__ rvar, int training, float eps, float momentum,
                                float *__restrict__ batch_stats, const int *__restrict__ rows_lin,
-                               float *__restrict__ dense, float *__restrict__ rows_out, long long split_plane) {
+                               float *__restrict__ dense, float *__restrict__ rows_out, _Float16 *__restrict__ split_out,
+                               long long split_plane) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = *n_rows;
     if (batch_stats && idx <= C) {
@@ -719,14 +720,13 @@ __global__ void bn_relu_kernel(float *__restrict__ rows, const int *__restrict__
     const float a = (float)(invstd * (double)gamma[c]);
     const float b = (float)((double)beta[c] - mean * invstd * (double)gamma[c]);
     const float y = fmaxf(fmaf(rows[idx], a, b), 0.f);
-    if (split_plane > 0) {  // for nb_enc_conv16: fp16 head and remainder planes in the bytes of an fp32 row matrix
-        _Float16 *sp = reinterpret_cast<_Float16 *>(rows_out);
+    if (split_out) {  // for nb_enc_conv16: fp16 head and remainder planes in the bytes of an fp32 row matrix
         const _Float16 h = (_Float16)y;
-        sp[idx] = h;
-        sp[split_plane + idx] = (_Float16)(y - (float)h);
-    } else {
-        (rows_out ? rows_out : rows)[idx] = y;  // training keeps the raw conv output for the backward pass
+        split_out[idx] = h;
+        split_out[split_plane + idx] = (_Float16)(y - (float)h);
     }
+    if (rows_out) rows_out[idx] = y;  // training keeps the raw conv output in `rows` for the backward pass
+    else if (!split_out) rows[idx] = y;
     if (dense) dense[(size_t)rows_lin[r] * C + c] = y;
 }
 
@@ -844,7 +844,7 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
     const long long threads = total > c + 1 ? total : c + 1;
     hipLaunchKernelGGL(bn_relu_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream, rows, n_rows,
                        c, stats, gamma, beta, running_mean, running_var, training, eps, momentum, batch_stats, rows_lin, dense, rows_out,
-                       0LL);
+                       (_Float16 *)nullptr, 0LL);
     NB_CHECK_LAUNCH("nb_enc_bn_relu");
     return NB_OK;
 }
@@ -852,7 +852,7 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
 int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c, const double *stats,
                          const float *gamma, const float *beta, float *running_mean, float *running_var, int training,
                          float eps, float momentum, float *batch_stats, const int32_t *rows_lin, float *dense,
-                         uint16_t *rows_split, void *stream) {
+                         uint16_t *rows_split, float *rows_out, void *stream) {
     NB_REQUIRE(rows && n_rows && gamma && beta && rows_split, "nb_enc_bn_relu_split: NULL pointer");
     NB_REQUIRE(training ? stats != nullptr : (running_mean && running_var), "nb_enc_bn_relu_split: statistics missing");
     NB_REQUIRE(!(training && momentum >= 0.f) || (running_mean && running_var && batch_stats),
@@ -863,7 +863,7 @@ int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_row
     const long long threads = total > c + 1 ? total : c + 1;
     hipLaunchKernelGGL(bn_relu_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                        const_cast<float *>(rows), n_rows, c, stats, gamma, beta, running_mean, running_var, training, eps, momentum,
-                       batch_stats, rows_lin, dense, reinterpret_cast<float *>(rows_split), total);
+                       batch_stats, rows_lin, dense, rows_out, reinterpret_cast<_Float16 *>(rows_split), total);
     NB_CHECK_LAUNCH("nb_enc_bn_relu_split");
     return NB_OK;
 }

@@ -90,12 +90,15 @@ class SparseConvNet(nn.Module):
             save.append({"rows_vert": rows_vert, "n_rows": n_rows, "n_max": n_max})
         volumes = []
         bn_updates = []
-        # Inference (no backward record): convolutions with >= 32 input channels run on the 16-bit matrix pipe with split
-        # operands (ops.enc_conv16, three products, fp32 accumulation); their input rows then arrive as fp16 head / remainder
-        # planes written by the producing BatchNorm kernel.  NB_ENC_SPLIT=0 keeps every layer on the exact-fp32 MFMA kernel.
-        fast = save is None and ENC_SPLIT
+        # Convolutions with >= 32 input channels run on the 16-bit matrix pipe with split operands (ops.enc_conv16, three
+        # products, fp32 accumulation: ~2^-21 relative per product); their input rows arrive as fp16 head / remainder planes
+        # written by the producing BatchNorm kernel, which in a training forward (save given) writes the fp32 activations
+        # next to them — the backward pass differentiates the exact-fp32 formulas on those.  NB_ENC_SPLIT=0 keeps every
+        # layer on the exact-fp32 MFMA kernel.
+        fast = ENC_SPLIT
         layers = [(name, cin, cout, n, stride, j) for name, cin, cout, n, stride in ENCODER_BLOCKS for j in range(n)]
         rows_are_split = False
+        rows_f32 = rows  # the fp32 form of the current layer's input rows (what the backward record keeps)
         stats_all = torch.zeros((len(layers), 256), dtype=torch.float64, device=dev)  # one fill for every layer's statistics
         for li, (name, cin, cout, n, stride, j) in enumerate(layers):
             block = getattr(self, name)
@@ -116,24 +119,26 @@ class SparseConvNet(nn.Module):
                 volumes.append(dense)
             next_split = fast and li + 1 < len(layers) and cout >= 32  # the consumer of these rows is an enc_conv16
             act = torch.empty_like(new_rows) if save is not None else None  # keep the raw conv output when saving
+            split = None
             if next_split:
-                new_rows, bstats = ops.enc_bn_relu_split(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
-                                                         bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
-                                                         momentum=bn.momentum if training else -1.0)
+                split, bstats = ops.enc_bn_relu_split(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
+                                                      bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
+                                                      momentum=bn.momentum if training else -1.0, rows_out=act)
             else:
                 bstats = ops.enc_bn_relu(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
                                          bn.running_mean, bn.running_var, training, bn.eps, out_lin, dense,
                                          momentum=bn.momentum if training else -1.0,  # running stats updated in-kernel
                                          rows_out=act)
             if save is not None:
-                save.append({"conv": conv, "bn": bn, "stride": stride, "in_rows": rows, "in_grid": grid, "in_dhw": dhw,
+                save.append({"conv": conv, "bn": bn, "stride": stride, "in_rows": rows_f32, "in_grid": grid, "in_dhw": dhw,
                              "in_lin": rows_lin, "n_in": n_rows, "n_in_max": n_max, "out_grid": out_grid,
                              "out_lin": out_lin, "n_out": n_out, "n_out_max": n_out_max, "out_dhw": out_dhw,
                              "x": new_rows, "y": act, "bstats": bstats, "level": len(volumes) - 1 if dense is not None else None})
-                new_rows = act
             if training:
                 bn_updates.append(bn.num_batches_tracked)
-            rows, grid, rows_lin, n_rows, n_max, dhw = new_rows, out_grid, out_lin, n_out, n_out_max, out_dhw
+            rows_f32 = act if save is not None else new_rows
+            rows = split if next_split else rows_f32
+            grid, rows_lin, n_rows, n_max, dhw = out_grid, out_lin, n_out, n_out_max, out_dhw
             rows_are_split = next_split
         if training:
             torch._foreach_add_(bn_updates, 1)  # nn.BatchNorm1d bookkeeping, one fused launch

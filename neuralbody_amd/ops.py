@@ -347,10 +347,13 @@ def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, st
 
 
 def enc_bn_relu_split(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, running_var, training, eps,
-                      rows_lin=None, dense=None, momentum=-1.0):
-    """nb_enc_bn_relu_split -> (rows_split int16 [2, n_rows_max, C], batch_stats)."""
+                      rows_lin=None, dense=None, momentum=-1.0, rows_out=None):
+    """nb_enc_bn_relu_split -> (rows_split int16 [2, n_rows_max, C], batch_stats); rows_out (fp32, same shape as rows):
+    receives the activated rows in fp32 as well (training forward)."""
     c = int(rows.shape[1])
     _req(rows, torch.float32, (None, c), "rows")
+    if rows_out is not None:
+        _req(rows_out, torch.float32, tuple(rows.shape), "rows_out")
     for t, nm in ((gamma, "gamma"), (beta, "beta"), (running_mean, "running_mean"), (running_var, "running_var")):
         _req(t, torch.float32, (c,), nm)
     if stats is not None:
@@ -366,7 +369,7 @@ def enc_bn_relu_split(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean
     check(_lib.lib().nb_enc_bn_relu_split(ptr(rows), ptr(n_rows), n_rows_max, c, ptr(stats), ptr(gamma), ptr(beta),
                                           ptr(running_mean), ptr(running_var), 1 if training else 0, float(eps),
                                           float(momentum), ptr(batch_stats), ptr(rows_lin), ptr(dense), ptr(split),
-                                          _stream()), "nb_enc_bn_relu_split")
+                                          ptr(rows_out), _stream()), "nb_enc_bn_relu_split")
     return split, batch_stats
 
 
