@@ -19,7 +19,8 @@ same without the rays whose last sample's density is within ILL_SIGMA of zero, w
 `--scaling strong` shards ONE view's rays over the ranks (parallel.render_sharded) instead of one view per rank.
 
 The JSON line also carries
-  roofline     — the dominant kernel (nb_march_ms6_kernel by default; --precision picks the others): algorithmic MLP
+  roofline     — the dominant kernel (nb_march_ms6_kernel or nb_march_f6_kernel by default: precision 'auto' times both
+                 organisations of the f16f6 arithmetic on the first view and keeps the faster one for this box; --precision picks the others): algorithmic MLP
                  flops (859 904 per ray-sample) / its average launch duration measured with HIP
                  events inside the timed region, against the dense MFMA peak of the arithmetic its main product runs on
                  (2.5 PFLOP/s for the fp16 / bf16 paths, 157.3 TFLOP/s for exact fp32); `executed_frac` = the MFMA work the
@@ -295,8 +296,8 @@ def extras(args, dev):
     # the record then holds a reference-precision number and an A/B of the kernels from ONE box
     from neuralbody_amd import ops
 
-    for prec in ("f32", "f16f6r", "bf16x3"):
-        if prec == (args.precision or "f16f6"):
+    for prec in ("f32", "f16f6", "f16f6r", "bf16x3"):  # (the default leg is one of the two f16f6 organisations: both are reported)
+        if prec == args.precision:
             continue
         sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, prec)
         with torch.no_grad():
@@ -429,7 +430,7 @@ def main():
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
-    tfile = {"bf16x3": "r01_march16_traffic.json", "f16f8": "r02_march_f16_traffic.json", "f16f6r": "r02_march_f6_traffic.json",
+    tfile = {"bf16x3": "r01_march16_traffic.json", "f16f8": "r02_march_f16_traffic.json", "f16f6r": "r03_march_f6_traffic.json",
              "f16f6": "r03_march_ms6_traffic.json"}.get(net.march_precision())
     tpath = os.path.join(ROOT, "profiles", tfile or "none")
     if tfile and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
@@ -478,6 +479,9 @@ def main():
     }
     if per_rank is not None:
         result["per_rank"] = per_rank
+    if getattr(net, "_auto_times", None):  # precision 'auto': what the first view measured for the two organisations (rank 0's box)
+        result["config"]["auto_organisation"] = {"chosen": net.march_precision(),
+                                                 "first_view_march_ms": {k: round(v, 3) for k, v in net._auto_times.items()}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         par = parity_check(sd, net, rend, poses[1], S)
         result["parity_linf"] = par["linf"]

@@ -34,6 +34,10 @@ BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
 DEFAULT_PRECISION = "auto"
 ENC_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # encoder convolutions with >= 32 input channels on the 16-bit matrix pipe
 SIX_BIT_MAX_SMALL = 0.5
+# precision 'auto': the first march of at least this many rays times both organisations of the f16f6 arithmetic (ring and
+# M-split kernel) on its own inputs and keeps the faster one for the life of the Network; NB_AUTO_TUNE=0 = always M-split
+AUTO_TUNE_MIN_RAYS = 1 << 17
+AUTO_TUNE = os.environ.get("NB_AUTO_TUNE", "1") != "0"
 
 
 class SparseConv3dParam(nn.Module):
@@ -159,6 +163,8 @@ class Network(nn.Module):
             raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'f16f6r', 'f16f8' or 'f16f6'")
         self._auto = None  # (weight key, chosen arithmetic) of precision 'auto'
         self._lb_cache = None  # (latent_index tensor, versions, bias) of latent_bias()
+        self._auto_org = None  # 'f16f6' / 'f16f6r': the measured choice of precision 'auto' (None: not measured yet)
+        self._auto_times = None  # {organisation: ms} of that measurement
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -182,7 +188,7 @@ class Network(nn.Module):
     # the packed blobs and their keys (storages!) are caches of the parameters: they are neither copied nor pickled
     def __getstate__(self):
         st = dict(self.__dict__)
-        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None)
+        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None, _auto_org=None)
         return st
 
     def __deepcopy__(self, memo):
@@ -218,9 +224,10 @@ class Network(nn.Module):
         return "bf16x3"
 
     def march_precision(self):
-        """Arithmetic of the fused march.  'auto' = 'f16f6' (cross terms in six bits on the M-split kernel: within 3 % of the
-        ring kernel 'f16f6r' on the fastest boxes of the pool and 10 % ahead of it on the slow-memory ones, among them the
-        driver's bench box — profiles/r03_march_kernels.md) unless the weights have
+        """Arithmetic of the fused march.  'auto' = the f16f6 arithmetic (cross terms in six bits) on whichever of its two
+        organisations is faster HERE — 'f16f6' (M-split kernel) until the first march of >= AUTO_TUNE_MIN_RAYS rays has timed
+        both (render_rays; the ring kernel 'f16f6r' is 2-3 % faster on the fast boxes of the pool, the M-split kernel 10 % on
+        the slow-memory ones: profiles/r03_march_kernels.md) — unless the weights have
         blocks fp6 cannot hold: more than SIX_BIT_MAX_SMALL of a layer's non-zero weights below 1/8 of their block maximum
         (normally distributed weights: ~0.2; the wide-dynamic-range stress case of tools/experiments/precision_sweep.py:
         ~0.75, where six-bit weights triple the error) — then 'f16f8'.  Decided once per weight version (one 5-float
@@ -231,6 +238,8 @@ class Network(nn.Module):
         if self._auto is None or self._auto[0] is not self._packed_key:
             worst = float(ops.six_bit_small_fraction(packed).max())
             self._auto = (self._packed_key, "f16f6" if worst <= SIX_BIT_MAX_SMALL else "f16f8", worst)
+        if self._auto[1] == "f16f6" and self._auto_org is not None:
+            return self._auto_org
         return self._auto[1]
 
     def packed_weights(self, precision=None):
@@ -345,6 +354,33 @@ class Network(nn.Module):
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._t_vals[key] = t_vals
         prec = self.march_precision()
+        if (self.precision == "auto" and prec == "f16f6" and self._auto_org is None and AUTO_TUNE and cull is None
+                and ray_o.shape[0] >= AUTO_TUNE_MIN_RAYS):
+            prec = self._auto_org = self._time_organisations(scene, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd,
+                                                             ray_order)
         return ops.march(scene, self.packed_weights(prec), lb, ray_o, ray_d, near, far, t_vals, t_rand,
                          white_bkgd=white_bkgd, want_raw=want_raw, precision=prec, ray_order=ray_order,
                          cull=cull)
+
+    def _time_organisations(self, scene, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd, ray_order):
+        """One warm and two timed launches of each organisation of the f16f6 arithmetic on the caller's own rays (HIP events on
+        the current stream, one host wait: ~0.1 s, once per Network).  Both compute the same arithmetic with a different
+        summation order (parity tests run both); which one is faster is a property of the box."""
+        packed = self.packed_weights("f16f6")  # holds both weight streams
+        saved, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None  # bench.py's per-launch events: not these
+        times = {}
+        try:
+            for org in ("f16f6", "f16f6r"):
+                kw = dict(white_bkgd=white_bkgd, precision=org, ray_order=ray_order)
+                ops.march(scene, packed, lb, ray_o, ray_d, near, far, t_vals, t_rand, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(2):
+                    ops.march(scene, packed, lb, ray_o, ray_d, near, far, t_vals, t_rand, **kw)
+                e1.record()
+                e1.synchronize()
+                times[org] = e0.elapsed_time(e1) / 2
+        finally:
+            ops.MARCH_EVENTS = saved
+        self._auto_times = times
+        return min(times, key=times.get)

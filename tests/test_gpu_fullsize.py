@@ -92,3 +92,29 @@ def test_full_size_encoder_matrix_pipe_kernels_match_the_fp32_kernels(monkeypatc
         assert err <= 2e-5 * scale, (lvl, err, scale)
         assert a.dim() == 5 and a.shape[0] == 1  # [1, C, D, H, W]
         assert torch.equal(a.abs().sum(1) > 0, b.abs().sum(1) > 0)  # the same active voxels
+
+
+def test_auto_times_both_organisations_once_and_keeps_the_faster():
+    """precision='auto': the first full-size march times the ring and the M-split kernel of the f16f6 arithmetic on its own
+    rays and the Network keeps the faster one (network.AUTO_TUNE_MIN_RAYS); the render of that call and of every later one is
+    the chosen kernel's, bit for bit."""
+    dev = torch.device(DEV)
+    sd, body, net, rend, bd, n = bench.build_scene(dev, 512, 512, 64, None)
+    assert net.precision == "auto" and net.march_precision() == "f16f6" and net._auto_org is None
+    with torch.no_grad():
+        first = rend.render(bd)["rgb_map"].clone()
+        org = net._auto_org
+        assert org in ("f16f6", "f16f6r") and net.march_precision() == org
+        print("measured: %s -> %s" % ({k: round(v, 2) for k, v in net._auto_times.items()}, org))
+        assert min(net._auto_times.values()) == net._auto_times[org]
+        again = rend.render(bd)["rgb_map"]
+        assert net._auto_org == org
+        sd2, body2, net2, rend2, bd2, _ = bench.build_scene(dev, 512, 512, 64, org)
+        explicit = rend2.render(bd2)["rgb_map"]
+    assert torch.equal(first, again)
+    assert float((first - explicit).abs().max()) <= 1e-6  # (another Network object: its encoder sums BatchNorm statistics with atomics)
+    # small marches (training batches, the fixtures) never trigger the measurement
+    sd3, body3, net3, rend3, bd3, _ = bench.build_scene(dev, 64, 64, 8, None)
+    with torch.no_grad():
+        rend3.render(bd3)
+    assert net3._auto_org is None and net3.march_precision() == "f16f6"
