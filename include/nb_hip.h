@@ -227,9 +227,12 @@ int nb_colsum(const float *x, int64_t n_rows, int32_t n_cols, int32_t ld, float 
 
 /* Backward of the 4-level trilinear lookup (F.grid_sample, latent_xyzc.py:62-72) restricted to the
  * ACTIVE voxels: d_feat dev [n,352] -> drows[l] dev [n_rows_l, C_l] (+=, atomics; zero them first),
- * grids[l] dev = index grid of level l (row id or -1).  scene->vol[] is not read. */
+ * grids[l] dev = index grid of level l (row id or -1).  scene->vol[] is not read.
+ * run_length >= 1: consecutive points [k run_length, (k+1) run_length) are the samples of ONE ray in depth order (the training
+ * step: N_samples); contributions to the same base voxel are summed along such a run before they are added atomically (the
+ * result is the same sum in another order).  1 = every point on its own. */
 int nb_trilinear_bwd(const nb_scene *scene, const int32_t *const grids[4], float *const drows[4],
-                     const float *wpts, const float *d_feat, int64_t n, void *stream);
+                     const float *wpts, const float *d_feat, int64_t n, int32_t run_length, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * Structured-latent-code encoder — replaces Network.encode_sparse_voxels

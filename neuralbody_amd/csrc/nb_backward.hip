@@ -99,39 +99,67 @@ struct TriArgs {
     const float *wpts;        // [n,3]
     const float *dF;          // [n,352]
     long long n;
+    int run;                  // consecutive points [k run, (k+1) run) are the samples of one ray
 };
 
+// One thread per (ray, 4-channel group): 88 groups = 8 + 16 + 32 + 32, walking the ray's `run` samples.  Consecutive samples
+// of a ray mostly share their base voxel on the coarse levels (sample spacing ~1.5 cm against 4 and 8 cm voxels), so the
+// eight corner contributions are summed in registers and leave as atomics only when the base voxel changes: round 2 issued one
+// atomic per (sample, channel, corner) — 184 M per training step, with hundreds of them contending for each coarse voxel.
 __global__ void trilinear_bwd_kernel(TriArgs a) {
-    // one thread per (point, 4-channel group): 88 groups = 8 + 16 + 32 + 32
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long pt = t / 88;
-    if (pt >= a.n) return;
+    const long long ray = t / 88;
+    const long long p0 = ray * a.run;
+    if (p0 >= a.n) return;
     const int g = (int)(t % 88);
     const int L = g < 8 ? 0 : (g < 24 ? 1 : (g < 56 ? 2 : 3));
     const int q = g - (L == 0 ? 0 : (L == 1 ? 8 : (L == 2 ? 24 : 56)));
     const int C = lvl_c(L);
-    const GridCoord gc = grid_coords(a.sc, a.wpts[pt * 3], a.wpts[pt * 3 + 1], a.wpts[pt * 3 + 2]);
     const int D = a.sc.dhw[L][0], H = a.sc.dhw[L][1], W = a.sc.dhw[L][2];
-    const float ix = unnorm_clamped(gc.gw, W), iy = unnorm_clamped(gc.gh, H), iz = unnorm_clamped(gc.gd, D);
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    const float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
-    const f32x4 d = *reinterpret_cast<const f32x4 *>(a.dF + pt * 352 + lvl_chan_base(L) + q * 4);
-    if (d.x == 0.f && d.y == 0.f && d.z == 0.f && d.w == 0.f) return;
+    const long long p1 = p0 + a.run < a.n ? p0 + a.run : a.n;
+    int bx = 0x7fffffff, by = 0, bz = 0;  // base voxel of the contributions held in acc
+    f32x4 acc[8];
+    auto flush = [&]() {
+        if (bx == 0x7fffffff) return;
 #pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
-        if ((unsigned)xx >= (unsigned)W || (unsigned)yy >= (unsigned)H || (unsigned)zz >= (unsigned)D) continue;
-        const int row = a.grid[L][((long long)zz * H + yy) * W + xx];
-        if (row < 0) continue;  // inactive voxel: a constant zero of .dense(), no parameter behind it
-        const float w = (wx[dx] * wy[dy]) * wz[dz];
-        float *dst = a.drows[L] + (size_t)row * C + q * 4;
-        atomicAdd(dst + 0, w * d.x);
-        atomicAdd(dst + 1, w * d.y);
-        atomicAdd(dst + 2, w * d.z);
-        atomicAdd(dst + 3, w * d.w);
+        for (int corner = 0; corner < 8; ++corner) {
+            const int xx = bx + (corner & 1), yy = by + ((corner >> 1) & 1), zz = bz + (corner >> 2);
+            if ((unsigned)xx >= (unsigned)W || (unsigned)yy >= (unsigned)H || (unsigned)zz >= (unsigned)D) continue;
+            const int row = a.grid[L][((long long)zz * H + yy) * W + xx];
+            if (row < 0) continue;  // inactive voxel: a constant zero of .dense(), no parameter behind it
+            const f32x4 v = acc[corner];
+            if (v.x == 0.f && v.y == 0.f && v.z == 0.f && v.w == 0.f) continue;
+            float *dst = a.drows[L] + (size_t)row * C + q * 4;
+            atomicAdd(dst + 0, v.x);
+            atomicAdd(dst + 1, v.y);
+            atomicAdd(dst + 2, v.z);
+            atomicAdd(dst + 3, v.w);
+        }
+    };
+    for (long long pt = p0; pt < p1; ++pt) {
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(a.dF + pt * 352 + lvl_chan_base(L) + q * 4);
+        if (d.x == 0.f && d.y == 0.f && d.z == 0.f && d.w == 0.f) continue;
+        const GridCoord gc = grid_coords(a.sc, a.wpts[pt * 3], a.wpts[pt * 3 + 1], a.wpts[pt * 3 + 2]);
+        const float ix = unnorm_clamped(gc.gw, W), iy = unnorm_clamped(gc.gh, H), iz = unnorm_clamped(gc.gd, D);
+        const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+        const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
+        if (x0 != bx || y0 != by || z0 != bz) {
+            flush();
+            bx = x0, by = y0, bz = z0;
+#pragma unroll
+            for (int corner = 0; corner < 8; ++corner) acc[corner] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float wx[2] = {(fx + 1.f) - ix, ix - fx}, wy[2] = {(fy + 1.f) - iy, iy - fy}, wz[2] = {(fz + 1.f) - iz, iz - fz};
+#pragma unroll
+        for (int corner = 0; corner < 8; ++corner) {
+            const float w = (wx[corner & 1] * wy[(corner >> 1) & 1]) * wz[corner >> 2];
+            acc[corner].x = fmaf(w, d.x, acc[corner].x);
+            acc[corner].y = fmaf(w, d.y, acc[corner].y);
+            acc[corner].z = fmaf(w, d.z, acc[corner].z);
+            acc[corner].w = fmaf(w, d.w, acc[corner].w);
+        }
     }
+    flush();
 }
 
 // ------------------------------------------------------------------ C[m,n] += A^T B over many rows (weight gradients)
@@ -449,8 +477,8 @@ int nb_colsum(const float *x, int64_t n_rows, int32_t n_cols, int32_t ld, float 
 }
 
 int nb_trilinear_bwd(const nb_scene *scene, const int32_t *const grids[4], float *const drows[4], const float *wpts,
-                     const float *d_feat, int64_t n, void *stream) {
-    NB_REQUIRE(scene && grids && drows && n >= 0, "nb_trilinear_bwd: bad argument");
+                     const float *d_feat, int64_t n, int32_t run_length, void *stream) {
+    NB_REQUIRE(scene && grids && drows && n >= 0 && run_length >= 1, "nb_trilinear_bwd: bad argument");
     if (n == 0) return NB_OK;
     NB_REQUIRE(wpts && d_feat, "nb_trilinear_bwd: NULL pointer");
     TriArgs a = {};
@@ -465,7 +493,9 @@ int nb_trilinear_bwd(const nb_scene *scene, const int32_t *const grids[4], float
     a.wpts = wpts;
     a.dF = d_feat;
     a.n = n;
-    hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(nb_ceil_div(n * 88, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    a.run = run_length;
+    hipLaunchKernelGGL(trilinear_bwd_kernel, dim3(nb_ceil_div(nb_ceil_div(n, run_length) * 88, 256)), dim3(256), 0,
+                       (hipStream_t)stream, a);
     NB_CHECK_LAUNCH("trilinear_bwd_kernel");
     return NB_OK;
 }

@@ -517,8 +517,9 @@ def colsum(x, out=None):
     return out
 
 
-def trilinear_bwd(scene, grids, drows, wpts, d_feat):
-    """nb_trilinear_bwd: d_feat [n,352] -> drows[l] += gradient of the active rows of level l."""
+def trilinear_bwd(scene, grids, drows, wpts, d_feat, run_length=1):
+    """nb_trilinear_bwd: d_feat [n,352] -> drows[l] += gradient of the active rows of level l.  run_length: the points come as
+    runs of that many consecutive samples of one ray (contributions to one voxel are pre-summed along a run)."""
     sc, _keep = scene
     _req(wpts, torch.float32, (None, 3), "wpts")
     n = wpts.shape[0]
@@ -530,7 +531,8 @@ def trilinear_bwd(scene, grids, drows, wpts, d_feat):
         _req(drows[l], torch.float32, (None, LEVEL_CHANNELS[l]), "drows[%d]" % l)
         g4[l] = grids[l].data_ptr()
         d4[l] = drows[l].data_ptr()
-    check(_lib.lib().nb_trilinear_bwd(C.byref(sc), g4, d4, ptr(wpts), ptr(d_feat), n, _stream()), "nb_trilinear_bwd")
+    check(_lib.lib().nb_trilinear_bwd(C.byref(sc), g4, d4, ptr(wpts), ptr(d_feat), n, int(run_length), _stream()),
+          "nb_trilinear_bwd")
     return drows
 
 

@@ -175,7 +175,7 @@ class RenderFunction(torch.autograd.Function):
         grids = [rec["out_grid"] for rec in dense]
         drows = [torch.zeros((rec["n_out_max"] if rec["n_out_max"] > 0 else 1, rec["y"].shape[1]), dtype=torch.float32,
                              device=w.device) for rec in dense]
-        ops.trilinear_bwd(ctx.scene, grids, drows, w, dF)
+        ops.trilinear_bwd(ctx.scene, grids, drows, w, dF, run_length=S)  # w: [rays x S, 3], a ray's samples consecutive
         ge, dcodes = encoder_backward(net.xyzc_net, ctx.enc_ctx, drows)
         g.update(ge)
         g["c.weight"] = dcodes

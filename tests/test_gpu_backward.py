@@ -193,6 +193,13 @@ def test_decoder_backward_matches_autograd():
         ref = x.grad[0].permute(1, 2, 3, 0)[act].numpy()  # [n_active, C], linear voxel order == row order
         _rel(drows[l].cpu().numpy(), ref, 1e-4, "grad of active voxels, level %d" % l)
         assert np.abs(ref).max() > 0
+    # the same sum with the contributions of consecutive points pre-summed per voxel (the training step passes N_samples;
+    # any run length, ragged tail included, must give the same gradients)
+    for run in (S, 7):
+        drows2 = [torch.zeros_like(d) for d in drows]
+        ops.trilinear_bwd(scene, grids, drows2, wd, dF, run_length=run)
+        for l in range(4):
+            _rel(drows2[l].cpu().numpy(), drows[l].cpu().numpy(), 2e-5, "run_length %d, level %d" % (run, l))
 
 
 def test_encoder_backward_matches_autograd():
