@@ -716,6 +716,15 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 #else
 #define MS6_STAMP(i) do { } while (0)
 #endif
+// stamps 26..31 are sub-stamps of ONE segment: -DMS6_TIMING=1 (or empty) the second gather, -DMS6_TIMING=2 the preparation of the
+// next depth step behind the folded view layer
+#if defined(MS6_TIMING) && (MS6_TIMING + 0) == 2
+#define MS6_SUBA(i) do { } while (0)
+#define MS6_SUBB(i) MS6_STAMP(i)
+#else
+#define MS6_SUBA(i) MS6_STAMP(i)
+#define MS6_SUBB(i) do { } while (0)
+#endif
 // MS6_TAP (debug builds): workgroup 0 dumps, at depth step 0, every layer's accumulators as [layer][feature][sample]
 // fp32 into a.raw instead of the raw output (fc_0, fc_1, fc_2 pre-activation: 3 x 256 x 64; folded view layer: 128 x 64) —
 // tools/experiments/ms6_tap_check.py compares them with nb_decode_points' fp32 activation tap
@@ -851,7 +860,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
             __syncthreads();
             MS6_STAMP(4);
             tile_wait();
-            MS6_STAMP(26);
+            MS6_SUBA(26);
             gather_parts<2, TILE_BYTES>(a.sc, g, b2, part, tile, [&](int grp8, const float (&o)[8]) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[8 * grp8 + e] = o[e];
@@ -859,21 +868,21 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
 #ifdef MS6_TIMING
             asm volatile("" : "+v"(v[0]), "+v"(v[8]), "+v"(v[16]), "+v"(v[24]), "+v"(v[31]));
 #endif
-            MS6_STAMP(27);
+            MS6_SUBA(27);
             const VoxBox b0 = vox_box<0>(a.sc, wb), b1 = vox_box<1>(a.sc, wb);
-            MS6_STAMP(28);
+            MS6_SUBA(28);
             {
                 HalfBlock hb = convert_halfblock<false>([&](int q) { return v[q]; });
 #ifdef MS6_TIMING
                 asm volatile("" : "+v"(hb.xl), "+v"(hb.xx));
 #endif
-                MS6_STAMP(29);
+                MS6_SUBA(29);
                 tile_dma<0, TILE_L0>(a.sc, b0, lane_i, lds_tile);
                 tile_dma<1, TILE_BYTES - TILE_L0>(a.sc, b1, lane_i, lds_tile + TILE_L0);
-                MS6_STAMP(30);
+                MS6_SUBA(30);
                 store_halfblock(actz, part >> 1, part & 1, sn, ss, hb);
             }
-            MS6_STAMP(31);
+            MS6_SUBA(31);
             ring_prime<P_B>(wl, ring);
             MS6_STAMP(5);
             __syncthreads();
@@ -1012,14 +1021,30 @@ __global__ __launch_bounds__(256, 2) void nb_march_ms6_kernel(MarchArgs a, const
         // step's level-3 tile now (in flight under the encodings, the last MFMA phase, the heads and the compositing)
         const f32x4 ro = rec[0], rd = rec[1];  // ox oy oz near | dx dy dz far
         z_next = (s + 1 < S) ? z_at(s + 1, ro.w, rd.w) : 0.f;
+#if defined(MS6_TIMING) && (MS6_TIMING + 0) == 2
+        asm volatile("" : "+v"(z_next));
+#endif
+        MS6_SUBB(26);
         if constexpr (!POINTS) {
             const float nx_ = __fadd_rn(ro.x, __fmul_rn(rd.x, z_next)), ny_ = __fadd_rn(ro.y, __fmul_rn(rd.y, z_next)),
                         nz_ = __fadd_rn(ro.z, __fmul_rn(rd.z, z_next));
             g = grid_coords(a.sc, nx_, ny_, nz_);
+#if defined(MS6_TIMING) && (MS6_TIMING + 0) == 2
+            asm volatile("" : "+v"(g.gw), "+v"(g.gh), "+v"(g.gd));
+#endif
+            MS6_SUBB(27);
             wb = wave_box16(g);
-            tile_dma<3, TILE_BYTES>(a.sc, vox_box<3>(a.sc, wb), lane_i, lds_tile);
+#if defined(MS6_TIMING) && (MS6_TIMING + 0) == 2
+            asm volatile("" : "+v"(wb.lo.gw), "+v"(wb.hi.gd));
+#endif
+            MS6_SUBB(28);
+            const VoxBox nb3 = vox_box<3>(a.sc, wb);
+            MS6_SUBB(29);
+            tile_dma<3, TILE_BYTES>(a.sc, nb3, lane_i, lds_tile);
         }
+        MS6_SUBB(30);
         ring_prime<P_VP>(wl, ring);  // behind the DMA (vmcnt retires in order), ahead of the encodings that cover its latency
+        MS6_SUBB(31);
         store_halfblock(actz, part >> 1, part & 1, sn, ss, peh);  // the encodings converted behind fc_1
         MS6_STAMP(20);
         __syncthreads();

@@ -37,6 +37,12 @@ for i, nm in enumerate(NAMES):
 print("| stamped part of a depth step | %.0f | |" % tot)
 print("| step to step | %.0f | |" % step.mean())
 x = out["raw"].view(torch.int32).reshape(-1)[:32 * 64 * 32].cpu().numpy().astype(np.int64).reshape(32, 64, 32)[:, 2:-1]
+if os.environ.get("MS6_SUB", "A") == "B":  # library built with -DMS6_TIMING=2
+    sub = [("ray record + next z", 19, 26), ("grid coordinates", 26, 27), ("wave box (DPP reductions)", 27, 28), ("voxel box", 28, 29),
+           ("issue the level-3 DMA", 29, 30), ("ring prime", 30, 31), ("store the encodings' operands", 31, 20)]
+    print("inside 'encodings + convert' (= preparation of the next depth step):",
+          ", ".join("%s %.0f" % (nm, ((x[:, :, e] - x[:, :, b]) & 0xffffffff).mean()) for nm, b, e in sub))
+    sys.exit(0)
 sub = [("tile wait", 4, 26), ("blend level 2", 26, 27), ("boxes of levels 0, 1", 27, 28), ("convert", 28, 29), ("issue the DMAs", 29, 30),
        ("store operands", 30, 31), ("ring prime", 31, 5)]
 print("inside 'gather L2 + convert + prime':", ", ".join("%s %.0f" % (nm, ((x[:, :, e] - x[:, :, b]) & 0xffffffff).mean()) for nm, b, e in sub))
