@@ -270,6 +270,7 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
  *   by the call unless flags has NB_CONV_STATS_ZEROED: the caller cleared it, e.g. one memset for the statistics of all
  *   17 layers instead of one launch per layer). */
 #define NB_CONV_STATS_ZEROED 1
+#define NB_CONV_BF16 2 /* nb_enc_conv16 only: the split operands are bf16 pairs (nb_enc_conv_pack16 mode 1, nb_enc_bn_relu_bwd dx_split) */
 int nb_enc_conv(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3],
                 const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max,
                 const int32_t out_dhw[3], int32_t stride, const float *weight, int32_t cin,
@@ -293,13 +294,18 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
 /* ---- the same convolution on the 16-bit matrix pipe (inference: no backward record) ----
  * Operands as fp16 head + fp16 remainder, three products per K chunk on v_mfma_f32_32x32x16_f16 with fp32 accumulation
  * (~2^-21 relative per product), 1.3-1.9x faster than nb_enc_conv.  cin in {32, 64, 128}, cout in {32, 64, 128}.
- *   nb_enc_conv_pack16: weight dev [3,3,3,Cin,Cout] fp32 -> packed dev, 27*Cin*Cout*2 uint16 (MFMA B-fragment order)
+ *   nb_enc_conv_pack16: weight dev [3,3,3,Cin,Cout] fp32 -> packed dev, 27*Cin*Cout*2 uint16 (MFMA B-fragment order).
+ *     mode 0: the forward convolution, fp16 pairs.  mode 1: the BACKWARD-INPUT convolution of a stride-1 layer as a
+ *     convolution of its own (d in[q] = sum_o d out[q + o - 1] . W[26 - o]^T: mirrored offsets, transposed slabs), bf16 pairs
+ *     (gradients span more binades than an un-scaled fp16 head holds): `cin`, `cout` are those of the packed convolution =
+ *     the layer's Cout, Cin; `weight` is the layer's weight [3,3,3,cout,cin].  Run it with nb_enc_conv16(flags = NB_CONV_BF16)
+ *     on the bf16 planes nb_enc_bn_relu_bwd writes (dx_split), in_grid = the layer's output grid, out_lin = its input rows.
  *   nb_enc_bn_relu_split: nb_enc_bn_relu whose activated rows leave as TWO fp16 planes in rows_split (dev, 2*n_rows_max*c
  *     uint16 = the bytes of an fp32 [n_rows_max, c] matrix: heads, then remainders); `rows` (the raw convolution output) is
  *     only read; dense as in nb_enc_bn_relu; rows_out (dev or NULL): the activated rows in fp32 as well (the training
  *     forward keeps them for nb_enc_bn_relu_bwd / nb_enc_conv_bwd_weight while the next convolution reads the planes)
  *   nb_enc_conv16: in_split = such a pair of planes with in_rows_cap rows each; everything else as nb_enc_conv */
-int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, void *stream);
+int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, int32_t mode, void *stream);
 int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c,
                          const double *stats, const float *gamma, const float *beta,
                          float *running_mean, float *running_var, int training, float eps, float momentum,
@@ -314,10 +320,11 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
 
 /* BatchNorm1d (batch statistics) + ReLU backward.  dy, y (activated rows), x (raw conv output) dev
  * [n_rows, c]; batch_stats dev [2c+1] as written by nb_enc_bn_relu; sums dev [2c] fp64 scratch.
- * Outputs: dx dev [n_rows, c] (may alias dy), dgamma / dbeta dev [c]. */
+ * Outputs: dx dev [n_rows, c] (may alias dy), dgamma / dbeta dev [c]; dx_split (dev or NULL): dx once more as two bf16
+ * planes [2, n_rows_max, c] (heads | remainders) for the backward-input convolution on the matrix pipe. */
 int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const int32_t *n_rows,
                        int32_t n_rows_max, int32_t c, const float *batch_stats, float eps, const float *gamma,
-                       double *sums, float *dx, float *dgamma, float *dbeta, void *stream);
+                       double *sums, float *dx, float *dgamma, float *dbeta, uint16_t *dx_split, void *stream);
 
 /* Gradient of the conv INPUT rows: din[q] = sum_o dx[r(q,o)] @ W[o]^T, where r(q,o) is the output row that
  * read input voxel q under kernel offset o.  out_grid = index grid of the OUTPUT tensor, in_lin = linear voxel

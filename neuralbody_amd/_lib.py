@@ -72,10 +72,10 @@ SIGNATURES = {
     "nb_enc_downsample_index": (C.c_int, [_P, _P, _I32, _I32x3, _I32x3, _P, _P, _P, _I32, _P, _P]),
     "nb_enc_conv": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _I32, _P]),
     "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
-    "nb_enc_conv_pack16": (C.c_int, [_P, _I32, _I32, _P, _P]),
+    "nb_enc_conv_pack16": (C.c_int, [_P, _I32, _I32, _P, _I32, _P]),
     "nb_enc_bn_relu_split": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "nb_enc_conv16": (C.c_int, [_P, _I32, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _I32, _P]),
-    "nb_enc_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, C.c_float, _P, _P, _P, _P, _P, _P]),
+    "nb_enc_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "nb_enc_conv_bwd_input": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P]),
     "nb_enc_conv_bwd_weight": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _P]),
     "nb_enc_scatter_codes_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),

@@ -198,9 +198,22 @@ __global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_
 // [offset][K chunk][channel tile][head, remainder][lane] x 8 fp16.
 typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));  // (the name predates the switch to fp16)
 typedef _Float16 nb_h16;
-#define NB_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+// BF: the operands are bf16 head / remainder pairs (the backward-input convolution: gradients span more binades than an
+// un-scaled fp16 head holds; a bf16 pair carries 16 mantissa bits, ~2^-16 relative per product) instead of fp16 pairs
+typedef __bf16 nb_bf16x8 __attribute__((ext_vector_type(8)));
+template <bool BF>
+__device__ __forceinline__ f32x16 nb_mfma16(const bf16x8 a, const bf16x8 b, const f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(nb_bf16x8, a), __builtin_bit_cast(nb_bf16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+#define NB_MFMA16(a, b, c) nb_mfma16<BF>((a), (b), (c))
 
-__global__ void conv_pack16_kernel(const float *__restrict__ w, int cin, int cout, bf16x8 *__restrict__ out) {
+// mode 0: the forward weight [27][cin][cout] as fp16 pairs.  mode 1: the weight of the BACKWARD-INPUT convolution of a stride-1
+// layer — dIn[q] = sum_o dOut[q + (o' - 1)] . W[26 - o']^T, i.e. the same kernels on the mirrored offsets and the transposed
+// slabs — as bf16 pairs: cin / cout are those of the packed convolution (= the layer's cout / cin), w is the layer's weight
+__global__ void conv_pack16_kernel(const float *__restrict__ w, int cin, int cout, bf16x8 *__restrict__ out, int mode) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // (((o * NC + c) * NTT + t) * 2 + part) * 64 + lane
     const int nc = cin / 16, ntt = cout / 32;
     if (idx >= (long long)27 * nc * ntt * 2 * 64) return;
@@ -211,15 +224,23 @@ __global__ void conv_pack16_kernel(const float *__restrict__ w, int cin, int cou
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float x = w[((size_t)o * cin + 16 * c + 8 * hi + e) * cout + 32 * t + j];
-        const nb_h16 h = (nb_h16)x;
-        v[e] = part ? (nb_h16)(x - (float)h) : h;
+        const int k = 16 * c + 8 * hi + e, n = 32 * t + j;  // input channel, output channel of the packed convolution
+        if (mode == 0) {
+            const float x = w[((size_t)o * cin + k) * cout + n];
+            const nb_h16 h = (nb_h16)x;
+            v[e] = part ? (nb_h16)(x - (float)h) : h;
+        } else {
+            const float x = w[((size_t)(26 - o) * cout + n) * cin + k];
+            const __bf16 h = (__bf16)x;
+            const __bf16 r = part ? (__bf16)(x - (float)h) : h;
+            v[e] = __builtin_bit_cast(nb_h16, r);
+        }
     }
     out[idx] = v;
 }
 
 // one wave = 32 output rows x NT tiles of 32 output channels (blockIdx.y selects the tile group)
-template <int CIN, int COUT, int NT>
+template <int CIN, int COUT, int NT, bool BF = false>
 __global__ __launch_bounds__(256) void conv16_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
                                                      const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
                                                      const int *__restrict__ n_out, Dims go, int stride,
@@ -320,7 +341,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const unsigned short *__res
 typedef const void __attribute__((address_space(1))) *nb_gptr_t;
 typedef void __attribute__((address_space(3))) *nb_lptr_t;
 
-template <int CIN, int COUT, int NT>
+template <int CIN, int COUT, int NT, bool BF = false>
 __global__ __launch_bounds__(256) void conv16_lds_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
                                                          const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
                                                          const int *__restrict__ n_out, Dims go, int stride,
@@ -439,7 +460,7 @@ __global__ __launch_bounds__(256) void conv16_lds_kernel(const unsigned short *_
 // order).  The mid levels of the SMPL grid (10-29 k rows) give 150-230 workgroups of the kernel above — less than one per
 // CU, one wave per SIMD — and each walks 27 offsets at 2.5-3.7 us apiece for 0.7 us of MFMA work: halving the chain halves
 // the launch, and the second wave per SIMD fills the first one's waits.
-template <int CIN, int COUT, int NT>
+template <int CIN, int COUT, int NT, bool BF = false>
 __global__ __launch_bounds__(512) void conv16_lds2_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
                                                           const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
                                                           const int *__restrict__ n_out, Dims go, int stride,
@@ -572,7 +593,7 @@ __global__ __launch_bounds__(512) void conv16_lds2_kernel(const unsigned short *
 // ~20 us of MFMA work per wave (profiles/r03_step_timeline.md).  Here the serial chain is ceil(27 / NW) offsets long and the
 // operands of offset k + 1 are re-loaded into the registers offset k has just consumed (rows and weight fragments, chunk by
 // chunk), so every load has a full offset of MFMAs to land.
-template <int CIN, int COUT, int NW>
+template <int CIN, int COUT, int NW, bool BF = false>
 __global__ __launch_bounds__(64 * NW) void conv16_ks_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
                                                            const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
                                                            const int *__restrict__ n_out, Dims go, int stride,
@@ -748,6 +769,77 @@ void launch_conv(int n_out_max, hipStream_t st, const float *in_rows, const int 
 
 }  // namespace
 
+template <bool BF>
+static int conv16_dispatch(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *in_grid, Dims gi, const int32_t *out_lin,
+                           const int32_t *n_out, int32_t n_out_max, Dims go, int32_t stride, const uint16_t *wpacked, int32_t cin,
+                           int32_t cout, float *out_rows, double *stats, hipStream_t st) {
+    const long long plane = (long long)in_rows_cap * cin;
+    const int row_groups = (int)nb_ceil_div(n_out_max, 128);
+    // small levels (the deepest one of the SMPL grid: ~1.6 k rows): the launch is a handful of workgroups whichever way it is
+    // tiled, so the chain of dependent L2 round trips per workgroup is what counts — offsets split over 8 waves (24 us instead
+    // of 67-98 us per 128-channel layer); larger levels are L2-bandwidth-bound under that tiling (weights per 32 rows)
+    if (n_out_max <= 4096) {
+#define NB_CONV16_KS_CASE(CI, CO)                                                                                           \
+    if (cin == CI && cout == CO) {                                                                                          \
+        hipLaunchKernelGGL((conv16_ks_kernel<CI, CO, 8, BF>), dim3((unsigned)nb_ceil_div(n_out_max, 32), CO / 32), dim3(512), 0, st, \
+                           in_split, plane, in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), \
+                           out_rows, stats);                                                                                \
+        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
+        return NB_OK;                                                                                                       \
+    }
+        NB_CONV16_KS_CASE(32, 32)
+        NB_CONV16_KS_CASE(32, 64)
+        NB_CONV16_KS_CASE(64, 64)
+        NB_CONV16_KS_CASE(64, 128)
+        NB_CONV16_KS_CASE(128, 128)
+#undef NB_CONV16_KS_CASE
+    }
+    // channel tiles per wave: all of them when the rows alone fill the chip (4 waves per group, 1024 SIMDs), else one per wave
+    // 64- and 128-channel layers: weight slab shared through LDS (measured slower for the 32-channel ones: 35 vs 29 us); all channel tiles per wave when the rows alone give >= 512
+    // workgroups, else two per wave (128 x 64-channel workgroups)
+#define NB_CONV16_LDS_CASE(CI, CO)                                                                                          \
+    if (cin == CI && cout == CO) {                                                                                           \
+        constexpr int NTT = CO / 32;                                                                                        \
+        if (row_groups < 512) {                                                                                             \
+            hipLaunchKernelGGL((conv16_lds2_kernel<CI, CO, 2, BF>), dim3(row_groups, NTT / 2), dim3(512), 0, st, in_split, plane, \
+                               in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,  \
+                               stats);                                                                                      \
+            NB_CHECK_LAUNCH("nb_enc_conv16");                                                                               \
+            return NB_OK;                                                                                                   \
+        }                                                                                                                   \
+        if (row_groups >= 512 || NTT <= 2)                                                                                  \
+            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, NTT, BF>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, \
+                               gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats); \
+        else                                                                                                                \
+            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, (NTT >= 2 ? 2 : 1), BF>), dim3(row_groups, NTT >= 2 ? NTT / 2 : 1), dim3(256), 0, st, in_split, plane, \
+                               in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,     \
+                               stats);                                                                                      \
+        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
+        return NB_OK;                                                                                                       \
+    }
+    NB_CONV16_LDS_CASE(64, 64)
+    NB_CONV16_LDS_CASE(64, 128)
+    NB_CONV16_LDS_CASE(128, 128)
+#undef NB_CONV16_LDS_CASE
+#define NB_CONV16_CASE(CI, CO)                                                                                              \
+    if (cin == CI && cout == CO) {                                                                                          \
+        constexpr int NTT = CO / 32;                                                                                        \
+        if (row_groups * 4 >= 2048 || NTT == 1)                                                                             \
+            hipLaunchKernelGGL((conv16_kernel<CI, CO, NTT, BF>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, gi, \
+                               out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats);     \
+        else                                                                                                                \
+            hipLaunchKernelGGL((conv16_kernel<CI, CO, 1, BF>), dim3(row_groups, NTT), dim3(256), 0, st, in_split, plane, in_grid, gi, \
+                               out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats);     \
+        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
+        return NB_OK;                                                                                                       \
+    }
+    NB_CONV16_CASE(32, 32)
+    NB_CONV16_CASE(32, 64)
+#undef NB_CONV16_CASE
+    nb_set_error("nb_enc_conv16: unsupported channel pair %d -> %d", cin, cout);
+    return NB_EINVAL;
+}
+
 extern "C" {
 
 int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3], int32_t *grid, int32_t *rows_vert,
@@ -868,12 +960,13 @@ int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_row
     return NB_OK;
 }
 
-int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, void *stream) {
+int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, int32_t mode, void *stream) {
     NB_REQUIRE(weight && packed, "nb_enc_conv_pack16: NULL pointer");
+    NB_REQUIRE(mode == 0 || mode == 1, "nb_enc_conv_pack16: mode %d", mode);
     NB_REQUIRE(cin >= 16 && cin % 16 == 0 && cout >= 32 && cout % 32 == 0, "nb_enc_conv_pack16: channel pair %d -> %d", cin, cout);
     const long long n = 27LL * (cin / 16) * (cout / 32) * 2 * 64;
     hipLaunchKernelGGL(conv_pack16_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
-                       reinterpret_cast<bf16x8 *>(packed));
+                       reinterpret_cast<bf16x8 *>(packed), mode);
     NB_CHECK_LAUNCH("nb_enc_conv_pack16");
     return NB_OK;
 }
@@ -890,71 +983,10 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
     const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]}, go = {out_dhw[0], out_dhw[1], out_dhw[2]};
     if (!(flags & NB_CONV_STATS_ZEROED)) NB_HIP(hipMemsetAsync(stats, 0, 2 * (size_t)cout * sizeof(double), st));
     if (n_out_max <= 0) return NB_OK;
-    const long long plane = (long long)in_rows_cap * cin;
-    const int row_groups = (int)nb_ceil_div(n_out_max, 128);
-    // small levels (the deepest one of the SMPL grid: ~1.6 k rows): the launch is a handful of workgroups whichever way it is
-    // tiled, so the chain of dependent L2 round trips per workgroup is what counts — offsets split over 8 waves (24 us instead
-    // of 67-98 us per 128-channel layer); larger levels are L2-bandwidth-bound under that tiling (weights per 32 rows)
-    if (n_out_max <= 4096) {
-#define NB_CONV16_KS_CASE(CI, CO)                                                                                           \
-    if (cin == CI && cout == CO) {                                                                                          \
-        hipLaunchKernelGGL((conv16_ks_kernel<CI, CO, 8>), dim3((unsigned)nb_ceil_div(n_out_max, 32), CO / 32), dim3(512), 0, st, \
-                           in_split, plane, in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), \
-                           out_rows, stats);                                                                                \
-        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
-        return NB_OK;                                                                                                       \
-    }
-        NB_CONV16_KS_CASE(32, 32)
-        NB_CONV16_KS_CASE(32, 64)
-        NB_CONV16_KS_CASE(64, 64)
-        NB_CONV16_KS_CASE(64, 128)
-        NB_CONV16_KS_CASE(128, 128)
-#undef NB_CONV16_KS_CASE
-    }
-    // channel tiles per wave: all of them when the rows alone fill the chip (4 waves per group, 1024 SIMDs), else one per wave
-    // 64- and 128-channel layers: weight slab shared through LDS (measured slower for the 32-channel ones: 35 vs 29 us); all channel tiles per wave when the rows alone give >= 512
-    // workgroups, else two per wave (128 x 64-channel workgroups)
-#define NB_CONV16_LDS_CASE(CI, CO)                                                                                          \
-    if (cin == CI && cout == CO) {                                                                                           \
-        constexpr int NTT = CO / 32;                                                                                        \
-        if (row_groups < 512) {                                                                                             \
-            hipLaunchKernelGGL((conv16_lds2_kernel<CI, CO, 2>), dim3(row_groups, NTT / 2), dim3(512), 0, st, in_split, plane, \
-                               in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,  \
-                               stats);                                                                                      \
-            NB_CHECK_LAUNCH("nb_enc_conv16");                                                                               \
-            return NB_OK;                                                                                                   \
-        }                                                                                                                   \
-        if (row_groups >= 512 || NTT <= 2)                                                                                  \
-            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, NTT>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, \
-                               gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats); \
-        else                                                                                                                \
-            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, (NTT >= 2 ? 2 : 1)>), dim3(row_groups, NTT >= 2 ? NTT / 2 : 1), dim3(256), 0, st, in_split, plane, \
-                               in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,     \
-                               stats);                                                                                      \
-        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
-        return NB_OK;                                                                                                       \
-    }
-    NB_CONV16_LDS_CASE(64, 64)
-    NB_CONV16_LDS_CASE(64, 128)
-    NB_CONV16_LDS_CASE(128, 128)
-#undef NB_CONV16_LDS_CASE
-#define NB_CONV16_CASE(CI, CO)                                                                                              \
-    if (cin == CI && cout == CO) {                                                                                          \
-        constexpr int NTT = CO / 32;                                                                                        \
-        if (row_groups * 4 >= 2048 || NTT == 1)                                                                             \
-            hipLaunchKernelGGL((conv16_kernel<CI, CO, NTT>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, gi, \
-                               out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats);     \
-        else                                                                                                                \
-            hipLaunchKernelGGL((conv16_kernel<CI, CO, 1>), dim3(row_groups, NTT), dim3(256), 0, st, in_split, plane, in_grid, gi, \
-                               out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats);     \
-        NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
-        return NB_OK;                                                                                                       \
-    }
-    NB_CONV16_CASE(32, 32)
-    NB_CONV16_CASE(32, 64)
-#undef NB_CONV16_CASE
-    nb_set_error("nb_enc_conv16: unsupported channel pair %d -> %d", cin, cout);
-    return NB_EINVAL;
+    return (flags & NB_CONV_BF16) ? conv16_dispatch<true>(in_split, in_rows_cap, in_grid, gi, out_lin, n_out, n_out_max, go, stride, wpacked,
+                                                          cin, cout, out_rows, stats, st)
+                                  : conv16_dispatch<false>(in_split, in_rows_cap, in_grid, gi, out_lin, n_out, n_out_max, go, stride, wpacked,
+                                                           cin, cout, out_rows, stats, st);
 }
 
 int nb_enc_gather_codes(const float *codes, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,

@@ -57,7 +57,8 @@ __global__ void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *
 __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
                                     const int *__restrict__ n_rows, int C, const float *__restrict__ batch_stats, float eps,
                                     const float *__restrict__ gamma, const double *__restrict__ sums,
-                                    float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                    float *__restrict__ dx, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                    __bf16 *__restrict__ dx_split, long long split_plane) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = *n_rows;
     if (idx < C) {
@@ -69,7 +70,13 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *_
     const double mean = batch_stats[c], invstd = 1.0 / sqrt((double)batch_stats[C + c] + (double)eps);
     const double xhat = ((double)x[idx] - mean) * invstd;
     const double g = y[idx] > 0.f ? (double)dy[idx] : 0.0;
-    dx[idx] = (float)(invstd * (double)gamma[c] * (g - sums[c] / n - xhat * sums[C + c] / n));
+    const float v = (float)(invstd * (double)gamma[c] * (g - sums[c] / n - xhat * sums[C + c] / n));
+    dx[idx] = v;
+    if (dx_split) {  // bf16 head and remainder planes for nb_enc_conv16(NB_CONV_BF16)
+        const __bf16 h = (__bf16)v;
+        dx_split[idx] = h;
+        dx_split[split_plane + idx] = (__bf16)(v - (float)h);
+    }
 }
 
 // ------------------------------------------------------------------ conv backward w.r.t. the input rows
@@ -229,7 +236,7 @@ extern "C" {
 
 int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const int32_t *n_rows, int32_t n_rows_max,
                        int32_t c, const float *batch_stats, float eps, const float *gamma, double *sums, float *dx,
-                       float *dgamma, float *dbeta, void *stream) {
+                       float *dgamma, float *dbeta, uint16_t *dx_split, void *stream) {
     NB_REQUIRE(dy && y && x && n_rows && batch_stats && gamma && sums && dx && dgamma && dbeta,
                "nb_enc_bn_relu_bwd: NULL pointer");
     NB_REQUIRE(c > 0 && n_rows_max >= 0, "nb_enc_bn_relu_bwd: bad sizes");
@@ -243,7 +250,7 @@ int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const in
     const long long total = (long long)n_rows_max * c;
     const long long threads = total > c ? total : c;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nb_ceil_div(threads, 256)), dim3(256), 0, st, dy, y, x, n_rows, c,
-                       batch_stats, eps, gamma, sums, dx, dgamma, dbeta);
+                       batch_stats, eps, gamma, sums, dx, dgamma, dbeta, reinterpret_cast<__bf16 *>(dx_split), total);
     NB_CHECK_LAUNCH("nb_enc_bn_relu_bwd");
     return NB_OK;
 }

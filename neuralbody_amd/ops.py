@@ -314,18 +314,24 @@ def enc_bn_relu(rows, n_rows, n_rows_max, stats, gamma, beta, running_mean, runn
     return batch_stats
 
 
-def enc_conv_pack16(weight):
-    """nb_enc_conv_pack16: spconv-layout fp32 weight -> fp16 head / remainder B fragments (int16 tensor)."""
+def enc_conv_pack16(weight, backward_input=False):
+    """nb_enc_conv_pack16: spconv-layout fp32 weight -> head / remainder B fragments (int16 tensor): fp16 pairs of the forward
+    convolution, or (backward_input) bf16 pairs of the stride-1 layer's backward-input convolution (mirrored offsets,
+    transposed slabs: a convolution with Cout input and Cin output channels)."""
     _req(weight, torch.float32, (3, 3, 3, None, None), "conv weight")
     cin, cout = int(weight.shape[3]), int(weight.shape[4])
     packed = torch.empty(27 * cin * cout * 2, dtype=torch.int16, device=weight.device)
-    check(_lib.lib().nb_enc_conv_pack16(ptr(weight), cin, cout, ptr(packed), _stream()), "nb_enc_conv_pack16")
+    if backward_input:
+        check(_lib.lib().nb_enc_conv_pack16(ptr(weight), cout, cin, ptr(packed), 1, _stream()), "nb_enc_conv_pack16")
+    else:
+        check(_lib.lib().nb_enc_conv_pack16(ptr(weight), cin, cout, ptr(packed), 0, _stream()), "nb_enc_conv_pack16")
     return packed
 
 
-def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, wpacked, cin, cout, stats=None):
+def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, wpacked, cin, cout, stats=None,
+               bf16=False):
     """nb_enc_conv16 on split rows (int16 [2, cap, Cin]: fp16 heads | remainders) -> (out_rows fp32, stats fp64); `stats` as
-    in enc_conv."""
+    in enc_conv.  bf16: the planes and the packed weight are bf16 pairs (the backward-input convolution)."""
     _req(in_split, torch.int16, (2, None, cin), "in_split")
     _req(wpacked, torch.int16, (27 * cin * cout * 2,), "wpacked")
     _req(in_grid, torch.int32, tuple(int(s) for s in in_dhw), "in_grid")
@@ -335,7 +341,7 @@ def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, st
         raise ValueError("out_lin shorter than n_out_max")
     dev = in_split.device
     out_rows = torch.empty((max(int(n_out_max), 1), cout), dtype=torch.float32, device=dev)
-    flags = 0 if stats is None else 1  # NB_CONV_STATS_ZEROED
+    flags = (0 if stats is None else 1) | (2 if bf16 else 0)  # NB_CONV_STATS_ZEROED | NB_CONV_BF16
     if stats is None:
         stats = torch.empty(2 * cout, dtype=torch.float64, device=dev)
     else:
@@ -536,8 +542,9 @@ def trilinear_bwd(scene, grids, drows, wpts, d_feat, run_length=1):
     return drows
 
 
-def enc_bn_relu_bwd(dy, y, x, n_rows, n_rows_max, batch_stats, eps, gamma):
-    """nb_enc_bn_relu_bwd -> (dx, dgamma, dbeta)."""
+def enc_bn_relu_bwd(dy, y, x, n_rows, n_rows_max, batch_stats, eps, gamma, want_split=False):
+    """nb_enc_bn_relu_bwd -> (dx, dgamma, dbeta) or, with want_split, (dx, dgamma, dbeta, dx_split int16 [2, rows, C]: dx as bf16
+    head / remainder planes for the backward-input convolution on the matrix pipe)."""
     c = int(x.shape[1])
     for t, nm in ((dy, "dy"), (y, "y"), (x, "x")):
         _req(t, torch.float32, (None, c), nm)
@@ -548,10 +555,11 @@ def enc_bn_relu_bwd(dy, y, x, n_rows, n_rows_max, batch_stats, eps, gamma):
     dx = torch.empty_like(x)
     dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    split = torch.empty((2, max(int(n_rows_max), 1), c), dtype=torch.int16, device=dev) if want_split else None
     check(_lib.lib().nb_enc_bn_relu_bwd(ptr(dy), ptr(y), ptr(x), ptr(n_rows), int(n_rows_max), c, ptr(batch_stats),
-                                        float(eps), ptr(gamma), ptr(sums), ptr(dx), ptr(dgamma), ptr(dbeta), _stream()),
-          "nb_enc_bn_relu_bwd")
-    return dx, dgamma, dbeta
+                                        float(eps), ptr(gamma), ptr(sums), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(split),
+                                        _stream()), "nb_enc_bn_relu_bwd")
+    return (dx, dgamma, dbeta, split) if want_split else (dx, dgamma, dbeta)
 
 
 def enc_conv_bwd_input(dx, out_grid, out_dhw, in_lin, n_in, n_in_max, in_dhw, stride, weight):

@@ -9,6 +9,8 @@ F | h1 | h2 | h3 | G | V | PE per point) and composites with `nb_composite`; the
 All arithmetic is fp32.  The merged feature_fc/latent_fc layer of the inference kernels is NOT used here: gradients are
 taken layer by layer exactly as the reference modules are written (lib/networks/latent_xyzc.py:99-121).
 """
+import os
+
 import torch
 
 from . import ops
@@ -82,6 +84,9 @@ def decoder_backward(net, tap, d_raw, latent_index):
     return g, dF
 
 
+BWD_INPUT_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # backward-input convolutions on the 16-bit matrix pipe (bf16 pairs)
+
+
 def encoder_backward(xyzc_net, ctx, drows_dense):
     """Backward of SparseConvNet.forward(save=ctx).  drows_dense[l] [n_rows_l, C_l]: gradient w.r.t. the active rows of
     dense level l (from nb_trilinear_bwd).  Returns (grads, dcodes): grads maps `xyzc_net.<block>.<k>.weight|bias` to
@@ -103,17 +108,30 @@ def encoder_backward(xyzc_net, ctx, drows_dense):
         if dy is None:
             raise RuntimeError("no gradient reaches the last encoder layer")
         conv, bn = rec["conv"], rec["bn"]
-        dx, dgamma, dbeta = ops.enc_bn_relu_bwd(dy, y, x, rec["n_out"], rec["n_out_max"], rec["bstats"], bn.eps,
-                                                bn.weight.detach())
-        g[names[id(bn)] + ".weight"] = dgamma
-        g[names[id(bn)] + ".bias"] = dbeta
         w = conv.weight.detach()
         cin, cout = int(w.shape[3]), int(w.shape[4])
+        # a stride-1 (submanifold) layer's backward-input product is a convolution of its own — mirrored offsets, transposed
+        # slabs, same active set — and runs on the forward's matrix-pipe kernels with bf16 head / remainder operands
+        # (nb_enc_conv16 with NB_CONV_BF16; gradients span more binades than an un-scaled fp16 head holds).  The strided layers
+        # and the 16-channel ones keep the exact-fp32 kernel.
+        on_pipe = BWD_INPUT_SPLIT and rec["stride"] == 1 and cin >= 32
+        if on_pipe:
+            dx, dgamma, dbeta, dx_split = ops.enc_bn_relu_bwd(dy, y, x, rec["n_out"], rec["n_out_max"], rec["bstats"], bn.eps,
+                                                              bn.weight.detach(), want_split=True)
+        else:
+            dx, dgamma, dbeta = ops.enc_bn_relu_bwd(dy, y, x, rec["n_out"], rec["n_out_max"], rec["bstats"], bn.eps,
+                                                    bn.weight.detach())
+        g[names[id(bn)] + ".weight"] = dgamma
+        g[names[id(bn)] + ".bias"] = dbeta
         g[names[id(conv)] + ".weight"] = ops.enc_conv_bwd_weight(rec["in_rows"], rec["in_grid"], rec["in_dhw"], rec["out_lin"],
                                                                rec["n_out"], rec["n_out_max"], rec["out_dhw"], rec["stride"],
                                                                dx, cin, cout)
-        dy = ops.enc_conv_bwd_input(dx, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
-                                    rec["in_dhw"], rec["stride"], w)
+        if on_pipe:
+            dy = ops.enc_conv16(dx_split, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
+                                rec["in_dhw"], 1, ops.enc_conv_pack16(w, backward_input=True), cout, cin, bf16=True)[0]
+        else:
+            dy = ops.enc_conv_bwd_input(dx, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
+                                        rec["in_dhw"], rec["stride"], w)
     dcodes = ops.enc_scatter_codes_bwd(dy, head["rows_vert"], head["n_rows"], head["n_max"], 6890)
     return g, dcodes
 
