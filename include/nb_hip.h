@@ -334,11 +334,14 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
                           const float *weight, int32_t cin, int32_t cout, float *din, void *stream);
 
 /* Gradient of the conv weight [3,3,3,Cin,Cout] (zeroed by the call): dW[o] = sum_r in[nbr(r,o)]^T (x) dx[r].
- * rulebook: dev int32 scratch [n_out_max * 27] (receives nbr(r,o), -1 = no active input voxel). */
+ * rulebook: dev int32 scratch [n_out_max * 27] (receives nbr(r,o), -1 = no active input voxel).
+ * dx_split (dev or NULL): dx as bf16 head / remainder planes [2, n_out_max, Cout] (nb_enc_bn_relu_bwd writes them); when given
+ * and Cin >= 32 the product runs on the 16-bit matrix pipe with both operands as bf16 pairs (three products, fp32 accumulate,
+ * ~2^-16 relative) instead of the exact-fp32 MFMA kernel. */
 int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3],
                            const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3],
-                           int32_t stride, const float *dx, int32_t cin, int32_t cout, float *dweight,
-                           int32_t *rulebook, void *stream);
+                           int32_t stride, const float *dx, const uint16_t *dx_split, int32_t cin, int32_t cout,
+                           float *dweight, int32_t *rulebook, void *stream);
 
 /* Embedding-lookup backward: dcodes[rows_vert[r], :] = drows[r, :] (dcodes zeroed by the caller). */
 int nb_enc_scatter_codes_bwd(const float *drows, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,

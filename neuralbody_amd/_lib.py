@@ -77,7 +77,7 @@ SIGNATURES = {
     "nb_enc_conv16": (C.c_int, [_P, _I32, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _I32, _P]),
     "nb_enc_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
     "nb_enc_conv_bwd_input": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P]),
-    "nb_enc_conv_bwd_weight": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _P]),
+    "nb_enc_conv_bwd_weight": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _P, _I32, _I32, _P, _P, _P]),
     "nb_enc_scatter_codes_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_enc_gather_codes": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_raygen": (C.c_int, [_I32, _I32, C.c_double * 9, C.c_double * 9, C.c_double * 3, C.c_float * 6, _P, _P, _P,

@@ -230,6 +230,172 @@ __global__ void scatter_codes_bwd_kernel(const float *__restrict__ drows, const 
     dcodes[(size_t)rows_vert[r] * C + c] = drows[idx];  // one row per vertex at most: plain store into a zeroed buffer
 }
 
+// ------------------------------------------------------------------ conv weight gradient on the 16-bit matrix pipe
+// dW[o] = sum_r in[nbr(r, o)]^T (x) dx[r] as v_mfma_f32_32x32x16_bf16 with both operands as bf16 head + remainder (three
+// products, fp32 accumulate).  The reduction runs over ROWS, so both MFMA operands are K-major: lane (channel, kg) needs 8
+// consecutive rows of one channel, the transpose of how rows are stored.  A workgroup stages 32 gathered input rows and the 32
+// matching dx rows row-major in LDS (fp32 -> bf16 pairs on the way; dx arrives as pairs from nb_enc_bn_relu_bwd) and reads the
+// fragments with ds_read_b64_tr_b16 (each 16-lane group transposes a [4 rows][16 channels] block: lane l receives channel
+// 16 (g & 1) + (l & 15), rows 8 (g >> 1) + 0..3 of the block whose 8-byte segments the lanes address —
+// tools/experiments/probe_trread.hip).  Row pitch = 2 C + 32 bytes: the four rows of a block fall into distinct banks.
+// One workgroup = (offset o, BW_ROWS consecutive output rows): the accumulators persist over its 32-row chunks and leave as
+// ONE set of atomics (the exact-fp32 kernel: one set per 256 rows), wave w owns a block of the [C_in / 32] x [C_out / 32]
+// tiles.  The next chunk's global loads are issued before the current chunk's MFMAs (two LDS buffers).
+constexpr int BW_ROWS = 1024;
+typedef short nb_s4 __attribute__((ext_vector_type(4)));
+typedef __bf16 nb_bf8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ nb_bf8 tr_frag(unsigned addr_lo4, unsigned addr_hi4) {  // rows +0..3 and +4..7 of a K = 8 group
+    nb_s4 a, b;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(addr_lo4));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b) : "v"(addr_hi4));
+    typedef short s8 __attribute__((ext_vector_type(8)));
+    const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(nb_bf8, v);
+}
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv_bwd_w16_kernel(const float *__restrict__ in_rows, const int *__restrict__ nbr,
+                                                           const int *__restrict__ n_out, const unsigned short *__restrict__ dx_split,
+                                                           long long dx_plane, float *__restrict__ dw) {
+    constexpr int CT = CIN / 32, OT = COUT / 32;               // tiles of dW[o]
+    constexpr int WCI = CT >= 2 ? 2 : 1, WCO = OT >= 2 ? 2 : 1;  // waves along each tile axis (4 waves when both >= 2)
+    constexpr int TCI = CT / WCI, TCO = OT / WCO;               // tiles per wave
+    constexpr int PA = CIN * 2 + 32, PB = COUT * 2 + 32;        // LDS row pitches in bytes
+    constexpr int A_BYTES = 32 * PA, B_BYTES = 32 * PB, BUF = 2 * A_BYTES + 2 * B_BYTES;  // head and remainder planes
+    __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int o = blockIdx.x;
+    const int n = *n_out;
+    const int row_begin = blockIdx.y * BW_ROWS;
+    if (row_begin >= n) return;  // workgroup-uniform
+    const int row_end = min(n, row_begin + BW_ROWS);
+    const int n_chunks = (row_end - row_begin + 31) / 32;
+    const bool active = wv < WCI * WCO;
+    const int wci = wv / WCO, wco = wv % WCO;
+
+    // staging roles: 8 threads per row; thread (r, p) moves channels [p C / 8, (p + 1) C / 8) of row r
+    const int sr = tid >> 3, sp = tid & 7;
+    constexpr int A4 = CIN / 32, B8 = COUT / 64 > 0 ? COUT / 64 : 1;  // float4 loads of A, 16-byte loads per plane of B, per thread
+    f32x4 ra[A4];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rbh[B8], rbl[B8];
+    bool b_lane = (COUT >= 64) || sp < 4;  // C_out = 32: a row's plane is 64 bytes = 4 threads x 16
+    auto fetch = [&](int chunk) {
+        const int row = row_begin + chunk * 32 + sr;
+        int nb = -1;
+        if (row < row_end) nb = nbr[(size_t)row * 27 + o];
+#pragma unroll
+        for (int q = 0; q < A4; ++q)
+            ra[q] = nb >= 0 ? *reinterpret_cast<const f32x4 *>(in_rows + (size_t)nb * CIN + sp * (CIN / 8) + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool live = nb >= 0;  // a row without a neighbour under this offset contributes nothing: zero dx too
+#pragma unroll
+        for (int q = 0; q < B8; ++q) {
+            const size_t e = (size_t)row * COUT + (size_t)(sp * B8 + q) * 8;
+            rbh[q] = (live && b_lane) ? *reinterpret_cast<const u32x4 *>(dx_split + e) : u32x4{0u, 0u, 0u, 0u};
+            rbl[q] = (live && b_lane) ? *reinterpret_cast<const u32x4 *>(dx_split + dx_plane + e) : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto stash = [&](int buf) {
+        char *base = lds + buf * BUF;
+        // A: fp32 -> bf16 head / remainder, 4 values = 8 bytes per plane per float4
+#pragma unroll
+        for (int q = 0; q < A4; ++q) {
+            const float v[4] = {ra[q].x, ra[q].y, ra[q].z, ra[q].w};
+            unsigned short h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const __bf16 hh = (__bf16)v[e];
+                h[e] = __builtin_bit_cast(unsigned short, hh);
+                l[e] = __builtin_bit_cast(unsigned short, (__bf16)(v[e] - (float)hh));
+            }
+            const int cb = (sp * (CIN / 8) + 4 * q) * 2;
+            *reinterpret_cast<uint2 *>(base + sr * PA + cb) = uint2{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16)};
+            *reinterpret_cast<uint2 *>(base + A_BYTES + sr * PA + cb) = uint2{l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16)};
+        }
+        if (b_lane) {
+#pragma unroll
+            for (int q = 0; q < B8; ++q) {
+                const int cb = (sp * B8 + q) * 16;
+                *reinterpret_cast<u32x4 *>(base + 2 * A_BYTES + sr * PB + cb) = rbh[q];
+                *reinterpret_cast<u32x4 *>(base + 2 * A_BYTES + B_BYTES + sr * PB + cb) = rbl[q];
+            }
+        }
+    };
+
+    f32x16 acc[TCI][TCO];
+#pragma unroll
+    for (int a = 0; a < TCI; ++a)
+#pragma unroll
+        for (int b = 0; b < TCO; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // fragment addressing: lane l of 16-lane group g addresses segment (row 8 (g >> 1) + (l15 >> 2), channels 16 (g & 1) + 4 (l15 & 3))
+    const int l15 = lane & 15, g = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)lds;
+    const unsigned a_lane = (8 * (g >> 1) + (l15 >> 2)) * PA + (16 * (g & 1) + 4 * (l15 & 3)) * 2;
+    const unsigned b_lane_off = (8 * (g >> 1) + (l15 >> 2)) * PB + (16 * (g & 1) + 4 * (l15 & 3)) * 2;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) fetch(c + 1);
+        if (active) {
+            const unsigned base = lds0 + (c & 1) * BUF;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                nb_bf8 ah[TCI], al[TCI], bh[TCO], bl[TCO];
+#pragma unroll
+                for (int a = 0; a < TCI; ++a) {
+                    const unsigned ad = base + a_lane + kc * 16 * PA + ((wci * TCI + a) * 32) * 2;
+                    ah[a] = tr_frag(ad, ad + 4 * PA);
+                    al[a] = tr_frag(ad + A_BYTES, ad + A_BYTES + 4 * PA);
+                }
+#pragma unroll
+                for (int b = 0; b < TCO; ++b) {
+                    const unsigned bd = base + 2 * A_BYTES + b_lane_off + kc * 16 * PB + ((wco * TCO + b) * 32) * 2;
+                    bh[b] = tr_frag(bd, bd + 4 * PB);
+                    bl[b] = tr_frag(bd + B_BYTES, bd + B_BYTES + 4 * PB);
+                }
+                // the reads above are inline asm: the compiler does not count them, so the wait is tied to every fragment register
+                if constexpr (TCI == 2 && TCO == 2)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(ah[1]), "+v"(al[1]), "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+                else if constexpr (TCI == 1 && TCO == 2)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+                else if constexpr (TCI == 2 && TCO == 1)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(ah[1]), "+v"(al[1]), "+v"(bh[0]), "+v"(bl[0]));
+                else
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));
+#pragma unroll
+                for (int a = 0; a < TCI; ++a)
+#pragma unroll
+                    for (int b = 0; b < TCO; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            }
+        }
+        if (c + 1 < n_chunks) stash((c + 1) & 1);  // the other buffer: its readers passed the barrier that ended chunk c - 1
+        __syncthreads();
+    }
+    if (!active) return;
+    // D fragment: lane (j = output channel, hi) holds input channels tile_row(r, hi)
+    const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < TCI; ++a)
+#pragma unroll
+        for (int b = 0; b < TCO; ++b) {
+            const int co = (wco * TCO + b) * 32 + j;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = (wci * TCI + a) * 32 + tile_row(r, hi);
+                atomicAdd(&dw[((size_t)o * CIN + ci) * COUT + co], acc[a][b][r]);
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" {
@@ -280,7 +446,8 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
 
 int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3], const int32_t *out_lin,
                            const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride,
-                           const float *dx, int32_t cin, int32_t cout, float *dweight, int32_t *rulebook, void *stream) {
+                           const float *dx, const uint16_t *dx_split, int32_t cin, int32_t cout, float *dweight,
+                           int32_t *rulebook, void *stream) {
     NB_REQUIRE(in_rows && in_grid && in_dhw && out_lin && n_out && out_dhw && dx && dweight,
                "nb_enc_conv_bwd_weight: NULL pointer");
     NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv_bwd_weight: stride %d", stride);
@@ -291,6 +458,18 @@ int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const i
     const Dims go = {out_dhw[0], out_dhw[1], out_dhw[2]}, gi = {in_dhw[0], in_dhw[1], in_dhw[2]};
     hipLaunchKernelGGL(conv_rulebook_kernel, dim3(nb_ceil_div((long long)n_out_max * 27, 256)), dim3(256), 0, st, in_grid, gi,
                        out_lin, n_out, go, stride, rulebook);
+    if (dx_split && cin >= 32) {  // bf16 pairs of dx given: the matrix-pipe kernel (the 16-channel layers stay exact fp32)
+        const long long plane = (long long)n_out_max * cout;
+#define X16(CI, CO)                                                                                                   \
+    if (cin == CI && cout == CO) {                                                                                    \
+        hipLaunchKernelGGL((conv_bwd_w16_kernel<CI, CO>), dim3(27, (unsigned)nb_ceil_div(n_out_max, BW_ROWS)), dim3(256), 0, st, \
+                           in_rows, rulebook, n_out, dx_split, plane, dweight);                                       \
+        NB_CHECK_LAUNCH("nb_enc_conv_bwd_weight");                                                                    \
+        return NB_OK;                                                                                                 \
+    }
+        X16(32, 32) X16(32, 64) X16(64, 64) X16(64, 128) X16(128, 128)
+#undef X16
+    }
 #define X(CI, CO)                                                                                                     \
     if (cin == CI && cout == CO) {                                                                                    \
         hipLaunchKernelGGL((conv_bwd_w_kernel<CI, CO>),                                                               \

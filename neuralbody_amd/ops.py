@@ -574,14 +574,18 @@ def enc_conv_bwd_input(dx, out_grid, out_dhw, in_lin, n_in, n_in_max, in_dhw, st
     return din
 
 
-def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, dx, cin, cout):
+def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, dx, cin, cout, dx_split=None):
+    """nb_enc_conv_bwd_weight -> dW [3,3,3,Cin,Cout].  dx_split (int16 [2, n_out_max, Cout], enc_bn_relu_bwd(want_split=True)):
+    the product runs on the 16-bit matrix pipe with bf16 pairs (Cin >= 32)."""
     _req(in_rows, torch.float32, (None, cin), "in_rows")
     _req(dx, torch.float32, (None, cout), "dx")
+    if dx_split is not None:
+        _req(dx_split, torch.int16, (2, max(int(n_out_max), 1), cout), "dx_split")
     dw = torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=dx.device)
     rulebook = torch.empty(max(int(n_out_max), 1) * 27, dtype=torch.int32, device=dx.device)
     check(_lib.lib().nb_enc_conv_bwd_weight(ptr(in_rows), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out),
-                                            int(n_out_max), _i3(out_dhw), int(stride), ptr(dx), cin, cout, ptr(dw),
-                                            ptr(rulebook), _stream()), "nb_enc_conv_bwd_weight")
+                                            int(n_out_max), _i3(out_dhw), int(stride), ptr(dx), ptr(dx_split), cin, cout,
+                                            ptr(dw), ptr(rulebook), _stream()), "nb_enc_conv_bwd_weight")
     return dw
 
 

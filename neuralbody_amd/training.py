@@ -115,7 +115,8 @@ def encoder_backward(xyzc_net, ctx, drows_dense):
         # (nb_enc_conv16 with NB_CONV_BF16; gradients span more binades than an un-scaled fp16 head holds).  The strided layers
         # and the 16-channel ones keep the exact-fp32 kernel.
         on_pipe = BWD_INPUT_SPLIT and rec["stride"] == 1 and cin >= 32
-        if on_pipe:
+        dx_split = None
+        if BWD_INPUT_SPLIT and cin >= 32:  # (the weight gradient of every >= 32-channel layer takes the planes too)
             dx, dgamma, dbeta, dx_split = ops.enc_bn_relu_bwd(dy, y, x, rec["n_out"], rec["n_out_max"], rec["bstats"], bn.eps,
                                                               bn.weight.detach(), want_split=True)
         else:
@@ -125,7 +126,7 @@ def encoder_backward(xyzc_net, ctx, drows_dense):
         g[names[id(bn)] + ".bias"] = dbeta
         g[names[id(conv)] + ".weight"] = ops.enc_conv_bwd_weight(rec["in_rows"], rec["in_grid"], rec["in_dhw"], rec["out_lin"],
                                                                rec["n_out"], rec["n_out_max"], rec["out_dhw"], rec["stride"],
-                                                               dx, cin, cout)
+                                                               dx, cin, cout, dx_split=dx_split)
         if on_pipe:
             dy = ops.enc_conv16(dx_split, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
                                 rec["in_dhw"], 1, ops.enc_conv_pack16(w, backward_input=True), cout, cin, bf16=True)[0]
