@@ -205,7 +205,9 @@ int nb_composite_bwd(const float *raw, const float *z_vals, const float *ray_d, 
 
 /* Row-major fp32 GEMM C[m,n] = alpha * op(A) op(B) + beta * C on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, exact
  * fp32): the backward of the Conv1d(k=1) layers (latent_xyzc.py:99-121).  lda/ldb/ldc are row strides.  op(A) = A^T
- * (trans_a) is the weight-gradient form dW = dY^T X (split over the long row dimension, fp32 atomics, op(B) = B only:
+ * (trans_a) is the weight-gradient form dW = dY^T X (split over the long row dimension, fp32 atomics; for M, N >= 32, K >= 1024
+ * and 16-byte aligned rows it runs on the 16-bit matrix pipe with both operands as bf16 head + remainder pairs, ~2^-16
+ * relative, else exact fp32; op(B) = B only:
  * trans_a && trans_b is refused with NB_EINVAL, no caller of the path needs it).  Summation order: the trans_a form and the
  * colsum epilogue of nb_gemm_fused accumulate with fp32 atomics, so weight / bias gradients are reproducible to rounding
  * (~1e-7 relative), not bit for bit, from run to run — like the reference's own cuBLAS / atomics-based backward.  k == 0 is

@@ -10,6 +10,7 @@
 //   nb_trilinear_bwd   dF [N,352] -> gradients of the ACTIVE voxel rows of the four feature volumes
 //                      (grid_sample backward restricted to active voxels: inactive sites are constants)
 #include "nb_march_common.h"
+#include "nb_trread.h"
 
 using namespace nbm;
 
@@ -212,6 +213,126 @@ __global__ __launch_bounds__(64 * TN_WAVES) void gemm_tn_kernel(const float *__r
             if (cm < M) atomicAdd(&C[(size_t)cm * ldc + bn], alpha * v);
         }
     }
+}
+
+// The same product on the 16-bit matrix pipe: both operands as bf16 head + remainder (three products per K = 16 chunk, fp32
+// accumulate, ~2^-16 relative), the recipe of conv_bwd_w16_kernel (nb_encoder_bwd.hip): the reduction runs over ROWS, so both
+// MFMA operands are K-major; a workgroup stages 32 rows x 128 columns of A and of B row-major in LDS (fp32 -> bf16 pairs on
+// the way) and reads the fragments with ds_read_b64_tr_b16 (nb_trread.h).  One workgroup = a 128 x 128 tile of C over
+// TN16_ROWS rows, wave w a 2 x 2 block of its 32 x 32 tiles; the next chunk's loads are issued before the current chunk's
+// MFMAs.  Ragged M / N: columns beyond the matrix are staged as zeros and not written back.
+constexpr int TN16_ROWS = 1024;
+constexpr int TN16_P = 128 * 2 + 32;            // LDS row pitch in bytes
+constexpr int TN16_PLANE = 32 * TN16_P;         // one bf16 plane of one operand
+constexpr int TN16_BUF = 4 * TN16_PLANE;        // A head | A remainder | B head | B remainder
+
+__global__ __launch_bounds__(256) void gemm_tn16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
+                                                        int ldb, long long R, int M, int N, float alpha,
+                                                        float *__restrict__ C, int ldc) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * TN16_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const long long row_begin = (long long)blockIdx.z * TN16_ROWS;
+    const long long row_end = row_begin + TN16_ROWS < R ? row_begin + TN16_ROWS : R;
+    const int n_chunks = (int)((row_end - row_begin + 31) / 32);
+    const int wm = wv >> 1, wn = wv & 1;  // the wave's 2 x 2 block of tiles
+    // a wave whose block lies outside the matrix has nothing to multiply (it still stages)
+    const bool active = m0 + wm * 64 < M && n0 + wn * 64 < N;
+    const int sr = tid >> 3, sp = tid & 7;  // staging: 8 threads per row, 16 columns each
+    f32x4 ra[4], rb[4];
+    auto fetch_one = [&](const float *__restrict__ P, int ld, int c0, int lim, long long row, f32x4 (&r)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = c0 + sp * 16 + 4 * q;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < row_end) {
+                const float *src = P + row * ld + c;
+                if (c + 3 < lim) v = *reinterpret_cast<const f32x4 *>(src);
+                else {
+                    if (c < lim) v.x = src[0];
+                    if (c + 1 < lim) v.y = src[1];
+                    if (c + 2 < lim) v.z = src[2];
+                }
+            }
+            r[q] = v;
+        }
+    };
+    auto fetch = [&](int chunk) {
+        const long long row = row_begin + chunk * 32 + sr;
+        fetch_one(A, lda, m0, M, row, ra);
+        fetch_one(B, ldb, n0, N, row, rb);
+    };
+    auto stash_one = [&](char *hp, const f32x4 (&r)[4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v[4] = {r[q].x, r[q].y, r[q].z, r[q].w};
+            unsigned short h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nbtr::split_bf16(v[e], h[e], l[e]);
+            const int cb = (sp * 16 + 4 * q) * 2;
+            *reinterpret_cast<uint2 *>(hp + sr * TN16_P + cb) = uint2{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16)};
+            *reinterpret_cast<uint2 *>(hp + TN16_PLANE + sr * TN16_P + cb) = uint2{l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16)};
+        }
+    };
+    auto stash = [&](int buf) {
+        stash_one(lds + buf * TN16_BUF, ra);
+        stash_one(lds + buf * TN16_BUF + 2 * TN16_PLANE, rb);
+    };
+    f32x16_ acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const unsigned lds0 = (unsigned)(size_t)lds, loff = nbtr::lane_offset(lane, TN16_P);
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) fetch(c + 1);
+        if (active) {
+            const unsigned base = lds0 + (c & 1) * TN16_BUF + loff;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                nbtr::bf8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned ad = base + kc * 16 * TN16_P + ((wm * 2 + t) * 32) * 2;
+                    ah[t] = nbtr::frag(ad, ad + 4 * TN16_P);
+                    al[t] = nbtr::frag(ad + TN16_PLANE, ad + TN16_PLANE + 4 * TN16_P);
+                    const unsigned bd = base + 2 * TN16_PLANE + kc * 16 * TN16_P + ((wn * 2 + t) * 32) * 2;
+                    bh[t] = nbtr::frag(bd, bd + 4 * TN16_P);
+                    bl[t] = nbtr::frag(bd + TN16_PLANE, bd + TN16_PLANE + 4 * TN16_P);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(al[0]), "+v"(ah[1]), "+v"(al[1]), "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]));
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            }
+        }
+        if (c + 1 < n_chunks) stash((c + 1) & 1);  // the other buffer: its readers passed the barrier that ended chunk c - 1
+        __syncthreads();
+    }
+    if (!active) return;
+    const int j = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int cn = n0 + (wn * 2 + b) * 32 + j;
+            if (cn >= N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cm = m0 + (wm * 2 + a) * 32 + tn_tile_row(r, hi);
+                if (cm < M) atomicAdd(&C[(size_t)cm * ldc + cn], alpha * acc[a][b][r]);
+            }
+        }
 }
 
 __global__ void scale_matrix_kernel(float *__restrict__ C, int m, int n, int ldc, float beta) {
@@ -433,6 +554,13 @@ int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, flo
             hipLaunchKernelGGL(scale_matrix_kernel, dim3(nb_ceil_div((long long)m * n, 256)), dim3(256), 0, st, c, m, n, ldc, beta);
         if (k == 0) {
             NB_CHECK_LAUNCH("scale_matrix_kernel");
+            return NB_OK;
+        }
+        // weight-gradient shapes (M, N >= 32, thousands of rows, 16-byte aligned rows): bf16 pairs on the 16-bit matrix pipe
+        if (m >= 32 && n >= 32 && k >= 1024 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0) {
+            hipLaunchKernelGGL(gemm_tn16_kernel, dim3(nb_ceil_div(m, 128), nb_ceil_div(n, 128), nb_ceil_div(k, TN16_ROWS)), dim3(256), 0,
+                               st, a, lda, b, ldb, (long long)k, m, n, alpha, c, ldc);
+            NB_CHECK_LAUNCH("gemm_tn16_kernel");
             return NB_OK;
         }
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(nb_ceil_div(k, TN_WAVES * TN_ROWS), nb_ceil_div(m, 32), nb_ceil_div(n, 32)), dim3(64 * TN_WAVES),

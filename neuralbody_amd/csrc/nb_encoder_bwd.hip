@@ -11,6 +11,7 @@
 //   nb_enc_conv_bwd_weight  dW[o] = sum_r in[nbr(r, o)]^T (x) dx[r]   (MFMA over row chunks, fp32 atomics into dW)
 //   nb_enc_scatter_codes_bwd  d c.weight[vertex of row r] = d rows[r]  (Embedding lookup backward, :33-34)
 #include "nb_common.h"
+#include "nb_trread.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -242,17 +243,8 @@ __global__ void scatter_codes_bwd_kernel(const float *__restrict__ drows, const 
 // ONE set of atomics (the exact-fp32 kernel: one set per 256 rows), wave w owns a block of the [C_in / 32] x [C_out / 32]
 // tiles.  The next chunk's global loads are issued before the current chunk's MFMAs (two LDS buffers).
 constexpr int BW_ROWS = 1024;
-typedef short nb_s4 __attribute__((ext_vector_type(4)));
-typedef __bf16 nb_bf8 __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ nb_bf8 tr_frag(unsigned addr_lo4, unsigned addr_hi4) {  // rows +0..3 and +4..7 of a K = 8 group
-    nb_s4 a, b;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(addr_lo4));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b) : "v"(addr_hi4));
-    typedef short s8 __attribute__((ext_vector_type(8)));
-    const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return __builtin_bit_cast(nb_bf8, v);
-}
+typedef nbtr::bf8 nb_bf8;
+__device__ __forceinline__ nb_bf8 tr_frag(unsigned addr_lo4, unsigned addr_hi4) { return nbtr::frag(addr_lo4, addr_hi4); }
 
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv_bwd_w16_kernel(const float *__restrict__ in_rows, const int *__restrict__ nbr,

@@ -106,6 +106,21 @@ def test_sgemm_relu_colsum():
         np.testing.assert_allclose(out[:, 1:n + 1].cpu().numpy(), ref.float().cpu().numpy(), rtol=1e-4, atol=2e-4)
         np.testing.assert_allclose(cs.cpu().numpy(), 0.25 + ref.sum(0).float().cpu().numpy(), rtol=1e-4, atol=2e-3)
         assert torch.equal(out[:, 0], C0[:, 0]) and torch.equal(out[:, n + 1], C0[:, n + 1])
+    # weight-gradient shapes with 16-byte aligned rows take the 16-bit matrix pipe (bf16 head + remainder pairs, fragments by
+    # ds_read_b64_tr_b16): ragged M = 346 (view_fc's input width) and N, a row count that is not a multiple of the 32-row chunk,
+    # accumulation into a slice
+    wa = torch.from_numpy(rs.standard_normal((5003, 400)).astype(np.float32)).to(DEV)
+    wb = torch.from_numpy(rs.standard_normal((5003, 260)).astype(np.float32)).to(DEV)
+    for (c0, c1, d0, d1) in ((8, 354, 4, 260), (0, 256, 0, 128), (16, 48, 100, 133)):
+        ref = (wa[:, c0:c1].double().T @ wb[:, d0:d1].double()).float()
+        got = ops.sgemm(wa[:, c0:c1], wb[:, d0:d1], trans_a=True)
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=4e-3)
+        assert float((got - ref).abs().max()) <= 3e-5 * float(ref.abs().max()) + 1e-3  # ~2^-16 relative of the column norms
+    acc2 = torch.full((346, 300), 0.25, device=DEV)
+    ref = (wa[:, 8:354].double().T @ wb[:, 4:260].double()).float()
+    ops.sgemm(wa[:, 8:354], wb[:, 4:260], trans_a=True, out=acc2[:, 20:276], alpha=0.5, beta=1.0)
+    np.testing.assert_allclose(acc2[:, 20:276].cpu().numpy(), (0.25 + 0.5 * ref).cpu().numpy(), rtol=1e-4, atol=4e-3)
+    assert float(acc2[:, :20].min()) == 0.25 and float(acc2[:, 276:].max()) == 0.25
     # k = 0: an empty product — C = beta C (+ the epilogue), in both forms (the fast kernel pre-loaded operand
     # panels before looking at k)
     c0 = torch.from_numpy(rs.standard_normal((128, 256)).astype(np.float32)).to(DEV)
