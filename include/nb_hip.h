@@ -214,7 +214,9 @@ int nb_composite_bwd(const float *raw, const float *z_vals, const float *ray_d, 
  * an empty product: C = beta C (and the epilogue). */
 int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
              const float *b, int32_t ldb, float beta, float *c, int32_t ldc, void *stream);
-/* The same with the epilogues of the backward chain fused (trans_a = 0 only):
+/* (The non-transposed-A form with op(B) = B, >= 1024 rows, K a multiple of 32 and 16-byte aligned operands — the dX = dY . W
+ * products — also runs on the 16-bit matrix pipe with bf16 pairs.)
+ * The same with the epilogues of the backward chain fused (trans_a = 0 only):
  *   mask_y (dev [m, >= n], row stride ldy, or NULL): C[r,c] = 0 where mask_y[r,c] <= 0 — the ReLU that followed the
  *            layer whose input gradient C is (mask_y = that layer's post-activation output);
  *   colsum (dev [n] or NULL): colsum[c] += sum_r C[r,c] after the mask — the bias gradient of that layer. */

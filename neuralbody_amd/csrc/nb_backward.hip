@@ -519,6 +519,135 @@ __global__ __launch_bounds__(256) void gemm_rows_fast_kernel(const float *__rest
     }
 }
 
+// gemm_rows_fast_kernel (op(B) = B) on the 16-bit matrix pipe, both operands as bf16 head + remainder pairs: the `dX = dY . W`
+// products of the MLP backward.  A fragment: a lane's row, 8 consecutive K values = two float4 straight from global memory, split
+// in registers.  B fragment: K-major (8 consecutive K of one column) from a [32 K][128 columns] LDS tile of bf16 pairs by
+// ds_read_b64_tr_b16 (nb_trread.h), staged once per workgroup and K chunk.  Same tile, same fused epilogue as the fp32 kernel.
+__global__ __launch_bounds__(256) void gemm_rows16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+                                                          long long R, int K, int N, float alpha, float beta, float *__restrict__ C,
+                                                          int ldc, const float *__restrict__ mask_y, int ldy,
+                                                          float *__restrict__ colsum) {
+    constexpr int KC = 32;
+    __shared__ __attribute__((aligned(16))) char bs[2][2 * TN16_PLANE];  // [buffer][head plane | remainder plane], 32 rows of pitch TN16_P
+    __shared__ float cs_lds[128];
+    if (threadIdx.x < 128) cs_lds[threadIdx.x] = 0.f;
+    const int tid = threadIdx.x, lane = tid & 63, i = lane & 31, kk = lane >> 5, wave = tid >> 6;
+    const long long row0 = ((long long)blockIdx.x * 4 + wave) * 32;
+    const int col0 = blockIdx.y * 128;
+    const long long arow = min(row0 + i, R - 1);  // rows past the end compute values that are never stored
+    const float *ap = A + arow * lda;
+    f32x16_ acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // cooperative load of one B chunk: 32 x 128 floats: thread -> (k = tid / 8, 16 consecutive columns)
+    const int sr = tid >> 3, sp = tid & 7;
+    f32x4 breg[4];
+    auto load_b = [&](int k0) {
+        const float *bp = B + (size_t)(k0 + sr) * ldb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int col = col0 + sp * 16 + 4 * q;
+            if (col + 3 < N) breg[q] = *reinterpret_cast<const f32x4 *>(bp + col);  // ldb % 4 == 0 and col0 % 4 == 0 on this path
+            else breg[q] = f32x4{col < N ? bp[col] : 0.f, col + 1 < N ? bp[col + 1] : 0.f, col + 2 < N ? bp[col + 2] : 0.f, 0.f};
+        }
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v[4] = {breg[q].x, breg[q].y, breg[q].z, breg[q].w};
+            unsigned short h[4], l[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nbtr::split_bf16(v[e], h[e], l[e]);
+            const int cb = (sp * 16 + 4 * q) * 2;
+            *reinterpret_cast<uint2 *>(bs[buf] + sr * TN16_P + cb) = uint2{h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16)};
+            *reinterpret_cast<uint2 *>(bs[buf] + TN16_PLANE + sr * TN16_P + cb) = uint2{l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16)};
+        }
+    };
+    // this lane's A values of one chunk: K = 16 kc + 8 kk + 0..7, kc = 0, 1
+    f32x4 a[4];
+    auto load_a = [&](int k0, f32x4 (&d)[4]) {
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            d[2 * kc] = *reinterpret_cast<const f32x4 *>(ap + k0 + 16 * kc + 8 * kk);
+            d[2 * kc + 1] = *reinterpret_cast<const f32x4 *>(ap + k0 + 16 * kc + 8 * kk + 4);
+        }
+    };
+    auto split8 = [&](const f32x4 lo4, const f32x4 hi4, nbtr::bf8 &h, nbtr::bf8 &l) {
+        const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+        nbtr::s8 hs, ls;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            unsigned short hh, ll;
+            nbtr::split_bf16(v[e], hh, ll);
+            hs[e] = (short)hh;
+            ls[e] = (short)ll;
+        }
+        h = __builtin_bit_cast(nbtr::bf8, hs);
+        l = __builtin_bit_cast(nbtr::bf8, ls);
+    };
+    const unsigned bs0 = (unsigned)(size_t)&bs[0][0], loff = nbtr::lane_offset(lane, TN16_P);
+    load_b(0);
+    load_a(0, a);
+    store_b(0);
+    __syncthreads();
+    const int nchunk = K / KC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        f32x4 an[4] = {a[0], a[1], a[2], a[3]};
+        if (ch + 1 < nchunk) {
+            load_b((ch + 1) * KC);
+            load_a((ch + 1) * KC, an);
+        }
+        const unsigned base = bs0 + buf * (2 * TN16_PLANE) + loff;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            nbtr::bf8 ah, al, bh[4], bl[4];
+            split8(a[2 * kc], a[2 * kc + 1], ah, al);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned bd = base + kc * 16 * TN16_P + (t * 32) * 2;
+                bh[t] = nbtr::frag(bd, bd + 4 * TN16_P);
+                bl[t] = nbtr::frag(bd + TN16_PLANE, bd + TN16_PLANE + 4 * TN16_P);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bh[0]), "+v"(bl[0]), "+v"(bh[1]), "+v"(bl[1]), "+v"(bh[2]), "+v"(bl[2]), "+v"(bh[3]), "+v"(bl[3]));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[t], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[t], acc[t], 0, 0, 0);
+            }
+        }
+        if (ch + 1 < nchunk) store_b(buf ^ 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = an[c];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int col = col0 + 32 * t + i;
+        if (col >= N || row0 >= R) continue;
+        float cs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = row0 + tn_tile_row(r, kk);
+            if (row >= R) continue;
+            float v = alpha * acc[t][r];
+            float *cp = C + row * ldc + col;
+            if (beta != 0.f) v += beta * *cp;
+            if (mask_y && !(mask_y[row * ldy + col] > 0.f)) v = 0.f;
+            *cp = v;
+            cs += v;
+        }
+        if (colsum) atomicAdd(&cs_lds[32 * t + i], cs);
+    }
+    if (colsum) {
+        __syncthreads();
+        if (threadIdx.x < 128 && col0 + (int)threadIdx.x < N) atomicAdd(&colsum[col0 + threadIdx.x], cs_lds[threadIdx.x]);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -572,6 +701,13 @@ int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, flo
     // k == 0 (an empty product: C = beta C, then the epilogue) goes to the general kernel, whose loop is guarded; the fast
     // kernel pre-loads its first operand panels before looking at k
     const bool aligned = k > 0 && k % 16 == 0 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ldb % 4 == 0 && ((uintptr_t)b % 16) == 0;
+    // the MLP backward's dX products (thousands of rows, K a multiple of 32, op(B) = B): bf16 pairs on the 16-bit matrix pipe
+    if (aligned && !trans_b && k % 32 == 0 && m >= 1024) {
+        hipLaunchKernelGGL(gemm_rows16_kernel, grid, block, 0, st, a, lda, b, ldb, (long long)m, k, n, alpha, beta, c, ldc, mask_y, ldy,
+                           colsum);
+        NB_CHECK_LAUNCH("gemm_rows16_kernel");
+        return NB_OK;
+    }
     if (aligned && trans_b)
         hipLaunchKernelGGL((gemm_rows_fast_kernel<true>), grid, block, 0, st, a, lda, b, ldb, (long long)m, k, n, alpha, beta, c, ldc, mask_y, ldy, colsum);
     else if (aligned)

@@ -121,6 +121,24 @@ def test_sgemm_relu_colsum():
     ops.sgemm(wa[:, 8:354], wb[:, 4:260], trans_a=True, out=acc2[:, 20:276], alpha=0.5, beta=1.0)
     np.testing.assert_allclose(acc2[:, 20:276].cpu().numpy(), (0.25 + 0.5 * ref).cpu().numpy(), rtol=1e-4, atol=4e-3)
     assert float(acc2[:, :20].min()) == 0.25 and float(acc2[:, 276:].max()) == 0.25
+    # dX shapes (thousands of rows, K a multiple of 32, aligned operands) take the 16-bit matrix pipe as well: bf16 pairs, the
+    # fused ReLU-mask / bias-gradient epilogue, accumulation, ragged N and a row count that is not a multiple of 128
+    for (m, k, n) in ((2050, 256, 352), (1100, 128, 260), (4096, 384, 128)):
+        A = torch.from_numpy(rs.standard_normal((m, k + 8)).astype(np.float32)).to(DEV)
+        Bm = torch.from_numpy(rs.standard_normal((k, n + 4)).astype(np.float32)).to(DEV)
+        Y = torch.from_numpy(rs.standard_normal((m, n + 7)).astype(np.float32)).to(DEV)
+        C0 = torch.from_numpy(rs.standard_normal((m, n + 8)).astype(np.float32)).to(DEV)
+        full = C0[:, 4:n + 4].double() + A[:, 4:k + 4].double() @ Bm[:, :n].double()
+        ref = full * (Y[:, 4:n + 4] > 0)
+        out = C0.clone()
+        cs = torch.full((n,), 0.25, device=DEV)
+        ops.sgemm(A[:, 4:k + 4], Bm[:, :n], out=out[:, 4:n + 4], beta=1.0, relu_mask=Y[:, 4:n + 4], colsum=cs)
+        scale = float(full.abs().max())
+        assert float((out[:, 4:n + 4].double() - ref).abs().max()) <= 3e-5 * scale, (m, k, n)
+        np.testing.assert_allclose(cs.cpu().numpy(), 0.25 + ref.sum(0).float().cpu().numpy(), rtol=1e-4, atol=3e-2)
+        assert torch.equal(out[:, :4], C0[:, :4]) and torch.equal(out[:, n + 4:], C0[:, n + 4:])
+        plain = ops.sgemm(A[:, 4:k + 4], Bm[:, :n])
+        assert float((plain.double() - A[:, 4:k + 4].double() @ Bm[:, :n].double()).abs().max()) <= 3e-5 * scale
     # k = 0: an empty product — C = beta C (+ the epilogue), in both forms (the fast kernel pre-loaded operand
     # panels before looking at k)
     c0 = torch.from_numpy(rs.standard_normal((128, 256)).astype(np.float32)).to(DEV)
