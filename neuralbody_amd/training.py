@@ -52,7 +52,9 @@ def decoder_backward(net, tap, d_raw, latent_index):
     g["view_fc.weight"] = gWv
     # dG = dV . W_view[:, :256]; column sums = latent_fc's bias gradient
     sum_dG = zeros(256)
-    dG = ops.sgemm(dV, Wv[:, 0:256], colsum=sum_dG)
+    # (a contiguous copy: rows of the [128, 346] weight are not 16-byte aligned, and the aligned kernels are 4x faster than the
+    # general one — one 128 KB copy against 180 us)
+    dG = ops.sgemm(dV, Wv[:, 0:256].contiguous(), colsum=sum_dG)
     # latent_fc on [feature_fc out | latent] (:106-111): feature_fc's output is recomputed from h3 (not in the tap)
     latent = net.latent.weight.detach().index_select(0, latent_index.reshape(-1)[:1].long())  # [1,128]
     feat = net.feature_fc.bias.detach()[None].expand(N, 256).contiguous()
