@@ -39,11 +39,29 @@ __global__ void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *
     double a = 0.0, b = 0.0;
     if (c < C) {
         const double mean = batch_stats[c], invstd = 1.0 / sqrt((double)batch_stats[C + c] + (double)eps);
-        for (long long r = r0 + w; r < r1; r += 4) {
-            const float g = y[r * C + c] > 0.f ? dy[r * C + c] : 0.f;
-            a += (double)g;
-            b += (double)g * (((double)x[r * C + c] - mean) * invstd);
+        // four rows per trip, their 12 loads issued together and four independent fp64 chains: the one-row loop ran at the
+        // latency of a load + two dependent fp64 adds per row (29 us per layer for 15-22 MB)
+        double a4[4] = {0.0, 0.0, 0.0, 0.0}, b4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (long long r = r0 + w; r < r1; r += 16) {
+            float yv[4], dv[4], xv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long long rr = r + 4 * q;
+                const bool ok = rr < r1;
+                const long long e = (ok ? rr : r) * C + c;
+                yv[q] = y[e];
+                dv[q] = ok ? dy[e] : 0.f;
+                xv[q] = x[e];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float g = yv[q] > 0.f ? dv[q] : 0.f;
+                a4[q] += (double)g;
+                b4[q] += (double)g * (((double)xv[q] - mean) * invstd);
+            }
         }
+        a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        b = (b4[0] + b4[1]) + (b4[2] + b4[3]);
     }
     pa[w][threadIdx.x & 63] = a;
     pb[w][threadIdx.x & 63] = b;
