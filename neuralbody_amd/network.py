@@ -363,23 +363,31 @@ class Network(nn.Module):
                          cull=cull)
 
     def _time_organisations(self, scene, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd, ray_order):
-        """One warm and two timed launches of each organisation of the f16f6 arithmetic on the caller's own rays (HIP events on
-        the current stream, one host wait: ~0.1 s, once per Network).  Both compute the same arithmetic with a different
+        """One warm and two timed launches of each organisation of the f16f6 arithmetic on the caller's own rays, the timed ones
+        alternating (HIP events on the current stream, one host wait: ~0.1 s, once per Network).  Both compute the same arithmetic with a different
         summation order (parity tests run both); which one is faster is a property of the box."""
         packed = self.packed_weights("f16f6")  # holds both weight streams
         saved, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None  # bench.py's per-launch events: not these
-        times = {}
+        orgs = ("f16f6", "f16f6r")
+        times = {org: 0.0 for org in orgs}
         try:
-            for org in ("f16f6", "f16f6r"):
-                kw = dict(white_bkgd=white_bkgd, precision=org, ray_order=ray_order)
-                ops.march(scene, packed, lb, ray_o, ray_d, near, far, t_vals, t_rand, **kw)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(2):
-                    ops.march(scene, packed, lb, ray_o, ray_d, near, far, t_vals, t_rand, **kw)
-                e1.record()
-                e1.synchronize()
-                times[org] = e0.elapsed_time(e1) / 2
+            def launch(org):
+                ops.march(scene, packed, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd=white_bkgd, precision=org,
+                          ray_order=ray_order)
+
+            for org in orgs:  # warm: code objects, clocks
+                launch(org)
+            spans = []
+            for _ in range(2):  # alternating, so that neither organisation is timed on the cooler chip
+                for org in orgs:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    launch(org)
+                    e1.record()
+                    spans.append((org, e0, e1))
+            spans[-1][2].synchronize()
+            for org, e0, e1 in spans:
+                times[org] += e0.elapsed_time(e1) / 2
         finally:
             ops.MARCH_EVENTS = saved
         self._auto_times = times
