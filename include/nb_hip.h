@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 16
+#define NB_ABI_VERSION 17
 
 /* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
@@ -49,6 +49,14 @@ extern "C" {
                              two workgroups per CU); a culled march (nb_cull) runs on NB_PREC_F16F6R's kernel.
                              Weight blocks whose elements span more than ~2^5 lose their small elements: see
                              nb_mlp_six_bit_stats_offset() */
+
+#define NB_PREC_F16F6V 5  /* nb_march / nb_decode_points: the NB_PREC_F16F6 arithmetic for fc_1 .. rgb_fc with fc_0 FOLDED INTO THE
+                             VOLUME: trilinear interpolation and fc_0 are both linear with nothing between them
+                             (latent_xyzc.py:62-72,99), so fc_0 . interp(V) = interp(fc_0 . V).  nb_fold_build stores
+                             U_l = fc_0[:, level l] . V_l per ACTIVE voxel (256 channels, fp16 head + fp16 remainder); the
+                             march fetches the rows of the voxels its 64 samples touch and contracts them with the sparse
+                             trilinear-weight matrix Wt [voxel x sample] on the matrix pipe (three fp16 products per K = 16
+                             voxels, products exact, fp32 accumulate: fp32-level accuracy).  Needs nb_scene.fold. */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */
@@ -69,6 +77,16 @@ int nb_device_count(void);
  * (lib/networks/latent_xyzc.py:30-39).  Volumes are CHANNELS-LAST: vol[l] is a dense
  * [D_l, H_l, W_l, C_l] fp32 array (C_l = 32, 64, 128, 128), zeros at inactive voxels.
  * ------------------------------------------------------------------------------- */
+/* fc_0 folded into the four latent volumes (NB_PREC_F16F6V), built by nb_fold_build from the SAME volumes and fc_0 weight:
+ * row r of level l = fc_0.weight[:, channels of level l] . V_l[voxel of row r]  (256 outputs) as 256 fp16 heads followed by 256
+ * fp16 remainders (1 KiB); grid[l] = index grid of the level ([D_l,H_l,W_l] int32: row id inside the level or -1 = no row). */
+typedef struct nb_fold {
+    const uint16_t *urows;            /* dev [(rows of all levels) + 1][512]; the extra last row is all zero */
+    const int32_t *grid[NB_N_LEVELS]; /* dev */
+    int32_t row_base[NB_N_LEVELS];    /* first row of each level inside urows */
+    int32_t zero_row;                 /* index of the all-zero row (inactive voxels, padding) */
+} nb_fold;
+
 typedef struct nb_scene {
     const float *vol[NB_N_LEVELS]; /* dev */
     int32_t vol_dhw[NB_N_LEVELS][3];
@@ -78,6 +96,7 @@ typedef struct nb_scene {
     const float *pose;
     float voxel_size[3]; /* cfg.voxel_size, dhw order (latent_xyzc.py:54) */
     int32_t out_sh[3];   /* full-resolution grid D,H,W (sp_input['out_sh']) */
+    const nb_fold *fold; /* HOST pointer or NULL; required by NB_PREC_F16F6V (which does not read vol[]) */
 } nb_scene;
 #define NB_POSE_FLOATS 15
 
@@ -121,13 +140,33 @@ int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream);
 #define NB_PACK_F16F6R 4 /* the ring-organised six-bit stream alone (NB_PACK_F16F6 includes it) */
 #define NB_PACK_F16F8 8
 #define NB_PACK_F16F6 16
-#define NB_PACK_ALL 31
+#define NB_PACK_F16F6V 32 /* the weight stream of NB_PREC_F16F6V (fc_1, fc_2, the folded colour head; fc_0 lives in nb_fold) */
+#define NB_PACK_ALL 63
 int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, void *stream);
 /* latent_row: dev pointer to latent.weight[latent_index] (128 floats);
  * out: dev, nb_mlp_latent_bias_size() floats = [256: bias of the merged feature_fc / latent_fc layer with the latent code
  * folded in | 128: bias of view_fc with that layer folded in as well (feature_fc, latent_fc and view_fc have no activation
  * between them, latent_xyzc.py:105-119; NB_PREC_F16F8 / NB_PREC_F16F6 run them as one layer)], MFMA fragment order. */
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * nb_fold_build — the encoder-side half of NB_PREC_F16F6V: replaces the first decoder layer's weight access in
+ * Network.calculate_density_color (lib/networks/latent_xyzc.py:99, `self.fc_0(features)`) together with the four
+ * F.grid_sample calls feeding it (:62-72), by pre-multiplying every ACTIVE voxel of the four volumes with fc_0.
+ *   vol[l] dev channels-last [D_l,H_l,W_l,C_l] fp32 (nb_scene.vol); rows_lin[l] dev [n_rows_max[l]] int32: linear voxel index
+ *   of each active row; n_rows[l] dev [1] int32 (device-side count, <= n_rows_max[l]); fc0_w dev [256,352] fp32 row-major;
+ *   urows dev [(sum of n_rows_max) + 1][512] uint16: level l's rows start at row sum_{k<l} n_rows_max[k]; the last row is
+ *   zero-filled by the call.  Exact fp32 products (v_mfma_f32_32x32x2_f32), then head = fp16(u), remainder = fp16(u - head).
+ * nb_sparsify — active set of a DENSE volume that did not come with one (volumes handed to Network.calculate_density_color by a
+ * caller other than encode_sparse_voxels): a voxel is active iff any channel is non-zero.  grid dev [D*H*W] int32 out (row id
+ * or -1), rows_lin dev [n_rows_max] out (linear-voxel order), n_rows dev [1] out (clamped to n_rows_max; rows beyond it are
+ * dropped: size n_rows_max = D*H*W to be safe); scratch dev nb_scan_scratch_size(D*H*W) bytes.
+ * ------------------------------------------------------------------------------- */
+int nb_fold_build(const float *const vol[NB_N_LEVELS], const int32_t *const rows_lin[NB_N_LEVELS],
+                  const int32_t *const n_rows[NB_N_LEVELS], const int32_t n_rows_max[NB_N_LEVELS], const float *fc0_w,
+                  uint16_t *urows, void *stream);
+int nb_sparsify(const float *vol, const int32_t dhw[3], int32_t c, int32_t *grid, int32_t *rows_lin, int32_t *n_rows,
+                int32_t n_rows_max, void *scratch, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * nb_decode_points — replaces Network.calculate_density_color

@@ -9,9 +9,18 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 16
-PRECISIONS = {"f32": 0, "bf16x3": 1, "f16f6r": 2, "f16f8": 3, "f16f6": 4}
-PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "f16f6r": 4, "f16f8": 8, "f16f6": 16}
+ABI_VERSION = 17
+PRECISIONS = {"f32": 0, "bf16x3": 1, "f16f6r": 2, "f16f8": 3, "f16f6": 4, "f16f6v": 5}
+PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "f16f6r": 4, "f16f8": 8, "f16f6": 16, "f16f6v": 32}
+
+
+class NbFold(C.Structure):
+    _fields_ = [
+        ("urows", C.c_void_p),                 # dev [(rows + 1), 512] uint16: fp16 heads | remainders of fc_0 . V per active voxel
+        ("grid", C.c_void_p * NB_N_LEVELS),    # dev index grids (row id inside the level or -1)
+        ("row_base", C.c_int32 * NB_N_LEVELS),
+        ("zero_row", C.c_int32),
+    ]
 
 
 class NbScene(C.Structure):
@@ -21,6 +30,7 @@ class NbScene(C.Structure):
         ("pose", C.c_void_p),  # dev: R[9] | Th[3] | bounds_min[3]
         ("voxel_size", C.c_float * 3),
         ("out_sh", C.c_int32 * 3),
+        ("fold", C.POINTER(NbFold)),  # host pointer or NULL
     ]
 
 
@@ -57,6 +67,8 @@ SIGNATURES = {
     "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
     "nb_mlp_pack_sections": (C.c_int, [C.POINTER(NbMlpParams), _P, C.c_int, _P]),
     "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),
+    "nb_fold_build": (C.c_int, [C.c_void_p * 4, C.c_void_p * 4, C.c_void_p * 4, C.c_int32 * 4, _P, _P, _P]),
+    "nb_sparsify": (C.c_int, [_P, _I32x3, _I32, _P, _P, _P, _I32, _P, _P]),
     "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
     "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.POINTER(NbCull), C.c_int,
                            _P, _P, _P, _P, _P, _P, C.c_int, _P]),

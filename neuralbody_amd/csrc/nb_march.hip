@@ -431,7 +431,8 @@ extern "C" {
 static long long ms6_stream_off() { return PACK_SIZE + nbm::bf16_stream_floats(); }
 static long long f16_stream_off() { return ms6_stream_off() + nbm::ms6_stream_floats(); }
 static long long f6_stream_off() { return f16_stream_off() + nbm::f16_stream_floats(); }
-int64_t nb_mlp_pack_size(void) { return f6_stream_off() + nbm::f6_stream_floats(); }
+static long long fold_stream_off() { return f6_stream_off() + nbm::f6_stream_floats(); }
+int64_t nb_mlp_pack_size(void) { return fold_stream_off() + nbm::fold_stream_floats(); }
 int64_t nb_mlp_latent_bias_size(void) { return 384; }
 int64_t nb_mlp_six_bit_stats_offset(void) { return f6_stream_off() + nbm::f6_stream_floats() - 16; }
 
@@ -463,6 +464,8 @@ int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, vo
     // the ring-organised six-bit stream: NB_PREC_F16F6R, culled marches of NB_PREC_F16F6, and the small-element statistic
     if (sections & (NB_PACK_F16F6 | NB_PACK_F16F6R))
         if (int rc = nbm::pack_f6_stream(p, packed, f6_stream_off(), (hipStream_t)stream)) return rc;
+    if (sections & NB_PACK_F16F6V)
+        if (int rc = nbm::pack_fold_stream(p, packed, fold_stream_off(), (hipStream_t)stream)) return rc;
     return NB_OK;
 }
 
@@ -482,9 +485,10 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
     if (n == 0) return NB_OK;
     NB_REQUIRE(wpts && raw_out, "nb_decode_points: NULL wpts / raw_out");
     NB_REQUIRE(density_only || (viewdir && latent_bias), "nb_decode_points: viewdir / latent_bias required");
-    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_F16F6, "nb_decode_points: precision %d",
-               precision);
-    NB_REQUIRE(!(dbg && precision == NB_PREC_F16F6), "nb_decode_points: NB_PREC_F16F6 has no activation tap (use NB_PREC_F32)");
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6V,
+               "nb_decode_points: precision %d", precision);
+    NB_REQUIRE(!(dbg && (precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6V)),
+               "nb_decode_points: NB_PREC_F16F6 / NB_PREC_F16F6V have no activation tap (use NB_PREC_F32)");
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
     a.pk = packed;
@@ -496,6 +500,10 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
     a.dbg = dbg;
     const dim3 grid(nb_ceil_div(n, 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (precision == NB_PREC_F16F6V) {
+        if (int rc = fill_fold(scene, &a.fold)) return rc;
+        return nbm::launch_points_fold(a, density_only, fold_stream_off(), st);
+    }
     if (precision == NB_PREC_F16F6) return nbm::launch_points_ms6(a, density_only, ms6_stream_off(), st);
     if (precision == NB_PREC_BF16X3) {
         if (!a.lb) a.lb = packed + OFF_B2;  // density only: the (unused) colour head still needs a readable bias
@@ -525,8 +533,13 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
                     white_bkgd,
                     rgb_map, disp_map, acc_map, weights, depth_map, raw);
     NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_F16F6R || precision == NB_PREC_F16F8 ||
-                   precision == NB_PREC_F16F6,
+                   precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6V,
                "nb_march: precision %d", precision);
+    if (precision == NB_PREC_F16F6V) {
+        NB_REQUIRE(!a.cull.n_views, "nb_march: NB_PREC_F16F6V has no sample culling yet (use NB_PREC_F16F6R)");
+        if (int rc = fill_fold(scene, &a.fold)) return rc;
+        return nbm::launch_march_fold(a, fold_stream_off(), (hipStream_t)stream);
+    }
     if (precision == NB_PREC_F16F8) return nbm::launch_march_f16(a, f16_stream_off(), (hipStream_t)stream);
     // the M-split kernel has no sample culling: culled marches take the ring kernel (same arithmetic, same packed section)
     if (precision == NB_PREC_F16F6 && !a.cull.n_views) return nbm::launch_march_ms6(a, ms6_stream_off(), (hipStream_t)stream);

@@ -84,6 +84,14 @@ struct SceneDev {
                                  // them itself keeps the results in VGPRs across its depth loop)
 };
 
+// fc_0 folded into the volumes (nb_fold, NB_PREC_F16F6V): rows of 256 fp16 heads + 256 fp16 remainders, index grids
+struct FoldDev {
+    const char *urows;
+    const int *grid[4];
+    int row_base[4];
+    unsigned zero_off;  // byte offset of the all-zero row
+};
+
 // sample culling against training-view silhouettes (nb_cull): the reference's fp32 operation order
 struct CullDev {
     int n_views, H, W, pre;
@@ -136,6 +144,7 @@ __device__ __forceinline__ bool cull_inside(const CullDev &c, const SceneDev &sc
 struct MarchArgs {
     SceneDev sc;
     CullDev cull;
+    FoldDev fold;
     const float *pk;  // packed decoder weights (format depends on the kernel family)
     const float *lb;
     // ray mode
@@ -617,7 +626,7 @@ struct WeightStore {
 
 inline int fill_scene(const nb_scene *s, SceneDev *d) {
     for (int l = 0; l < 4; ++l) {
-        NB_REQUIRE(s->vol[l] != nullptr, "nb_scene.vol[%d] is NULL", l);
+        NB_REQUIRE(s->vol[l] != nullptr || s->fold != nullptr, "nb_scene.vol[%d] is NULL", l);
         d->vol[l] = s->vol[l];
         for (int k = 0; k < 3; ++k) {
             NB_REQUIRE(s->vol_dhw[l][k] >= 1, "nb_scene.vol_dhw[%d][%d] = %d", l, k, s->vol_dhw[l][k]);
@@ -636,6 +645,22 @@ inline int fill_scene(const nb_scene *s, SceneDev *d) {
     return NB_OK;
 }
 
+
+// fold != NULL is required (and checked) by the kernels that read it only
+inline int fill_fold(const nb_scene *s, FoldDev *d) {
+    const nb_fold *f = s->fold;
+    NB_REQUIRE(f != nullptr, "nb_scene.fold is NULL: NB_PREC_F16F6V marches the fc_0-folded planes of nb_fold_build");
+    NB_REQUIRE(f->urows != nullptr && f->zero_row >= 0 && f->zero_row < (1 << 21), "nb_fold: urows NULL or zero_row %d out of range",
+               f->zero_row);
+    d->urows = reinterpret_cast<const char *>(f->urows);
+    for (int l = 0; l < 4; ++l) {
+        NB_REQUIRE(f->grid[l] != nullptr && f->row_base[l] >= 0 && f->row_base[l] <= f->zero_row, "nb_fold: level %d", l);
+        d->grid[l] = f->grid[l];
+        d->row_base[l] = f->row_base[l];
+    }
+    d->zero_off = (unsigned)f->zero_row * 1024u;
+    return NB_OK;
+}
 
 inline int fill_cull(const nb_cull *c, CullDev *d) {
     d->n_views = 0;
@@ -690,6 +715,11 @@ long long ms6_stream_floats();
 int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
 int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st);
 int launch_points_ms6(MarchArgs a, int density_only, long long stream_off, hipStream_t st);
+// fc_0 folded into the volumes, fp16 + scaled-6-bit for the remaining layers (nb_march_fold.hip)
+long long fold_stream_floats();
+int pack_fold_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
+int launch_march_fold(MarchArgs a, long long stream_off, hipStream_t st);
+int launch_points_fold(MarchArgs a, int density_only, long long stream_off, hipStream_t st);
 // fp16 + scaled-8-bit march (nb_march_f16.hip)
 long long f16_stream_floats();
 int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);

@@ -40,6 +40,19 @@ AUTO_TUNE_MIN_RAYS = 1 << 17
 AUTO_TUNE = os.environ.get("NB_AUTO_TUNE", "1") != "0"
 
 
+class FeatureVolumes(list):
+    """The four volumes of `Network.encode_sparse_voxels` ([1,C,D,H,W] views of channels-last storage, as the reference
+    returns them) together with the index structures they were scattered from: `sparse[l]` = (index grid [D,H,W] int32, linear
+    voxel index of every active row, device-side row count [1], row capacity).  Precision 'f16f6v' builds its fc_0-folded
+    planes from them (`fold`: (fc_0 weight key, ops.fold_build result), rebuilt when the weight changes); a plain list of
+    volumes from elsewhere gets its active set from ops.sparsify."""
+
+    def __init__(self, volumes, sparse=None):
+        super().__init__(volumes)
+        self.sparse = sparse
+        self.fold = None
+
+
 class SparseConv3dParam(nn.Module):
     """Holds the weight of one SubMConv3d / SparseConv3d in spconv 1.x layout [kD,kH,kW,Cin,Cout]
     (bias=False).  The convolution itself runs in nb_enc_conv."""
@@ -93,6 +106,7 @@ class SparseConvNet(nn.Module):
         if save is not None:
             save.append({"rows_vert": rows_vert, "n_rows": n_rows, "n_max": n_max})
         volumes = []
+        sparse = []  # per volume: (index grid, rows_lin, n_rows, capacity) of the rows it was scattered from
         bn_updates = []
         # Convolutions with >= 32 input channels run on the 16-bit matrix pipe with split operands (ops.enc_conv16, three
         # products, fp32 accumulation: ~2^-21 relative per product); their input rows arrive as fp16 head / remainder planes
@@ -121,6 +135,7 @@ class SparseConvNet(nn.Module):
             if name in DENSE_AFTER and j == n - 1:
                 dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
                 volumes.append(dense)
+                sparse.append((out_grid, out_lin, n_out, n_out_max))
             next_split = fast and li + 1 < len(layers) and cout >= 32  # the consumer of these rows is an enc_conv16
             act = torch.empty_like(new_rows) if save is not None else None  # keep the raw conv output when saving
             split = None
@@ -146,7 +161,7 @@ class SparseConvNet(nn.Module):
             rows_are_split = next_split
         if training:
             torch._foreach_add_(bn_updates, 1)  # nn.BatchNorm1d bookkeeping, one fused launch
-        return volumes
+        return FeatureVolumes(volumes, sparse)
 
 
 _MLP_NAMES = {"fc0": "fc_0", "fc1": "fc_1", "fc2": "fc_2", "alpha": "alpha_fc", "feature": "feature_fc",
@@ -159,8 +174,8 @@ class Network(nn.Module):
         # decoder GEMM arithmetic: "bf16x3" (split-bf16 MFMA, 3 products, fp32 accumulate) or "f32" (exact
         # fp32 MFMA); both stay inside the 1e-4 RGB parity budget, see DESIGN.md
         self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
-        if self.precision not in ("auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6"):
-            raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'f16f6r', 'f16f8' or 'f16f6'")
+        if self.precision not in ("auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6", "f16f6v"):
+            raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'f16f6r', 'f16f8', 'f16f6' or 'f16f6v'")
         self._auto = None  # (weight key, chosen arithmetic) of precision 'auto'
         self._lb_cache = None  # (latent_index tensor, versions, bias) of latent_bias()
         self._auto_org = None  # 'f16f6' / 'f16f6r': the measured choice of precision 'auto' (None: not measured yet)
@@ -217,7 +232,7 @@ class Network(nn.Module):
         RendererMesh): exact fp32, split bf16, or — the default — the march's f16f6 arithmetic on the same M-split kernel
         (every point a one-sample ray).  'f16f8' and 'f16f6r' exist as march organisations only: their points take split bf16,
         and so do the points of an 'auto' network whose weights made the march fall back to 'f16f8'."""
-        if self.precision in ("f32", "bf16x3", "f16f6"):
+        if self.precision in ("f32", "bf16x3", "f16f6", "f16f6v"):
             return self.precision
         if self.precision == "auto":
             return "f16f6" if self.march_precision() == "f16f6" else "bf16x3"
@@ -289,10 +304,12 @@ class Network(nn.Module):
         return lb
 
     # ------------------------------------------------------------------ scene description
-    def make_scene(self, feature_volume, sp_input):
+    def make_scene(self, feature_volume, sp_input, precision=None):
         """nb_scene of one frame.  R / Th / bounds stay on the device (ops.make_pose packs them into the 15-float
         block the kernels read): no host copy, no sync and — unlike round 1's address-keyed host cache — nothing
-        that could hand frame k+1 the pose of frame k when the allocator recycles the batch's addresses."""
+        that could hand frame k+1 the pose of frame k when the allocator recycles the batch's addresses.
+        precision 'f16f6v' marches the fc_0-folded planes of the volumes (ops.fold_build): built once per (volumes, fc_0
+        weight version) and kept on the FeatureVolumes object."""
         vols = []
         for v in feature_volume:
             vols.append(v if v.dim() == 4 else ops.volume_as_channels_last(v))
@@ -300,7 +317,20 @@ class Network(nn.Module):
         if R.numel() != 9 or bounds.numel() != 6:
             raise NotImplementedError("batch size 1 only (train.batch_size / test batch are 1 in every shipped config)")
         out_sh = [int(s) for s in sp_input["out_sh"]]
-        return ops.make_scene(vols, ops.make_pose(R, Th, bounds, device=vols[0].device), self.voxel_size, out_sh)
+        fold = self._fold_planes(feature_volume, vols) if precision == "f16f6v" else None
+        return ops.make_scene(vols, ops.make_pose(R, Th, bounds, device=vols[0].device), self.voxel_size, out_sh, fold=fold)
+
+    def _fold_planes(self, feature_volume, vols):
+        w = self.fc_0.weight.detach()
+        key = (w.data_ptr(), w._version)
+        fv = feature_volume if isinstance(feature_volume, FeatureVolumes) else None
+        if fv is not None and fv.fold is not None and fv.fold[0] == key and fv.fold[1] is w.untyped_storage():
+            return fv.fold[2]
+        sparse = fv.sparse if fv is not None and fv.sparse is not None else [ops.sparsify(v) for v in vols]
+        fold = ops.fold_build(vols, sparse, w)
+        if fv is not None:
+            fv.fold = (key, w.untyped_storage(), fold)  # holds the storage: its address cannot be recycled under the key
+        return fold
 
     # ------------------------------------------------------------------ reference API
     def encode_sparse_voxels(self, sp_input, save=None):
@@ -313,12 +343,12 @@ class Network(nn.Module):
         codes = self.c.weight.detach()
         vols = self.xyzc_net(codes, coord, sp_input["out_sh"], self.training, save)
         # logical layout [1,C,D,H,W] like spconv's .dense(); storage stays channels-last
-        return [v.permute(3, 0, 1, 2)[None] for v in vols]
+        return FeatureVolumes([v.permute(3, 0, 1, 2)[None] for v in vols], vols.sparse)
 
     def calculate_density(self, wpts, feature_volume, sp_input):
         if wpts.shape[0] != 1:
             raise NotImplementedError("batch size 1 only")
-        scene = self.make_scene(feature_volume, sp_input)
+        scene = self.make_scene(feature_volume, sp_input, self._point_precision())
         p = wpts.reshape(-1, 3).float().contiguous()
         out = ops.decode_points(scene, self.packed_weights(self._point_precision()), None, p, None, density_only=True,
                                 precision=self._point_precision())
@@ -327,7 +357,7 @@ class Network(nn.Module):
     def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
         if wpts.shape[0] != 1:
             raise NotImplementedError("batch size 1 only")
-        scene = self.make_scene(feature_volume, sp_input)
+        scene = self.make_scene(feature_volume, sp_input, self._point_precision())
         p = wpts.reshape(-1, 3).float().contiguous()
         v = viewdir.reshape(-1, 3).float().contiguous()
         lb = self.latent_bias(sp_input["latent_index"])
@@ -346,14 +376,16 @@ class Network(nn.Module):
     def render_rays(self, ray_o, ray_d, near, far, feature_volume, sp_input, n_samples, t_rand=None,
                     white_bkgd=False, want_raw=False, ray_order=None, cull=None):
         """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
-        scene = self.make_scene(feature_volume, sp_input)
+        prec = self.march_precision()
+        if cull is not None and prec == "f16f6v":
+            prec = "f16f6r"  # sample culling: the ring kernel (same arithmetic behind fc_0)
+        scene = self.make_scene(feature_volume, sp_input, prec)
         lb = self.latent_bias(sp_input["latent_index"])
         key = (int(n_samples), str(ray_o.device))  # a constant of (S, device), not of the frame
         t_vals = self._t_vals.get(key)
         if t_vals is None:
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._t_vals[key] = t_vals
-        prec = self.march_precision()
         if (self.precision == "auto" and prec == "f16f6" and self._auto_org is None and AUTO_TUNE and cull is None
                 and ray_o.shape[0] >= AUTO_TUNE_MIN_RAYS):
             prec = self._auto_org = self._time_organisations(scene, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd,

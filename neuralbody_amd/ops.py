@@ -6,7 +6,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import NbCull, NbError, NbMlpParams, NbScene, check, ptr
+from ._lib import NbCull, NbError, NbFold, NbMlpParams, NbScene, check, ptr
 
 LEVEL_CHANNELS = (32, 64, 128, 128)
 DBG_WIDTH = 1600
@@ -64,9 +64,60 @@ def make_pose(R, Th, bounds, device=None):
     return _req(pose, torch.float32, (15,), "pose")
 
 
-def make_scene(volumes_cl, pose, voxel_size, out_sh):
+def sparsify(volume_cl):
+    """nb_sparsify: active set of a dense channels-last volume [D,H,W,C] that came without one -> (grid [D,H,W] int32,
+    rows_lin [cap] int32, n_rows [1] int32, cap).  Capacity = every voxel (no device -> host read)."""
+    _req(volume_cl, torch.float32, (None, None, None, None), "volume")
+    dhw = [int(v) for v in volume_cl.shape[:3]]
+    nvox = dhw[0] * dhw[1] * dhw[2]
+    dev = volume_cl.device
+    grid = torch.empty(dhw, dtype=torch.int32, device=dev)
+    buf = torch.zeros(nvox + 1, dtype=torch.int32, device=dev)
+    rows_lin, n_rows = buf[:nvox], buf[nvox:]
+    scratch = scan_scratch(nvox, dev)
+    check(_lib.lib().nb_sparsify(ptr(volume_cl), _i3(dhw), int(volume_cl.shape[3]), ptr(grid), ptr(rows_lin), ptr(n_rows),
+                                 nvox, ptr(scratch), _stream()), "nb_sparsify")
+    return grid, rows_lin, n_rows, nvox
+
+
+def fold_build(volumes_cl, sparse, fc0_w):
+    """nb_fold_build: the fc_0-folded planes of one frame (precision 'f16f6v').  volumes_cl: the four channels-last
+    volumes; sparse: per level (grid, rows_lin, n_rows[1], n_rows_max) — the encoder's index structures, or `sparsify`'s;
+    fc0_w [256,352(,1)].  Returns (NbFold, keepalive)."""
+    if fc0_w.dim() == 3:
+        fc0_w = fc0_w[:, :, 0]
+    fc0_w = fc0_w.detach()
+    if not fc0_w.is_contiguous():
+        fc0_w = fc0_w.contiguous()
+    _req(fc0_w, torch.float32, (256, 352), "fc0_w")
+    v4, l4, n4, caps = (C.c_void_p * 4)(), (C.c_void_p * 4)(), (C.c_void_p * 4)(), (C.c_int32 * 4)()
+    f = NbFold()
+    base = 0
+    for l, (v, (grid, rows_lin, n_rows, cap)) in enumerate(zip(volumes_cl, sparse)):
+        _req(v, torch.float32, (None, None, None, LEVEL_CHANNELS[l]), "volume[%d]" % l)
+        _req(grid, torch.int32, tuple(int(x) for x in v.shape[:3]), "grid[%d]" % l)
+        _req(rows_lin, torch.int32, (None,), "rows_lin[%d]" % l)
+        _req(n_rows, torch.int32, (1,), "n_rows[%d]" % l)
+        cap = max(int(cap), 1)
+        if rows_lin.shape[0] < cap:
+            raise ValueError("rows_lin[%d] shorter than its capacity" % l)
+        v4[l], l4[l], n4[l], caps[l] = v.data_ptr(), rows_lin.data_ptr(), n_rows.data_ptr(), cap
+        f.grid[l] = grid.data_ptr()
+        f.row_base[l] = base
+        base += cap
+    if base >= (1 << 21):
+        raise ValueError("fold_build: %d rows exceed the 2 GiB plane the march addresses with 32-bit offsets" % base)
+    urows = torch.empty((base + 1, 512), dtype=torch.int16, device=volumes_cl[0].device)
+    f.urows = urows.data_ptr()
+    f.zero_row = base
+    check(_lib.lib().nb_fold_build(v4, l4, n4, caps, ptr(fc0_w), ptr(urows), _stream()), "nb_fold_build")
+    return f, [urows, fc0_w] + [t for sp in sparse for t in sp[:3]]
+
+
+def make_scene(volumes_cl, pose, voxel_size, out_sh, fold=None):
     """volumes_cl: four contiguous [D,H,W,C] fp32 device tensors; pose: the 15-float DEVICE block of make_pose;
-    voxel_size (3, dhw) and out_sh (3) are HOST sequences.  Returns (NbScene, keepalive)."""
+    voxel_size (3, dhw) and out_sh (3) are HOST sequences; fold: `fold_build`'s result (precision 'f16f6v').
+    Returns (NbScene, keepalive)."""
     sc = NbScene()
     if len(volumes_cl) != 4:
         raise ValueError("expected 4 feature volumes")
@@ -80,7 +131,11 @@ def make_scene(volumes_cl, pose, voxel_size, out_sh):
     for k in range(3):
         sc.voxel_size[k] = float(voxel_size[k])
         sc.out_sh[k] = int(out_sh[k])
-    return sc, list(volumes_cl) + [pose]
+    keep = list(volumes_cl) + [pose]
+    if fold is not None:
+        sc.fold = C.pointer(fold[0])
+        keep += [fold[0]] + list(fold[1])
+    return sc, keep
 
 
 def mlp_pack_size():

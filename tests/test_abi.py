@@ -21,12 +21,12 @@ def test_library_exports_every_header_symbol(lib):
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.nb_abi_version() == _lib.ABI_VERSION == 16
+    assert lib.nb_abi_version() == _lib.ABI_VERSION == 17
 
 
 def test_sizes_and_struct_layout(lib):
     # 8*44*256 + 256 + 2*(8*32*256 + 256) + 256 + 4 + 8*32*256 + 4*44*256 + 128 + 384 + 4
-    assert lib.nb_mlp_pack_size() == 333320 + 650 * 2048 // 4 + 4 * 272 * 1024 // 4 + 2 * (540 * 2048 // 4 + 16)  # fp32 fragments + bf16 ring stream + M-split f16f6 streams + ring f16f8 and f16f6 streams with their scale words
+    assert lib.nb_mlp_pack_size() == 333320 + 650 * 2048 // 4 + 4 * 272 * 1024 // 4 + 2 * (540 * 2048 // 4 + 16) + 4 * 176 * 1024 // 4  # fp32 fragments + bf16 ring stream + M-split f16f6 streams + ring f16f8 and f16f6 streams with their scale words + the fc_0-folded kernel's stream
     assert lib.nb_mlp_latent_bias_size() == 384
     assert C.sizeof(_lib.NbMlpParams) == 16 * 8
     assert lib.nb_scan_scratch_size(0) >= 256 and lib.nb_scan_scratch_size(1 << 20) >= 2 * 4 * (1 << 20)
@@ -42,15 +42,17 @@ def test_ctypes_structs_match_the_header_compiled_by_gcc(tmp_path):
     src = tmp_path / "layout.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "nb_hip.h"\n'
-        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nb_scene), offsetof(nb_scene, vol_dhw), '
+        'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(nb_scene), offsetof(nb_scene, vol_dhw), '
         'offsetof(nb_scene, pose), offsetof(nb_scene, voxel_size), offsetof(nb_scene, out_sh), sizeof(nb_cull), '
-        'offsetof(nb_cull, msk), offsetof(nb_cull, cam), offsetof(nb_cull, snap), sizeof(nb_mlp_params)); return 0; }\n')
+        'offsetof(nb_cull, msk), offsetof(nb_cull, cam), offsetof(nb_cull, snap), sizeof(nb_mlp_params), offsetof(nb_scene, fold), '
+        'sizeof(nb_fold), offsetof(nb_fold, grid), offsetof(nb_fold, row_base), offsetof(nb_fold, zero_row)); return 0; }\n')
     exe = tmp_path / "layout"
     subprocess.check_call([gcc, "-I", os.path.dirname(_lib.HEADER), str(src), "-o", str(exe)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    S, K = _lib.NbScene, _lib.NbCull
+    S, K, F = _lib.NbScene, _lib.NbCull, _lib.NbFold
     want = [C.sizeof(S), S.vol_dhw.offset, S.pose.offset, S.voxel_size.offset, S.out_sh.offset, C.sizeof(K), K.msk.offset,
-            K.cam.offset, K.snap.offset, C.sizeof(_lib.NbMlpParams)]
+            K.cam.offset, K.snap.offset, C.sizeof(_lib.NbMlpParams), S.fold.offset, C.sizeof(F), F.grid.offset,
+            F.row_base.offset, F.zero_row.offset]
     assert got == want, (got, want)
 
 
