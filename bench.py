@@ -58,6 +58,9 @@ PRECISION_INFO = {
     # the same arithmetic, M-split workgroups (round 3, the default and the kernel behind nb_decode_points): 4 waves x 408
     # MFMAs per 64 samples (fc_0's K padded to 384, the encodings' to 128)
     "f16f6": ("f16+f6", "nb_march_ms6_kernel", 4 * 408 * 32768 / 64.0, 2500.0),
+    # round 4: fc_0 folded into the volume.  Per wave and depth step of 64 samples: fc_1 96, fc_2 96, the folded colour head 48,
+    # the encodings 24 MFMAs, and 12 per 16 voxels of the step's voxel list (59 voxels = 4.2 chunks on average on the bench view)
+    "f16f6v": ("f16+f6", "nb_march_fold_kernel", 4 * (264 + 12 * 4.2) * 32768 / 64.0, 2500.0),
 }
 
 
@@ -328,7 +331,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--precision", default=None, choices=[None, "auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6"])
+    ap.add_argument("--precision", default=None, choices=[None, "auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6", "f16f6v"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one view per GPU per step (views shard with no collective but the tile all-gather); "
                          "strong: one view per step, its rays split over the GPUs")
@@ -431,7 +434,7 @@ def main():
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
     tfile = {"bf16x3": "r01_march16_traffic.json", "f16f8": "r02_march_f16_traffic.json", "f16f6r": "r03_march_f6_traffic.json",
-             "f16f6": "r03_march_ms6_traffic.json"}.get(net.march_precision())
+             "f16f6": "r03_march_ms6_traffic.json", "f16f6v": "r04_march_fold_traffic.json"}.get(net.march_precision())
     tpath = os.path.join(ROOT, "profiles", tfile or "none")
     if tfile and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
         with open(tpath) as f:
@@ -463,7 +466,11 @@ def main():
                                            "terms in 8 bits (fp8 e4m3 weights, bf8 e5m2 activations) on "
                                            "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate",
                                   "f16f6": "the f16f6r arithmetic on the M-split organisation (round 3: four waves share 64 rays, "
-                                           "activations in LDS, weights streamed from L2, two workgroups per CU)"}[net.march_precision()],
+                                           "activations in LDS, weights streamed from L2, two workgroups per CU)",
+                                  "f16f6v": "fc_0 folded into the volume (U = fc_0 . V per active voxel, fp16 head + remainder; the "
+                                            "trilinear lookup is an MFMA against the sparse weight matrix of the workgroup's voxel "
+                                            "list, three fp16 products, fp32 accumulate); fc_1 .. rgb_fc: the f16f6 arithmetic on the "
+                                            "M-split organisation"}[net.march_precision()],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,

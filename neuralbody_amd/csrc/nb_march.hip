@@ -536,7 +536,6 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
                    precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6V,
                "nb_march: precision %d", precision);
     if (precision == NB_PREC_F16F6V) {
-        NB_REQUIRE(!a.cull.n_views, "nb_march: NB_PREC_F16F6V has no sample culling yet (use NB_PREC_F16F6R)");
         if (int rc = fill_fold(scene, &a.fold)) return rc;
         return nbm::launch_march_fold(a, fold_stream_off(), (hipStream_t)stream);
     }

@@ -81,8 +81,8 @@ constexpr int WT_CHUNK = 4096;                 // Wt of 16 voxels: [form: heads,
 constexpr int U_CHUNK = 4096;                  // one wave's 64 features of 16 voxels: [form][M tile] x 1 KiB transposable image
 constexpr int K_CAP = 128;                     // voxels per pass (8 chunks)
 constexpr int SCR_A = ACT_BYTES;               // alpha_fc partial sums [64 samples][4 waves] floats
-constexpr int WBOX_OFF = SCR_A;                // ... and, between two uses of those, the (wave, level) boxes: 16 x 8 ints
 constexpr int SCR_C = SCR_A + 1024;            // rgb_fc partial sums [3][64][4] floats
+constexpr int WBOX_OFF = SCR_C;                // ... and, between two uses of those, the (wave, level) boxes: 16 x 8 ints
 // small fp32 parameters staged once per workgroup (LDS reads are counted on lgkmcnt: a global load at the head of a layer
 // phase would drain the weight ring's vmcnt queue): offsets in floats
 constexpr int PRM_OFF = SCR_C + 3072;
@@ -94,7 +94,7 @@ static_assert(RAY_OFF % 16 == 0, "16-byte aligned records");
 // the folded first layer's bookkeeping
 constexpr int LC_OFF = RAY_OFF + 64 * RAY_FLOATS * 4;  // per level: D H W fmx | fmy fmz fpx fpy | fpz grid_lo grid_hi row_base
 constexpr int LVL_OFF = LC_OFF + 4 * 48;               // per level, of the step about to be marched: xlo ylo zlo nx | nxy k0 n -
-constexpr int HDR_OFF = LVL_OFF + 4 * 32;              // K | tier | - | -
+constexpr int HDR_OFF = LVL_OFF + 4 * 32;              // K | - | - | -
 constexpr int TBL_OFF = HDR_OFF + 16;                  // K_CAP byte offsets of U rows
 constexpr int DUMMY_OFF = TBL_OFF + K_CAP * 4;         // where the weights of corners outside the volume go
 constexpr int LDS_BYTES = DUMMY_OFF + 16;
@@ -325,9 +325,10 @@ template <int MT>
 __device__ __forceinline__ void init_bias(const float *bp, int tile0, int hi, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        const f32x16 b = bias_tile_g(bp, tile0 + m, hi);
-        acc[m][0] = b;
-        acc[m][1] = b;
+        // the second N tile's copy straight from LDS as well: 4 reads instead of 16 v_mov
+        acc[m][0] = bias_tile_g(bp, tile0 + m, hi);
+        asm volatile("" ::: "memory");
+        acc[m][1] = bias_tile_g(bp, tile0 + m, hi);
     }
 }
 
@@ -428,10 +429,11 @@ __device__ __forceinline__ void prep_boxes(char *actz, const Lvl &lv, const Grid
     int zlo = take ? min(max(q.z0, 0), lv.D - 1) : BOX_BIG, zhi = take ? min(max(q.z0 + 1, 0), lv.D - 1) : -1;
     xlo = red_min16i(xlo); ylo = red_min16i(ylo); zlo = red_min16i(zlo);
     xhi = red_max16i(xhi); yhi = red_max16i(yhi); zhi = red_max16i(zhi);
+    const int any = __builtin_amdgcn_ballot_w64(take) != 0ull;  // does the wave decode any sample at all
     if (write && os == 0) {
         i32x4 *d = reinterpret_cast<i32x4 *>(actz + WBOX_OFF + (wslot * 4 + part) * 32);
         d[0] = i32x4{xlo, ylo, zlo, xhi};
-        d[1] = i32x4{yhi, zhi, 0, 0};
+        d[1] = i32x4{yhi, zhi, any, 0};
     }
 }
 
@@ -440,6 +442,7 @@ struct Prep {
     int xlo, ylo, zlo, nx, nxy, n, k0;
     int K;     // uniform
     int tier;  // uniform: 0 = one pass over all 64 samples, 1 = groups of 16 samples (one wave's), 2 = single samples
+    int any;   // uniform: at least one sample takes part
 };
 __device__ __forceinline__ int box_count(int xlo, int ylo, int zlo, int xhi, int yhi, int zhi) {
     return (xhi < xlo || yhi < ylo || zhi < zlo) ? 0 : (xhi - xlo + 1) * (yhi - ylo + 1) * (zhi - zlo + 1);
@@ -447,11 +450,12 @@ __device__ __forceinline__ int box_count(int xlo, int ylo, int zlo, int xhi, int
 template <int NW>
 __device__ __forceinline__ Prep prep_wg(const char *actz, int part) {
     int xlo = BOX_BIG, ylo = BOX_BIG, zlo = BOX_BIG, xhi = -1, yhi = -1, zhi = -1;
-    int n16[NW];
+    int n16[NW], any = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         const i32x4 *s = reinterpret_cast<const i32x4 *>(actz + WBOX_OFF + (w * 4 + part) * 32);
         const i32x4 a = s[0], b = s[1];
+        any |= b.z;
         n16[w] = box_count(a.x, a.y, a.z, a.w, b.x, b.y);
         xlo = min(xlo, a.x); ylo = min(ylo, a.y); zlo = min(zlo, a.z);
         xhi = max(xhi, a.w); yhi = max(yhi, b.x); zhi = max(zhi, b.y);
@@ -466,6 +470,7 @@ __device__ __forceinline__ Prep prep_wg(const char *actz, int part) {
     p.K = n0 + n1 + n2 + n3;
     p.k0 = part == 0 ? 0 : (part == 1 ? n0 : (part == 2 ? n0 + n1 : n0 + n1 + n2));
     p.tier = 0;
+    p.any = any;
     if constexpr (NW > 1) {
         if (p.K > K_CAP) {  // uniform
             int worst = 0;
@@ -510,17 +515,13 @@ __device__ __forceinline__ void tbl_store(char *actz, const TblLoad &t, const Lv
         if (t.idx[q] >= 0) tbl[t.idx[q]] = t.rid[q] < 0 ? zero_off : (unsigned)(lv.rbase + t.rid[q]) << 10;
     if (tid < 16 && K + tid < ((K + 15) & ~15)) tbl[K + tid] = zero_off;  // the padding of the last chunk
 }
-__device__ __forceinline__ void lvl_store(char *actz, const Prep &p, int tid, int os, int part, bool with_tier) {
+__device__ __forceinline__ void lvl_store(char *actz, const Prep &p, int tid, int os, int part) {
     if (tid < 64 && os == 0) {
         i32x4 *d = reinterpret_cast<i32x4 *>(actz + LVL_OFF + part * 32);
         d[0] = i32x4{p.xlo, p.ylo, p.zlo, p.nx};
         d[1] = i32x4{p.nxy, p.k0, p.n, 0};
     }
-    if (tid == 0) {
-        int *h = reinterpret_cast<int *>(actz + HDR_OFF);
-        h[0] = p.K;
-        if (with_tier) h[1] = p.tier;
-    }
+    if (tid == 0) *reinterpret_cast<int *>(actz + HDR_OFF) = p.K;
 }
 
 // the K list of the step about to be marched, per wave: chunks, the wave's U region (R chunk slots behind the Wt chunks)
@@ -685,7 +686,7 @@ struct CompState {
 template <int T>
 __device__ __forceinline__ void composite_slice(CompState &c, const char *actz, const float *pk, int sample, int part, float z_step,
                                                 float z_after, bool last, const MarchArgs &a, long long ray, int sidx, int S, bool valid,
-                                                WeightStore4 &wstore) {
+                                                WeightStore4 &wstore, bool ins) {
     const f32x4 *rec = reinterpret_cast<const f32x4 *>(actz + RAY_OFF) + sample * (RAY_FLOATS / 4);
     if constexpr (T == 0) {
         const f32x4 pa = *reinterpret_cast<const f32x4 *>(actz + SCR_A + sample * 16);
@@ -695,6 +696,7 @@ __device__ __forceinline__ void composite_slice(CompState &c, const char *actz, 
             const f32x4 pc = *reinterpret_cast<const f32x4 *>(actz + SCR_C + (ch * 64 + sample) * 16);
             c.out[ch] = ((pc.x + pc.y) + (pc.z + pc.w)) + pk[P_RB + ch];
         }
+        if (!ins) c.out[0] = c.out[1] = c.out[2] = c.out[3] = 0.f;  // culled sample: raw = 0 (if_clight_renderer_mmsk.py:54-59)
     } else if constexpr (T == 1) {
         const float d = last ? 1e10f : __fsub_rn(z_after, z_step);
         c.dist = __fmul_rn(d, rec[2].w);
@@ -745,7 +747,7 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 }
 
 // ---------------------------------------------------------------- the kernel
-// FOLD_TAP (debug builds, tools/experiments/fold_tap_check.py): workgroup 0 dumps, at depth step 0, every layer's accumulators
+// FOLD_TAP (debug builds, tools/experiments/fold_check.py tap): workgroup 0 dumps, at depth step 0, every layer's accumulators
 // as [layer][feature][sample] fp32 into a.raw instead of the raw output (fc_0, fc_1, fc_2 pre-activation: 3 x 256 x 64;
 // folded view layer: 128 x 64), to be compared with nb_decode_points' fp32 activation tap
 #ifdef FOLD_TAP
@@ -762,9 +764,13 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 // MODE 0: rays (nb_march).  MODE 1 / 2: explicit points (nb_decode_points, raw [n,4] / density [n,1]): a point with its view
 // direction is a one-sample "ray" (origin = the point, direction = the view direction taken as given, z = 0) whose decoder
 // output is stored instead of composited; MODE 2 stops behind alpha_fc.
-template <int MODE>
+// CULL (rays only): nb_cull — a sample that projects outside any silhouette is not decoded: it joins no voxel box, scatters no
+// weights, and its raw output is 0 (if_clight_renderer_mmsk.py:54-59); a depth step without a single inside sample skips its
+// layers altogether (workgroup-uniform).
+template <int MODE, bool CULL>
 __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, const char *stream) {
     constexpr bool POINTS = MODE != 0, DENSITY_ONLY = MODE == 2;
+    static_assert(!(CULL && POINTS), "sample culling is a property of the ray march");
     saturate_fp16_conversions();
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     char *act = lds;
@@ -846,34 +852,46 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
     typedef void __attribute__((address_space(3))) *lptr_t;
     const unsigned lds_base = (unsigned)(unsigned long long)(lptr_t)(lds);  // wave-uniform LDS byte address
 
-    // ---- the K list of step 0
     float z_cur;
-    GridCoord g;  // grid coordinates of the step about to be marched (this lane's sample)
-    int tier;
-    {
-        const int os = lane & 15, part = lane >> 4, sample = 16 * wave + os;
+    GridCoord g;      // grid coordinates of the step about to be marched (this lane's sample)
+    bool ins = true;  // ... and whether it survives the silhouette test
+    int tier, active;  // uniform: how the step's voxel list is marched (Prep::tier); any sample to decode at all
+    // The voxel list of step `sn` in one go (step 0, and behind a step whose layers were skipped): sample position, boxes,
+    // the workgroup's K list and its table.  Ends with everything written but not yet published (the caller's barrier).
+    auto prep_sequential = [&](int sn, float &z_out, int lane_c) {
+        const int os = lane_c & 15, part = lane_c >> 4, sample = 16 * wave + os;
         const f32x4 *rec = reinterpret_cast<const f32x4 *>(lds + RAY_OFF) + sample * (RAY_FLOATS / 4);
         const f32x4 ro = rec[0], rd = rec[1];
-        z_cur = z_at(0, ro.w, rd.w);
-        g = grid_coords(a.sc, __fadd_rn(ro.x, __fmul_rn(rd.x, z_cur)), __fadd_rn(ro.y, __fmul_rn(rd.y, z_cur)),
-                        __fadd_rn(ro.z, __fmul_rn(rd.z, z_cur)));
+        z_out = z_at(sn, ro.w, rd.w);
+        const float px = __fadd_rn(ro.x, __fmul_rn(rd.x, z_out)), py = __fadd_rn(ro.y, __fmul_rn(rd.y, z_out)),
+                    pz = __fadd_rn(ro.z, __fmul_rn(rd.z, z_out));
+        g = grid_coords(a.sc, px, py, pz);
+        if constexpr (CULL) ins = cull_inside(a.cull, a.sc, px, py, pz);
         const Lvl lv = load_lvl(lds, part);
-        prep_boxes(lds, lv, g, true, wave, true, os, part);
+        prep_boxes(lds, lv, g, ins, wave, true, os, part);
         __syncthreads();
         const Prep pr = prep_wg<4>(lds, part);
         tier = __builtin_amdgcn_readfirstlane(pr.tier);
+        active = __builtin_amdgcn_readfirstlane(pr.any);
         if (tier == 0) {
             const TblLoad tl = tbl_issue(pr, lv, wave, os);
             tbl_store(lds, tl, lv, a.fold.zero_off, pr.K, tid);
         }
-        lvl_store(lds, pr, tid, os, part, true);
-        __syncthreads();
-        if (tier == 0) {
+        lvl_store(lds, pr, tid, os, part);
+    };
+    // The step's U rows requested and its trilinear weights built (behind the barrier that published table and boxes).
+    auto fetch_and_weights = [&](int lane_c) {
+        if (tier == 0 && active) {
+            const int os = lane_c & 15, part = lane_c >> 4;
             const UCfg u = ucfg(lds, lds_base, wave);
-            dma_initial(a, lds, lane, wave, u);
-            wt_build(lds, lv, g, true, wave, os, part, u.nch);
+            dma_initial(a, lds, lane_c, wave, u);
+            const Lvl lv = load_lvl(lds, part);
+            wt_build(lds, lv, g, ins, wave, os, part, u.nch);
         }
-    }
+    };
+    prep_sequential(0, z_cur, lane);
+    __syncthreads();
+    fetch_and_weights(lane);
     for (int s = 0; s < S; ++s) {
         // loop-invariant address roots are laundered so that LICM does not hoist (and spill) hundreds of addresses
         int zero = 0, lane_i = lane;
@@ -883,195 +901,209 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
         char *actz = act + zero;
         const float *pk = reinterpret_cast<const float *>(actz + PRM_OFF);
         const f32x4 *rec = reinterpret_cast<const f32x4 *>(actz + RAY_OFF) + sample * (RAY_FLOATS / 4);
-        f32x16 acc[2][2];
         const int sn = sample >> 5, ss = sample & 31;  // N tile and column of this lane's sample
-
-        // ---- fc_0 folded into the volume: H1_pre = b0 + U^T . Wt over the step's voxel list
-        __syncthreads();  // Wt (and, on the grouped path, nothing yet) is visible
-        init_bias<2>(pk + P_B0, 2 * wave, hi, acc);
-        if (tier == 0) {
-            const UCfg u = ucfg(actz, lds_base, wave);
-            fold_mfma(a, actz, lane_i, wave, u, acc);
-        } else {
-            // rays far apart: sample groups of 16 (one wave's) or single samples, each through boxes -> table -> U -> Wt -> MFMA
-            const Lvl lv = load_lvl(actz, part);
-            const int n_groups = tier == 1 ? 4 : 64;
-            for (int gi = 0; gi < n_groups; ++gi) {
-                const bool take = tier == 1 ? wave == gi : sample == gi;
-                prep_boxes(actz, lv, g, take, 0, wave == (tier == 1 ? gi : gi >> 4), os, part);
-                __syncthreads();
-                const Prep pr = prep_wg<1>(actz, part);
-                const TblLoad tl = tbl_issue(pr, lv, wave, os);
-                tbl_store(actz, tl, lv, a.fold.zero_off, pr.K, tid);
-                lvl_store(actz, pr, tid, os, part, false);
-                __syncthreads();
-                const UCfg u = ucfg(actz, lds_base, wave);
-                dma_initial(a, actz, lane_i, wave, u);
-                wt_build(actz, lv, g, take, wave, os, part, u.nch);
-                __syncthreads();
-                fold_mfma(a, actz, lane_i, wave, u, acc);
-                __syncthreads();
-            }
-        }
-        FOLD_DUMP(0, 2)
-        ring_prime<P_L1>(wl, ring);
-        publish_s(actz, lane_i, wave, acc);
-        // ---- fc_1, fc_2
-        init_bias<2>(pk + P_B1, 2 * wave, hi, acc);
-        // The positional encodings of this step (lane (sample, axis a = part < 3): x_a, (sin, cos)(x_a 2^k) k < 10, v_a, (sin, cos)
-        // (v_a 2^k) k < 4, two zeros; part 3: zeros) and their conversion into operands ride behind fc_1's MFMAs, one slice per
-        // MFMA step; the finished half-block waits in registers until the view layer has released the activation buffers.
-        Conv6 pec;
-        {
-            const f32x4 ro = rec[0], rd = rec[1], rv = rec[2];  // ox oy oz near | dx dy dz far | vx vy vz |d|
-            const float keep = part < 3 ? 1.f : 0.f;
-            const float xa = part == 0 ? __fadd_rn(ro.x, __fmul_rn(rd.x, z_cur))
-                                       : (part == 1 ? __fadd_rn(ro.y, __fmul_rn(rd.y, z_cur)) : __fadd_rn(ro.z, __fmul_rn(rd.z, z_cur)));
-            const float va = part == 0 ? rv.x : (part == 1 ? rv.y : rv.z);
-            Rev2 tx, tv;
-            float e[32];
-            auto pe_fill = [&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                if constexpr (t == 0) {
-                    tx = rev2(xa);
-                    tv = rev2(va);
-                    e[0] = xa;
-                    e[21] = va;
-                    e[30] = 0.f;
-                    e[31] = 0.f;
-                } else if constexpr (t <= 10) {
-                    sincos_rev2<t - 1>(tx, e[2 * t - 1], e[2 * t]);
-                } else if constexpr (t <= 14) {
-                    sincos_rev2<t - 11>(tv, e[2 * t], e[2 * t + 1]);
-                } else if constexpr (t >= 16) {
-                    constexpr int i = t - 16;
-                    conv6_pair<2 * i>(pec, e[4 * i] * keep, e[4 * i + 1] * keep);
-                    conv6_pair<2 * i + 1>(pec, e[4 * i + 2] * keep, e[4 * i + 3] * keep);
-                }
-            };
-            if constexpr (DENSITY_ONLY) layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc);
-            else layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc, pe_fill);
-        }
-        HalfBlock peh;
-        if constexpr (!DENSITY_ONLY) peh = conv6_finish(pec);
-        FOLD_DUMP(1, 2)
-        // ---- the next step's sample: depth, grid coordinates, (wave, level) boxes (published by the barriers of publish_s)
+        const bool more = s + 1 < S;                   // uniform
+        const bool ins_cur = ins;
         float z_next = 0.f;
-        const bool more = s + 1 < S;  // uniform
-        if (more) {
-            const f32x4 ro = rec[0], rd = rec[1];
-            z_next = z_at(s + 1, ro.w, rd.w);
-            g = grid_coords(a.sc, __fadd_rn(ro.x, __fmul_rn(rd.x, z_next)), __fadd_rn(ro.y, __fmul_rn(rd.y, z_next)),
-                            __fadd_rn(ro.z, __fmul_rn(rd.z, z_next)));
-            const Lvl lv = load_lvl(actz, part);
-            prep_boxes(actz, lv, g, true, wave, true, os, part);
-        }
-        publish_s(actz, lane_i, wave, acc);
-        // ---- its voxel list: the workgroup's boxes, K, and the index-grid lookups (in flight under fc_2's MFMAs)
-        TblLoad tl;
-        int tier_next = 0, k_next = 0;
-        if (more) {
-            const Lvl lv = load_lvl(actz, part);
-            const Prep pr = prep_wg<4>(actz, part);
-            tier_next = __builtin_amdgcn_readfirstlane(pr.tier);
-            k_next = __builtin_amdgcn_readfirstlane(pr.K);
-            tl.rid[0] = tl.rid[1] = tl.idx[0] = tl.idx[1] = -1;
-            if (tier_next == 0) tl = tbl_issue(pr, lv, wave, os);
-            lvl_store(actz, pr, tid, os, part, true);
-        }
-        init_bias<2>(pk + P_B2, 2 * wave, hi, acc);
-        layer_s<P_L2, 2, 4, true>(wl, actz, lane_i, ring, acc);
-        if (more && tier_next == 0) {
-            const Lvl lv = load_lvl(actz, part);
-            tbl_store(actz, tl, lv, a.fold.zero_off, k_next, tid);
-        }
-        FOLD_DUMP(2, 2)
-        if constexpr (DENSITY_ONLY) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = relu1(acc[m][n][r]);
-        } else {
-            publish_s(actz, lane_i, wave, acc);  // acc now holds relu(h3)
-        }
-        // ---- alpha_fc: partial dot product over this wave's 64 features, finished by the owner lanes
-        {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float s4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent chains
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const f32x4 *aw = reinterpret_cast<const f32x4 *>(pk + P_AW + hi * 128 + 16 * (2 * wave + m));
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) {
-                        const f32x4 w4 = aw[q4];
-                        s4[0] = fmaf(w4.x, acc[m][n][4 * q4 + 0], s4[0]);
-                        s4[1] = fmaf(w4.y, acc[m][n][4 * q4 + 1], s4[1]);
-                        s4[2] = fmaf(w4.z, acc[m][n][4 * q4 + 2], s4[2]);
-                        s4[3] = fmaf(w4.w, acc[m][n][4 * q4 + 3], s4[3]);
-                    }
+        int tier_next = 0, active_next = 1;
+        __syncthreads();  // Wt is visible
+        if (!CULL || active) {
+            f32x16 acc[2][2];
+            // ---- fc_0 folded into the volume: H1_pre = b0 + U^T . Wt over the step's voxel list
+            init_bias<2>(pk + P_B0, 2 * wave, hi, acc);
+            if (tier == 0) {
+                const UCfg u = ucfg(actz, lds_base, wave);
+                fold_mfma(a, actz, lane_i, wave, u, acc);
+            } else {
+                // rays far apart: sample groups of 16 (one wave's) or single samples, each through boxes -> table -> U -> Wt -> MFMA
+                const Lvl lv = load_lvl(actz, part);
+                const int n_groups = tier == 1 ? 4 : 64;
+                for (int gi = 0; gi < n_groups; ++gi) {
+                    const bool take = ins_cur && (tier == 1 ? wave == gi : sample == gi);
+                    prep_boxes(actz, lv, g, take, 0, wave == (tier == 1 ? gi : gi >> 4), os, part);
+                    __syncthreads();
+                    const Prep pr = prep_wg<1>(actz, part);
+                    const TblLoad tl = tbl_issue(pr, lv, wave, os);
+                    tbl_store(actz, tl, lv, a.fold.zero_off, pr.K, tid);
+                    lvl_store(actz, pr, tid, os, part);
+                    __syncthreads();
+                    const UCfg u = ucfg(actz, lds_base, wave);
+                    dma_initial(a, actz, lane_i, wave, u);
+                    wt_build(actz, lv, g, take, wave, os, part, u.nch);
+                    __syncthreads();
+                    fold_mfma(a, actz, lane_i, wave, u, acc);
+                    __syncthreads();
                 }
-                float sa = add_halves((s4[0] + s4[1]) + (s4[2] + s4[3]));
-                if (hi == 0) reinterpret_cast<float *>(actz + SCR_A)[(n * 32 + (lane_i & 31)) * 4 + wave] = sa;
             }
-        }
-        if constexpr (!DENSITY_ONLY) {
-            // ---- the colour head's linear part as ONE layer (feature_fc . latent_fc . view_fc folded at pack time, bias: second
-            // block of nb_mlp_latent_bias): one tile per wave, K phase over fc_2's outputs, then over the encodings
-            init_bias<1>(pk + P_LB, wave, hi, acc);
-            layer_s<P_VG, 1, 4, false>(wl, actz, lane_i, ring, acc);
-            __syncthreads();
-            ring_prime<P_VP>(wl, ring);
-            store_halfblock(actz, part >> 1, part & 1, sn, ss, peh);  // the encodings converted behind fc_1
-            __syncthreads();
-            layer_s<P_VP, 1, 2, false>(wl, actz, lane_i, ring, acc);
-            FOLD_DUMP(3, 1)
-            // ---- rgb_fc partial sums over this wave's 32 view features
+            FOLD_DUMP(0, 2)
+            ring_prime<P_L1>(wl, ring);
+            publish_s(actz, lane_i, wave, acc);
+            // ---- fc_1, fc_2
+            init_bias<2>(pk + P_B1, 2 * wave, hi, acc);
+            // The positional encodings of this step (lane (sample, axis a = part < 3): x_a, (sin, cos)(x_a 2^k) k < 10, v_a, (sin,
+            // cos)(v_a 2^k) k < 4, two zeros; part 3: zeros) and their conversion into operands ride behind fc_1's MFMAs, one slice
+            // per MFMA step; the finished half-block waits in registers until the view layer has released the activation buffers.
+            Conv6 pec;
+            {
+                const f32x4 ro = rec[0], rd = rec[1], rv = rec[2];  // ox oy oz near | dx dy dz far | vx vy vz |d|
+                const float keep = part < 3 ? 1.f : 0.f;
+                const float xa = part == 0 ? __fadd_rn(ro.x, __fmul_rn(rd.x, z_cur))
+                                           : (part == 1 ? __fadd_rn(ro.y, __fmul_rn(rd.y, z_cur)) : __fadd_rn(ro.z, __fmul_rn(rd.z, z_cur)));
+                const float va = part == 0 ? rv.x : (part == 1 ? rv.y : rv.z);
+                Rev2 tx, tv;
+                float e[32];
+                auto pe_fill = [&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t == 0) {
+                        tx = rev2(xa);
+                        tv = rev2(va);
+                        e[0] = xa;
+                        e[21] = va;
+                        e[30] = 0.f;
+                        e[31] = 0.f;
+                    } else if constexpr (t <= 10) {
+                        sincos_rev2<t - 1>(tx, e[2 * t - 1], e[2 * t]);
+                    } else if constexpr (t <= 14) {
+                        sincos_rev2<t - 11>(tv, e[2 * t], e[2 * t + 1]);
+                    } else if constexpr (t >= 16) {
+                        constexpr int i = t - 16;
+                        conv6_pair<2 * i>(pec, e[4 * i] * keep, e[4 * i + 1] * keep);
+                        conv6_pair<2 * i + 1>(pec, e[4 * i + 2] * keep, e[4 * i + 3] * keep);
+                    }
+                };
+                if constexpr (DENSITY_ONLY) layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc);
+                else layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc, pe_fill);
+            }
+            HalfBlock peh;
+            if constexpr (!DENSITY_ONLY) peh = conv6_finish(pec);
+            FOLD_DUMP(1, 2)
+            publish_s(actz, lane_i, wave, acc);
+            init_bias<2>(pk + P_B2, 2 * wave, hi, acc);
+            layer_s<P_L2, 2, 4, true>(wl, actz, lane_i, ring, acc);
+            FOLD_DUMP(2, 2)
+            // ---- the next step's sample: depth, grid coordinates, silhouette test, (wave, level) boxes — published by the
+            // barriers of the publish below
+            if (more) {
+                const f32x4 ro = rec[0], rd = rec[1];
+                z_next = z_at(s + 1, ro.w, rd.w);
+                const float px = __fadd_rn(ro.x, __fmul_rn(rd.x, z_next)), py = __fadd_rn(ro.y, __fmul_rn(rd.y, z_next)),
+                            pz = __fadd_rn(ro.z, __fmul_rn(rd.z, z_next));
+                g = grid_coords(a.sc, px, py, pz);
+                if constexpr (CULL) ins = cull_inside(a.cull, a.sc, px, py, pz);
+                const Lvl lv = load_lvl(actz, part);
+                prep_boxes(actz, lv, g, ins, wave, true, os, part);
+            }
+            if constexpr (DENSITY_ONLY) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] = relu1(acc[m][n][r]);
+            } else {
+                publish_s(actz, lane_i, wave, acc);  // acc now holds relu(h3)
+            }
+            // ---- alpha_fc: partial dot product over this wave's 64 features, finished by the owner lanes
             {
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n) {
+                    float s4[4] = {0.f, 0.f, 0.f, 0.f};  // four independent chains
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
-                        const f32x4 *rw = reinterpret_cast<const f32x4 *>(pk + P_RW + (ch * 2 + hi) * 64 + 16 * wave);
-                        float c4[4] = {0.f, 0.f, 0.f, 0.f};
+                    for (int m = 0; m < 2; ++m) {
+                        const f32x4 *aw = reinterpret_cast<const f32x4 *>(pk + P_AW + hi * 128 + 16 * (2 * wave + m));
 #pragma unroll
                         for (int q4 = 0; q4 < 4; ++q4) {
-                            const f32x4 w4 = rw[q4];
-                            c4[0] = fmaf(w4.x, relu1(acc[0][n][4 * q4 + 0]), c4[0]);
-                            c4[1] = fmaf(w4.y, relu1(acc[0][n][4 * q4 + 1]), c4[1]);
-                            c4[2] = fmaf(w4.z, relu1(acc[0][n][4 * q4 + 2]), c4[2]);
-                            c4[3] = fmaf(w4.w, relu1(acc[0][n][4 * q4 + 3]), c4[3]);
+                            const f32x4 w4 = aw[q4];
+                            s4[0] = fmaf(w4.x, acc[m][n][4 * q4 + 0], s4[0]);
+                            s4[1] = fmaf(w4.y, acc[m][n][4 * q4 + 1], s4[1]);
+                            s4[2] = fmaf(w4.z, acc[m][n][4 * q4 + 2], s4[2]);
+                            s4[3] = fmaf(w4.w, acc[m][n][4 * q4 + 3], s4[3]);
                         }
-                        float sc = add_halves((c4[0] + c4[1]) + (c4[2] + c4[3]));
-                        if (hi == 0) reinterpret_cast<float *>(actz + SCR_C)[(ch * 64 + n * 32 + (lane_i & 31)) * 4 + wave] = sc;
                     }
+                    float sa = add_halves((s4[0] + s4[1]) + (s4[2] + s4[3]));
+                    if (hi == 0) reinterpret_cast<float *>(actz + SCR_A)[(n * 32 + (lane_i & 31)) * 4 + wave] = sa;
+                }
             }
+            if constexpr (!DENSITY_ONLY) {
+                // ---- the next step's voxel list: the workgroup's boxes, K, and the index-grid lookups (in flight under the MFMAs
+                // of the colour head's first phase, stored behind them)
+                TblLoad tl;
+                int k_next = 0;
+                if (more) {
+                    const Lvl lv = load_lvl(actz, part);
+                    const Prep pr = prep_wg<4>(actz, part);
+                    tier_next = __builtin_amdgcn_readfirstlane(pr.tier);
+                    active_next = __builtin_amdgcn_readfirstlane(pr.any);
+                    k_next = __builtin_amdgcn_readfirstlane(pr.K);
+                    tl.rid[0] = tl.rid[1] = tl.idx[0] = tl.idx[1] = -1;
+                    if (tier_next == 0) tl = tbl_issue(pr, lv, wave, os);
+                    lvl_store(actz, pr, tid, os, part);
+                }
+                // ---- the colour head's linear part as ONE layer (feature_fc . latent_fc . view_fc folded at pack time, bias:
+                // second block of nb_mlp_latent_bias): one tile per wave, K phase over fc_2's outputs, then over the encodings
+                init_bias<1>(pk + P_LB, wave, hi, acc);
+                layer_s<P_VG, 1, 4, false>(wl, actz, lane_i, ring, acc);
+                if (more && tier_next == 0) {
+                    const Lvl lv = load_lvl(actz, part);
+                    tbl_store(actz, tl, lv, a.fold.zero_off, k_next, tid);
+                }
+                __syncthreads();
+                ring_prime<P_VP>(wl, ring);
+                store_halfblock(actz, part >> 1, part & 1, sn, ss, peh);  // the encodings converted behind fc_1
+                __syncthreads();
+                layer_s<P_VP, 1, 2, false>(wl, actz, lane_i, ring, acc);
+                FOLD_DUMP(3, 1)
+                // ---- rgb_fc partial sums over this wave's 32 view features
+                {
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        float rl[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) rl[r] = relu1(acc[0][n][r]);
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) {
+                            const f32x4 *rw = reinterpret_cast<const f32x4 *>(pk + P_RW + (ch * 2 + hi) * 64 + 16 * wave);
+                            float c4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) {
+                                const f32x4 w4 = rw[q4];
+                                c4[0] = fmaf(w4.x, rl[4 * q4 + 0], c4[0]);
+                                c4[1] = fmaf(w4.y, rl[4 * q4 + 1], c4[1]);
+                                c4[2] = fmaf(w4.z, rl[4 * q4 + 2], c4[2]);
+                                c4[3] = fmaf(w4.w, rl[4 * q4 + 3], c4[3]);
+                            }
+                            float sc = add_halves((c4[0] + c4[1]) + (c4[2] + c4[3]));
+                            if (hi == 0) reinterpret_cast<float *>(actz + SCR_C)[(ch * 64 + n * 32 + (lane_i & 31)) * 4 + wave] = sc;
+                        }
+                    }
+                }
+            }
+        } else if (more) {
+            prep_sequential(s + 1, z_next, lane_i);
+            tier_next = tier;
+            active_next = active;
         }
-        __syncthreads();  // the activation buffers are free; the heads' partial sums are visible
+        __syncthreads();  // the activation buffers are free; the heads' partial sums, the next step's table and boxes are visible
         // ---- the next step's U rows and trilinear weights: in flight / built under this step's heads and compositing
-        if (more && tier_next == 0) {
-            const UCfg u = ucfg(actz, lds_base, wave);
-            dma_initial(a, actz, lane_i, wave, u);
-            const Lvl lv = load_lvl(actz, part);
-            wt_build(actz, lv, g, true, wave, os, part, u.nch);
+        if (more) {
+            tier = tier_next;
+            active = active_next;
+            fetch_and_weights(lane_i);
         }
         // ---- owner lanes: finish the heads; composite (rays) or hand the decoder output over (points)
         {
             CompState cs;
             if constexpr (POINTS) {
-                composite_slice<0>(cs, actz, pk, sample, part, z_cur, z_next, true, a, ray, s, S, valid, wstore);
+                composite_slice<0>(cs, actz, pk, sample, part, z_cur, z_next, true, a, ray, s, S, valid, wstore, true);
                 if (valid && part == 0) {
                     if constexpr (DENSITY_ONLY) a.raw_out[ray] = cs.out[3];
                     else *reinterpret_cast<f32x4 *>(a.raw_out + ray * 4) = f32x4{cs.out[0], cs.out[1], cs.out[2], cs.out[3]};
                 }
             } else {
-                sfor<0, 8>([&](auto tc) { composite_slice<decltype(tc)::value>(cs, actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore); });
+                sfor<0, 8>([&](auto tc) { composite_slice<decltype(tc)::value>(cs, actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore, !CULL || ins_cur); });
             }
         }
         z_cur = z_next;
-        tier = tier_next;
     }
     if (!POINTS && valid && (lane >> 4) == 0) {
         const f32x4 *rec = reinterpret_cast<const f32x4 *>(lds + RAY_OFF) + (16 * wave + (lane & 15)) * (RAY_FLOATS / 4);
@@ -1179,8 +1211,9 @@ int pack_fold_stream(const nb_mlp_params *p, float *packed, long long stream_off
 
 int launch_march_fold(MarchArgs a, long long stream_off, hipStream_t st) {
     a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 64);
-    hipLaunchKernelGGL(nb_march_fold_kernel<0>, dim3(a.n_wave_groups), dim3(256), 0, st, a,
-                       reinterpret_cast<const char *>(a.pk + stream_off));
+    const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
+    if (a.cull.n_views) hipLaunchKernelGGL((nb_march_fold_kernel<0, true>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    else hipLaunchKernelGGL((nb_march_fold_kernel<0, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     NB_CHECK_LAUNCH("nb_march_fold_kernel");
     return NB_OK;
 }
@@ -1189,8 +1222,8 @@ int launch_march_fold(MarchArgs a, long long stream_off, hipStream_t st) {
 int launch_points_fold(MarchArgs a, int density_only, long long stream_off, hipStream_t st) {
     a.n_wave_groups = (int)nb_ceil_div(a.n_pts, 64);
     const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
-    if (density_only) hipLaunchKernelGGL(nb_march_fold_kernel<2>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
-    else hipLaunchKernelGGL(nb_march_fold_kernel<1>, dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    if (density_only) hipLaunchKernelGGL((nb_march_fold_kernel<2, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
+    else hipLaunchKernelGGL((nb_march_fold_kernel<1, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     NB_CHECK_LAUNCH("nb_march_fold_kernel (points)");
     return NB_OK;
 }

@@ -377,8 +377,6 @@ class Network(nn.Module):
                     white_bkgd=False, want_raw=False, ray_order=None, cull=None):
         """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
         prec = self.march_precision()
-        if cull is not None and prec == "f16f6v":
-            prec = "f16f6r"  # sample culling: the ring kernel (same arithmetic behind fc_0)
         scene = self.make_scene(feature_volume, sp_input, prec)
         lb = self.latent_bias(sp_input["latent_index"])
         key = (int(n_samples), str(ray_o.device))  # a constant of (S, device), not of the frame

@@ -491,16 +491,17 @@ def image_assemble(mask_at_box, rgb_map, depth_map=None, white_bkgd=False, bgr=F
     return img, depth
 
 
-def tile_order(pix, width, tile_w=8, tile_h=4):
-    """Permutation (int32) that groups rays into tile_w x tile_h pixel tiles: `pix` are the linear pixel
-    ids (row-major, image `width`) of the rays.  32 consecutive slots = one compact tile, and inside it every 16
-    consecutive slots = one 4 x 4 pixel block (the M-split march gathers per 16 samples: a 4 x 4 block keeps its voxel
-    box smaller than an 8 x 2 strip), so the rays marched together touch the same few voxels on every pyramid level."""
+def tile_order(pix, width, tile=8, block=4):
+    """Permutation (int32) that groups rays into tile x tile pixel tiles made of block x block pixel blocks: `pix` are the
+    linear pixel ids (row-major, image `width`) of the rays.  64 consecutive slots = one compact 8 x 8 tile (what a workgroup
+    of the fused march takes: the voxels its 64 samples touch at a depth step are then a few small boxes), every 16
+    consecutive slots = one 4 x 4 block (one wave's samples), every 32 = an 8 x 4 half tile."""
     py, px = torch.div(pix, width, rounding_mode="floor"), pix % width
-    n_tx = (width + tile_w - 1) // tile_w
-    half = tile_w // 2
-    inner = torch.div(px % tile_w, half, rounding_mode="floor") * (half * tile_h) + (py % tile_h) * half + (px % half)
-    key = (torch.div(py, tile_h, rounding_mode="floor") * n_tx + torch.div(px, tile_w, rounding_mode="floor")) * (tile_w * tile_h) + inner
+    n_tx = (width + tile - 1) // tile
+    per = tile // block
+    blk = torch.div(py % tile, block, rounding_mode="floor") * per + torch.div(px % tile, block, rounding_mode="floor")
+    inner = blk * (block * block) + (py % block) * block + (px % block)
+    key = (torch.div(py, tile, rounding_mode="floor") * n_tx + torch.div(px, tile, rounding_mode="floor")) * (tile * tile) + inner
     return torch.argsort(key).to(torch.int32)
 
 

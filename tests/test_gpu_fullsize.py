@@ -57,12 +57,12 @@ def _check(size, n_samples, n_check, precision):
     return err
 
 
-@pytest.mark.parametrize("precision", ["f16f6", "f16f6r", "f16f8", "bf16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16f6v", "f16f6", "f16f6r", "f16f8", "bf16x3", "f32"])
 def test_headline_view_512x512x64_train_mode(precision):
     _check(512, 64, 4096, precision)
 
 
-@pytest.mark.parametrize("precision", ["f16f6", "f16f8", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f16f6v", "f16f6", "f16f8", "bf16x3"])
 def test_config3_view_1024x1024x128(precision):
     _check(1024, 128, 1024, precision)
 

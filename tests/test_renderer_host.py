@@ -14,8 +14,8 @@ def _renderer(H, W):
 
 def test_tile_order_of_a_full_coverage_view_needs_no_mask_readback():
     """Every pixel a ray: the order is a function of the image geometry; it equals what the general path (non-zeros of the
-    mask -> tile keys -> argsort) gives, is a permutation, is computed once per geometry / ray range, and 32 consecutive slots
-    hold one 8x4 pixel tile."""
+    mask -> tile keys -> argsort) gives, is a permutation, is computed once per geometry / ray range, and 64 consecutive slots
+    hold one 8x8 pixel tile (32: an 8x4 half, 16: a 4x4 block)."""
     H, W = 16, 24
     r = _renderer(H, W)
     n = H * W
@@ -23,9 +23,11 @@ def test_tile_order_of_a_full_coverage_view_needs_no_mask_readback():
     ref = ops.tile_order(torch.nonzero(torch.ones(n, dtype=torch.bool)).reshape(-1), W)
     assert torch.equal(full, ref) and full.dtype == torch.int32
     assert torch.equal(torch.sort(full.long()).values, torch.arange(n))
+    tile = full[:64].long()
+    assert int((tile // W).max() - (tile // W).min()) == 7 and int((tile % W).max() - (tile % W).min()) == 7
     tile = full[:32].long()
     assert int((tile // W).max() - (tile // W).min()) == 3 and int((tile % W).max() - (tile % W).min()) == 7
-    for half in (full[:16].long(), full[16:32].long()):  # every 16 slots: one 4 x 4 pixel block (the M-split march's gather unit)
+    for half in (full[:16].long(), full[16:32].long()):  # every 16 slots: one 4 x 4 pixel block (one wave's samples in the fused march)
         assert int((half // W).max() - (half // W).min()) == 3 and int((half % W).max() - (half % W).min()) == 3
     again = r._tile_order({"mask_at_box": torch.ones(1, n, dtype=torch.bool)}, n, 0, n)  # another mask tensor, same geometry
     assert again is full
