@@ -19,8 +19,7 @@ same without the rays whose last sample's density is within ILL_SIGMA of zero, w
 `--scaling strong` shards ONE view's rays over the ranks (parallel.render_sharded) instead of one view per rank.
 
 The JSON line also carries
-  roofline     — the dominant kernel (nb_march_ms6_kernel or nb_march_f6_kernel by default: precision 'auto' times both
-                 organisations of the f16f6 arithmetic on the first view and keeps the faster one for this box; --precision picks the others): algorithmic MLP
+  roofline     — the dominant kernel (nb_march_fold_kernel by default; --precision f32 picks the exact one): algorithmic MLP
                  flops (859 904 per ray-sample) / its average launch duration measured with HIP
                  events inside the timed region, against the dense MFMA peak of the arithmetic its main product runs on
                  (2.5 PFLOP/s for the fp16 / bf16 paths, 157.3 TFLOP/s for exact fp32); `executed_frac` = the MFMA work the
@@ -46,21 +45,11 @@ FLOP_PER_SAMPLE = 859904.0  # MLP MACs x 2 as the reference la
 PRECISION_INFO = {
     # feature_fc.latent_fc merged, latent folded into a bias: 331 648 MAC/sample on v_mfma_f32_32x32x2_f32
     "f32": ("f32", "nb_march_kernel", 663296.0, 157.3),
-    # the same layers as 1944 v_mfma_f32_32x32x16_bf16 per 32 samples (bf16 hi/lo split: 3 products, K padded to 16)
-    "bf16x3": ("bf16", "nb_march16_kernel", 1944 * 32768 / 32.0, 2500.0),
-    # fp16 main product (520 K=16 MFMAs per 32 samples: fc_0 176, fc_1 128, fc_2 128, the folded feature_fc/latent_fc/view_fc
-    # layer 64, view_fc over the encodings 24) + 272 K=64 scaled 8-bit MFMAs for the two cross terms; the 8-bit flops are
-    # counted at half weight (their dense peak is 2x the fp16 peak), i.e. in fp16-equivalent matrix-pipe time
-    "f16f8": ("f16+f8", "nb_march_f16_kernel", (520 * 32768 + 272 * 131072 / 2.0) / 32.0, 2500.0),
-    # the same with the cross terms in 6 bits: a K=64 fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA
-    # (profiles/r02_probe_mxrate.log), so it is counted as one (a quarter of its flops)
-    "f16f6r": ("f16+f6", "nb_march_f6_kernel", (520 + 272) * 32768 / 32.0, 2500.0),
-    # the same arithmetic, M-split workgroups (round 3, the default and the kernel behind nb_decode_points): 4 waves x 408
-    # MFMAs per 64 samples (fc_0's K padded to 384, the encodings' to 128)
-    "f16f6": ("f16+f6", "nb_march_ms6_kernel", 4 * 408 * 32768 / 64.0, 2500.0),
-    # round 4: fc_0 folded into the volume.  Per wave and depth step of 64 samples: fc_1 96, fc_2 96, the folded colour head 48,
-    # the encodings 24 MFMAs, and 12 per 16 voxels of the step's voxel list (59 voxels = 4.2 chunks on average on the bench view)
-    "f16f6v": ("f16+f6", "nb_march_fold_kernel", 4 * (264 + 12 * 4.2) * 32768 / 64.0, 2500.0),
+    # fc_0 folded into the volume; fc_1 / fc_2 / the folded colour head: fp16 main product + two six-bit cross terms (a K=64
+    # fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA, profiles/r02_probe_mxrate.log, and is counted as
+    # one).  Per wave and depth step of 64 samples: fc_1 96, fc_2 96, the colour head 48 + 24 over the encodings, and 12 per 16
+    # voxels of the step's voxel list (8 x 8 pixel tiles of the bench view: 59 voxels = 4.2 chunks on average)
+    "f16f6": ("f16+f6", "nb_march_fold_kernel", 4 * (264 + 12 * 4.2) * 32768 / 64.0, 2500.0),
 }
 
 
@@ -295,11 +284,11 @@ def extras(args, dev):
           "note": "8 spiral views (512x512x64, each view: nb_raygen + encoder + march + nb_image_assemble) / 6 training steps "
                   "(1024 random rays x 64 jittered samples, forward + backward + clip + Adam); *_ms_per_view / *_march_ms: the timed "
                   "view of this run rendered with the other arithmetics (3 steps each), roofline fraction of each against ITS peak"}
-    # the same view in the reference's own precision (exact fp32 MFMA) and on the other organisations of the default arithmetic:
-    # the record then holds a reference-precision number and an A/B of the kernels from ONE box
+    # the same view in the reference's own precision (exact fp32 MFMA): the record then holds a reference-precision number from
+    # the same box
     from neuralbody_amd import ops
 
-    for prec in ("f32", "f16f6", "f16f6r", "bf16x3"):  # (the default leg is one of the two f16f6 organisations: both are reported)
+    for prec in ("f32",):
         if prec == args.precision:
             continue
         sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, prec)
@@ -320,7 +309,95 @@ def extras(args, dev):
         ex["%s_march_ms" % prec] = march
         ex["%s_roofline_frac" % prec] = FLOP_PER_SAMPLE * n_rays * args.samples / (march * 1e-3) / 1e12 / peak
         del net, rend
+    ex.update(culled_bench(args, dev))
+    ex.update(encoder_bench(args, dev))
     return ex
+
+
+def culled_bench(args, dev):
+    """The mask-culled renderers the shipped visualisation configs select (if_clight_renderer_mmsk.py / _msk.py: 4 resp. 1
+    training-view silhouettes) on the capsule body with synthetic silhouettes, as in the fixtures: ms per view and the share of
+    samples that survive the culling."""
+    from neuralbody_amd import ops
+    from neuralbody_amd import synthetic as syn
+    from neuralbody_amd.network import Network
+    from neuralbody_amd.renderer import RenderConfig, RendererMmsk, RendererMsk
+
+    H = W = args.size
+    sd = syn.make_weights(0, num_train_frame=230)
+    body = syn.make_body(seed=0, layout="capsules")
+    K, R, T = syn.full_coverage_camera(body, H, W)
+    net = Network(num_train_frame=230, precision=args.precision)
+    net.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
+    net = net.to(dev).train()
+    ro, rd, near, far, mask, n = ops.raygen(H, W, K, R, T, body["can_bounds"], dev)
+    n = int(n)
+    batch = syn.make_batch(body, np.zeros((1, 3), np.float32), np.zeros((1, 3), np.float32), np.zeros(1, np.float32),
+                           np.zeros(1, np.float32), np.ones(1, bool))
+    bd = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in batch.items()
+          if k not in ("ray_o", "ray_d", "near", "far", "mask_at_box")}
+    bd.update(ray_o=ro[None, :n], ray_d=rd[None, :n], near=near[None, :n], far=far[None, :n], mask_at_box=mask[None].bool())
+    out = {}
+    for kind, nv, cls in (("mmsk", 3, RendererMmsk), ("msk", 1, RendererMsk)):
+        msks, Ks, RT = syn.make_view_masks(body, 256, 256, n_views=nv)
+        b = dict(bd)
+        if kind == "mmsk":
+            b.update(msks=torch.from_numpy(msks[None]).to(dev), Ks=torch.from_numpy(Ks[None]).to(dev), RT=torch.from_numpy(RT[None]).to(dev))
+        else:
+            b.update(msk=torch.from_numpy((msks[0] * 255)[None].astype(np.uint8)).to(dev), K=torch.from_numpy(Ks[0][None]).to(dev),
+                     RT=torch.from_numpy(RT[0][None]).to(dev), R0_snap=bd["R"].clone(), Th0_snap=bd["Th"].reshape(1, 3).clone())
+        rend = cls(net, RenderConfig(N_samples=args.samples, perturb=0.0, H=H, W=W))
+        with torch.no_grad():
+            o = rend.render(b, want_raw=True)
+            torch.cuda.synchronize()
+            ops.MARCH_EVENTS = []
+            for _ in range(3):
+                rend.render(b)
+            torch.cuda.synchronize()
+            ev, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
+        out["%s_march_ms" % kind] = float(np.mean([x.elapsed_time(y) for x, y in ev]))
+        # a culled sample's raw output is exactly 0 (if_clight_renderer_mmsk.py:54-59); decoded ones are never all-zero
+        out["%s_surviving_sample_fraction" % kind] = float((o["raw"][0].abs().sum(-1) != 0).float().mean())
+    out["culled_note"] = ("mmsk / msk: RendererMmsk (3 silhouette views) / RendererMsk (1) on the capsule body, %dx%dx%d, 256x256 masks; "
+                          "march only; a depth step none of whose 64 samples survives skips its layers" % (H, W, args.samples))
+    return out
+
+
+def encoder_bench(args, dev):
+    """Encoder + glue of one view (everything Renderer.render enqueues before the march: prepare_sp_input, the 17 sparse
+    layers, the fc_0-folded planes, the latent bias): device time between two HIP events with the march stubbed out, and the
+    number of kernel launches counted by torch's profiler."""
+    sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, args.precision)
+
+    def front():
+        sp = rend.prepare_sp_input(bd)
+        vols = net.encode_sparse_voxels(sp)
+        net.make_scene(vols, sp, net.march_precision())
+        net.latent_bias(sp["latent_index"])
+
+    with torch.no_grad():
+        for _ in range(3):
+            front()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            front()
+        e1.record()
+        torch.cuda.synchronize()
+        launches = None
+        try:
+            from torch.profiler import ProfilerActivity, profile
+
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                front()
+                torch.cuda.synchronize()
+            launches = sum(1 for e in prof.events() if e.device_type is not None and str(e.device_type).endswith("CUDA"))
+        except Exception:  # the profiler is informational
+            pass
+    return {"encoder_ms": e0.elapsed_time(e1) / 10, "launches_per_view": launches,
+            "encoder_note": "prepare_sp_input + 17 sparse conv/BN/ReLU layers + nb_fold_build + latent bias of one view, no march: "
+                            "HIP events over 10 repetitions; launches = device kernels + memsets of one repetition (torch.profiler)"}
 
 
 def main():
@@ -331,7 +408,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--precision", default=None, choices=[None, "auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6", "f16f6v"])
+    ap.add_argument("--precision", default=None, choices=[None, "auto", "f32", "f16f6"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one view per GPU per step (views shard with no collective but the tile all-gather); "
                          "strong: one view per step, its rays split over the GPUs")
@@ -433,8 +510,7 @@ def main():
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
-    tfile = {"bf16x3": "r01_march16_traffic.json", "f16f8": "r02_march_f16_traffic.json", "f16f6r": "r03_march_f6_traffic.json",
-             "f16f6": "r03_march_ms6_traffic.json", "f16f6v": "r04_march_fold_traffic.json"}.get(net.march_precision())
+    tfile = {"f16f6": "r04_march_fold_traffic.json"}.get(net.march_precision())
     tpath = os.path.join(ROOT, "profiles", tfile or "none")
     if tfile and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
         with open(tpath) as f:
@@ -455,22 +531,14 @@ def main():
                                "Renderer.render = encoder + fused march, %s; the timed region cycles through %d camera poses" % (
                                    H, W, S, "one view per GPU per step" if args.scaling == "weak" else "one view per step, rays split over the GPUs", len(poses)),
                    "rays_per_view": n_rays, "out_sh": [int(s) for s in body["out_sh"]],
-                   "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-                                  "bf16x3": "bf16 hi+lo split of weights and activations, 3 products per K chunk on "
-                                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate",
-                                  "f16f6r": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
-                                            "terms in 6 bits (fp6 e2m3 weights, bf6 e3m2 activations, E8M0 scales per 32 K) on "
-                                            "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; ring organisation (one wave per "
-                                            "SIMD, weights through an LDS ring)",
-                                  "f16f8": "fp16 head x fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross "
-                                           "terms in 8 bits (fp8 e4m3 weights, bf8 e5m2 activations) on "
-                                           "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate",
-                                  "f16f6": "the f16f6r arithmetic on the M-split organisation (round 3: four waves share 64 rays, "
-                                           "activations in LDS, weights streamed from L2, two workgroups per CU)",
-                                  "f16f6v": "fc_0 folded into the volume (U = fc_0 . V per active voxel, fp16 head + remainder; the "
-                                            "trilinear lookup is an MFMA against the sparse weight matrix of the workgroup's voxel "
-                                            "list, three fp16 products, fp32 accumulate); fc_1 .. rgb_fc: the f16f6 arithmetic on the "
-                                            "M-split organisation"}[net.march_precision()],
+                   "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), trilinear gather on the VALU",
+                                  "f16f6": "fc_0 folded into the volume (U = fc_0 . V per active voxel, fp16 head + remainder; the "
+                                           "trilinear lookup is an MFMA against the sparse weight matrix of the workgroup's voxel "
+                                           "list, three fp16 products, fp32 accumulate); fc_1, fc_2 and the colour head: fp16 head x "
+                                           "fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross terms in 6 bits "
+                                           "(fp6 e2m3 weights, bf6 e3m2 activations, E8M0 scales per 32 K) on "
+                                           "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; four waves share 64 rays, activations in "
+                                           "LDS, weights streamed from L2, two workgroups per CU"}[net.march_precision()],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
@@ -479,16 +547,14 @@ def main():
                      "executed_tflops": exec_flop * rays_per_launch * S / (march_ms * 1e-3) / 1e12,
                      "executed_frac": exec_flop * rays_per_launch * S / (march_ms * 1e-3) / 1e12 / peak,
                      "note": "achieved = 859904 algorithmic flop/sample x %d samples/launch / avg launch time (HIP events); "
-                             "the kernel issues %.0f MFMA flop/sample (merged feature_fc.latent_fc layer%s), so "
-                             "executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~219 MB/launch "
-                             "(<0.1%% of the launch time at 8 TB/s)"
-                             % (rays_per_launch * S, exec_flop, ", x3 for the bf16 hi/lo split" if net.march_precision().startswith("bf16") else "")},
+                             "the kernel issues ~%.0f MFMA flop/sample (fp16-equivalent pipe time; fc_0 folded into the volume, merged "
+                             "colour head), so executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~150 MB/launch "
+                             "(<0.1%% of the launch time at 8 TB/s)" % (rays_per_launch * S, exec_flop)},
     }
     if per_rank is not None:
         result["per_rank"] = per_rank
-    if getattr(net, "_auto_times", None):  # precision 'auto': what the first view measured for the two organisations (rank 0's box)
-        result["config"]["auto_organisation"] = {"chosen": net.march_precision(),
-                                                 "first_view_march_ms": {k: round(v, 3) for k, v in net._auto_times.items()}}
+    if net.precision == "auto":
+        result["config"]["auto"] = {"chosen": net.march_precision(), "six_bit_small_fraction_worst_layer": net._auto[2] if net._auto else None}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         par = parity_check(sd, net, rend, poses[1], S)
         result["parity_linf"] = par["linf"]

@@ -32,31 +32,21 @@ extern "C" {
 
 #define NB_ABI_VERSION 17
 
-/* arithmetic of the decoder GEMMs (nb_decode_points / nb_march `precision` argument) */
-#define NB_PREC_F32 0    /* exact fp32 on v_mfma_f32_32x32x2_f32 */
-#define NB_PREC_BF16X3 1 /* bf16 hi+lo split of both operands, 3 products on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
-#define NB_PREC_F16F6R 2  /* nb_march only: the NB_PREC_F16F6 arithmetic on the ring organisation (one wave = 32 sample columns
-                             with its activations in registers, weights through an LDS ring by LDS-DMA, one workgroup per
-                             CU): the host of sample culling, and the reference point for measurements */
-#define NB_PREC_F16F8 3   /* nb_march only: fp16 main product on v_mfma_f32_32x32x16_f16 + the two cross terms of the
-                             fp16 head/remainder split in 8 bits (weights fp8 e4m3, activations bf8 e5m2) on
-                             v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate: ~2^-15 relative error per term at 1.8
-                             instead of 3 matrix-pipe units (ring organisation) */
-#define NB_PREC_F16F6 4   /* nb_march only, the default: the same split with the cross terms in 6 bits (weights fp6 e2m3 with a
-                             pack-time E8M0 scale per row and 32 K, activations bf6 e3m2 with a run-time E8M0 scale per sample
-                             and 32 K): the K=64 scaled MFMA then issues at the rate of one K=16 fp16 MFMA (8-bit: 1.9x).
-                             Workgroups organised by output-feature quarters (activations in LDS, weights straight from L2,
-                             two workgroups per CU); a culled march (nb_cull) runs on NB_PREC_F16F6R's kernel.
-                             Weight blocks whose elements span more than ~2^5 lose their small elements: see
-                             nb_mlp_six_bit_stats_offset() */
-
-#define NB_PREC_F16F6V 5  /* nb_march / nb_decode_points: the NB_PREC_F16F6 arithmetic for fc_1 .. rgb_fc with fc_0 FOLDED INTO THE
-                             VOLUME: trilinear interpolation and fc_0 are both linear with nothing between them
-                             (latent_xyzc.py:62-72,99), so fc_0 . interp(V) = interp(fc_0 . V).  nb_fold_build stores
-                             U_l = fc_0[:, level l] . V_l per ACTIVE voxel (256 channels, fp16 head + fp16 remainder); the
-                             march fetches the rows of the voxels its 64 samples touch and contracts them with the sparse
-                             trilinear-weight matrix Wt [voxel x sample] on the matrix pipe (three fp16 products per K = 16
-                             voxels, products exact, fp32 accumulate: fp32-level accuracy).  Needs nb_scene.fold. */
+/* arithmetic of the decoder (nb_decode_points / nb_march `precision` argument) */
+#define NB_PREC_F32 0   /* exact fp32 on v_mfma_f32_32x32x2_f32, trilinear gather of the dense volumes on the VALU: the reference's
+                           own precision (the training forward, the activation tap, debugging) */
+#define NB_PREC_F16F6 1 /* the default.  fc_0 FOLDED INTO THE VOLUME: trilinear interpolation and fc_0 are both linear with
+                           nothing between them (latent_xyzc.py:62-72,99), so fc_0 . interp(V) = interp(fc_0 . V).
+                           nb_fold_build stores U_l = fc_0[:, level l] . V_l per ACTIVE voxel (256 channels, fp16 head + fp16
+                           remainder); the kernel fetches the rows of the voxels its 64 samples touch and contracts them with
+                           the sparse trilinear-weight matrix Wt [voxel x sample] on the matrix pipe (three fp16 products per
+                           K = 16 voxels, products exact, fp32 accumulate: fp32-level accuracy).  Needs nb_scene.fold.
+                           fc_1, fc_2 and the colour head (feature_fc . latent_fc . view_fc folded into one layer): fp16 head x
+                           fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross terms in 6 bits (weights fp6
+                           e2m3 with a pack-time E8M0 scale per row and 32 K, activations bf6 e3m2 with a run-time E8M0 scale
+                           per sample and 32 K) on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate: ~2^-15 relative per term.
+                           Weight blocks whose elements span more than ~2^5 lose their small elements: see
+                           nb_mlp_six_bit_stats_offset() */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */
@@ -77,7 +67,7 @@ int nb_device_count(void);
  * (lib/networks/latent_xyzc.py:30-39).  Volumes are CHANNELS-LAST: vol[l] is a dense
  * [D_l, H_l, W_l, C_l] fp32 array (C_l = 32, 64, 128, 128), zeros at inactive voxels.
  * ------------------------------------------------------------------------------- */
-/* fc_0 folded into the four latent volumes (NB_PREC_F16F6V), built by nb_fold_build from the SAME volumes and fc_0 weight:
+/* fc_0 folded into the four latent volumes (NB_PREC_F16F6), built by nb_fold_build from the SAME volumes and fc_0 weight:
  * row r of level l = fc_0.weight[:, channels of level l] . V_l[voxel of row r]  (256 outputs) as 256 fp16 heads followed by 256
  * fp16 remainders (1 KiB); grid[l] = index grid of the level ([D_l,H_l,W_l] int32: row id inside the level or -1 = no row). */
 typedef struct nb_fold {
@@ -96,15 +86,15 @@ typedef struct nb_scene {
     const float *pose;
     float voxel_size[3]; /* cfg.voxel_size, dhw order (latent_xyzc.py:54) */
     int32_t out_sh[3];   /* full-resolution grid D,H,W (sp_input['out_sh']) */
-    const nb_fold *fold; /* HOST pointer or NULL; required by NB_PREC_F16F6V (which does not read vol[]) */
+    const nb_fold *fold; /* HOST pointer or NULL; required by NB_PREC_F16F6 (which does not read vol[]) */
 } nb_scene;
 #define NB_POSE_FLOATS 15
 
 /* ---------------------------------------------------------------------------------
  * Packed decoder weights.  nb_mlp_pack_size() floats; produced by nb_mlp_pack() from
  * the reference's parameter tensors (Conv1d(k=1) weights [out,in,1] viewed as [out,in]).
- * The blob holds both formats (fp32 fragments for NB_PREC_F32, a bf16 hi/lo fragment stream for
- * NB_PREC_BF16X3).  The packing re-orders every layer into MFMA A-operand fragment order and merges
+ * The blob holds both formats (fp32 fragments for NB_PREC_F32, the fp16 / fp6 fragment stream of NB_PREC_F16F6).
+ * The packing re-orders every layer into MFMA A-operand fragment order and merges
  * feature_fc with the first 256 columns of latent_fc (no activation sits between them,
  * latent_xyzc.py:106-111).  nb_mlp_latent_bias() folds the per-frame latent code
  * (latent_xyzc.py:108-111) into that merged layer's bias; call it whenever
@@ -112,11 +102,12 @@ typedef struct nb_scene {
  * ------------------------------------------------------------------------------- */
 int64_t nb_mlp_pack_size(void);        /* floats in the packed blob */
 int64_t nb_mlp_latent_bias_size(void); /* floats in the per-frame bias block (384: see nb_mlp_latent_bias) */
-/* Float offset inside the packed blob of 8 int32 counters written with the NB_PACK_F16F6 section: for each of the four
- * layers of that kernel (fc_0, fc_1, fc_2, the folded feature_fc / latent_fc / view_fc layer) {small, nonzero} = how many non-zero weights lie below 1/8 of the maximum of
- * their (row, 32 K) block — where fp6 e2m3 keeps fewer than 3 significant bits — and how many are non-zero at all.
- * small / nonzero is ~0.2 for normally distributed weights; a caller that cannot rule out weight blocks with a wide
- * dynamic range (> ~2^5) uses it to fall back to NB_PREC_F16F8 (the Python Network does, precision "auto"). */
+/* Float offset inside the packed blob of 6 int32 counters written with the NB_PACK_F16F6 section: for each of the three
+ * layers that kernel runs with six-bit cross terms (fc_1, fc_2, the folded feature_fc / latent_fc / view_fc layer) {small, nonzero}
+ * = how many non-zero weights lie below 1/8 of the maximum of their (row, 32 K) block — where fp6 e2m3 keeps fewer than 3
+ * significant bits — and how many are non-zero at all.  small / nonzero is ~0.2 for normally distributed weights; a caller that
+ * cannot rule out weight blocks with a wide dynamic range (> ~2^5) uses it to fall back to NB_PREC_F32 (the Python Network does,
+ * precision "auto"). */
 int64_t nb_mlp_six_bit_stats_offset(void);
 
 typedef struct nb_mlp_params { /* all dev, row-major [out,in] / [out] */
@@ -136,21 +127,17 @@ int nb_mlp_pack(const nb_mlp_params *p, float *packed, void *stream);
 /* The same, writing only the sections a caller is going to use (a training step changes the weights every iteration and
  * decodes with NB_PREC_F32 only).  The fp32 section (NB_PACK_F32) is always written. */
 #define NB_PACK_F32 1
-#define NB_PACK_BF16X3 2
-#define NB_PACK_F16F6R 4 /* the ring-organised six-bit stream alone (NB_PACK_F16F6 includes it) */
-#define NB_PACK_F16F8 8
-#define NB_PACK_F16F6 16
-#define NB_PACK_F16F6V 32 /* the weight stream of NB_PREC_F16F6V (fc_1, fc_2, the folded colour head; fc_0 lives in nb_fold) */
-#define NB_PACK_ALL 63
+#define NB_PACK_F16F6 2 /* the weight stream of NB_PREC_F16F6 (fc_1, fc_2, the folded colour head; fc_0 lives in nb_fold) */
+#define NB_PACK_ALL 3
 int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, void *stream);
 /* latent_row: dev pointer to latent.weight[latent_index] (128 floats);
  * out: dev, nb_mlp_latent_bias_size() floats = [256: bias of the merged feature_fc / latent_fc layer with the latent code
  * folded in | 128: bias of view_fc with that layer folded in as well (feature_fc, latent_fc and view_fc have no activation
- * between them, latent_xyzc.py:105-119; NB_PREC_F16F8 / NB_PREC_F16F6 run them as one layer)], MFMA fragment order. */
+ * between them, latent_xyzc.py:105-119; NB_PREC_F16F6 runs them as one layer)], MFMA fragment order. */
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream);
 
 /* ---------------------------------------------------------------------------------
- * nb_fold_build — the encoder-side half of NB_PREC_F16F6V: replaces the first decoder layer's weight access in
+ * nb_fold_build — the encoder-side half of NB_PREC_F16F6: replaces the first decoder layer's weight access in
  * Network.calculate_density_color (lib/networks/latent_xyzc.py:99, `self.fc_0(features)`) together with the four
  * F.grid_sample calls feeding it (:62-72), by pre-multiplying every ACTIVE voxel of the four volumes with fc_0.
  *   vol[l] dev channels-last [D_l,H_l,W_l,C_l] fp32 (nb_scene.vol); rows_lin[l] dev [n_rows_max[l]] int32: linear voxel index
@@ -174,7 +161,7 @@ int nb_sparsify(const float *vol, const int32_t dhw[3], int32_t c, int32_t *grid
  * Network.calculate_density (:74-89).
  *   wpts    dev [n,3] world-space points; viewdir dev [n,3] (ignored when density_only)
  *   raw_out dev [n,4] (rgb logits, sigma)   or [n,1] sigma when density_only
- *   dbg     dev or NULL: activation tap, NB_TAP_WIDTH floats per point:
+ *   dbg     dev or NULL (NB_PREC_F32 only): activation tap, NB_TAP_WIDTH floats per point:
  *           [F 352 | h1 256 | h2 256 | h3 256 | G 256 (latent_fc output) | V 128 | PE 90 | pad]
  *           (post-ReLU where the layer has one) — what the backward pass consumes; also used by tests
  * ------------------------------------------------------------------------------- */
@@ -189,6 +176,7 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
  * (if_clight_renderer_mmsk.py:54-59).  pre_affine != 0 (the _msk variant) first maps the point
  * world -> SMPL space of the rendered pose (scene R, Th) -> world of the snapshot frame (R0, Th0).
  * ------------------------------------------------------------------------------- */
+#define NB_SLOT_DEAD (-2147483647 - 1) /* nb_march ray_order: empty slot */
 #define NB_MAX_CULL_VIEWS 64 /* the reference loops over batch['Ks'].size(1) training views (4 or 6 in the shipped configs) */
 #define NB_CULL_CAM_FLOATS 21
 typedef struct nb_cull {
@@ -201,7 +189,7 @@ typedef struct nb_cull {
 } nb_cull;
 
 /* ---------------------------------------------------------------------------------
- * nb_march — the fused per-ray path: replaces Renderer.get_pixel_value
+ * nb_march — the fused per-ray path (both precisions serve sample culling and the raw output): replaces Renderer.get_pixel_value
  * (lib/networks/renderer/if_clight_renderer.py:62-92), i.e. get_sampling_points (:11-27),
  * get_density_color (:54-60), Network.calculate_density_color and raw2outputs
  * (lib/networks/renderer/nerf_net_utils.py:6-51, raw_noise_std = 0), for ALL rays of a
@@ -209,9 +197,12 @@ typedef struct nb_cull {
  *   ray_o, ray_d dev [n_rays,3]; near, far dev [n_rays]
  *   t_vals  dev [n_samples]  = torch.linspace(0,1,n_samples)   (if_clight_renderer.py:13)
  *   t_rand  dev [n_rays,n_samples] in [0,1) or NULL            (stratified jitter, :16-23)
- *   ray_order dev [n_rays] int32 permutation or NULL: lane slot i marches ray ray_order[i].  Results are
- *           written at the ray's own index, so this only changes WHICH rays share a wavefront (e.g. 8x4
- *           pixel tiles instead of row segments, for gather locality); outputs are bit-identical.
+ *   ray_order dev [n_slots] int32 or NULL (n_slots ignored, slot i = ray i): WHICH rays march together.  64 consecutive slots
+ *           share a workgroup (whose voxel list is the union of what its samples touch: the caller groups neighbouring
+ *           pixels, e.g. 8 x 8 tiles).  Entry v >= 0: the slot marches ray v and stores its results at the ray's own index;
+ *           v = -(r + 1) in (NB_SLOT_DEAD, 0): a padding slot that marches ray r's data and stores nothing (keeps a partially
+ *           filled tile's group together); NB_SLOT_DEAD: an empty slot — a group of 64 (aligned) slots is either free of
+ *           them or consists of them (it is skipped).  Every ray must appear exactly once as v >= 0.  n_slots % 64 == 0.
  *   cull    HOST pointer to an nb_cull (whose msk / cam / snap members are DEVICE pointers) or NULL (no culling)
  *   outputs dev: rgb_map [n_rays,3], disp_map/acc_map/depth_map [n_rays],
  *           weights [n_rays,n_samples]; raw (optional, may be NULL) [n_rays,n_samples,4]
@@ -219,7 +210,7 @@ typedef struct nb_cull {
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias,
              const float *ray_o, const float *ray_d, const float *near, const float *far,
              int64_t n_rays, int32_t n_samples, const float *t_vals, const float *t_rand,
-             const int32_t *ray_order, const nb_cull *cull, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
+             const int32_t *ray_order, int64_t n_slots, const nb_cull *cull, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
              float *depth_map, float *raw, int precision, void *stream);
 
 /* ---------------------------------------------------------------------------------

@@ -10,8 +10,9 @@ HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
 ABI_VERSION = 17
-PRECISIONS = {"f32": 0, "bf16x3": 1, "f16f6r": 2, "f16f8": 3, "f16f6": 4, "f16f6v": 5}
-PACK_SECTIONS = {"f32": 1, "bf16x3": 2, "f16f6r": 4, "f16f8": 8, "f16f6": 16, "f16f6v": 32}
+SLOT_DEAD = -2147483648  # NB_SLOT_DEAD
+PRECISIONS = {"f32": 0, "f16f6": 1}
+PACK_SECTIONS = {"f32": 1, "f16f6": 2}
 
 
 class NbFold(C.Structure):
@@ -70,7 +71,7 @@ SIGNATURES = {
     "nb_fold_build": (C.c_int, [C.c_void_p * 4, C.c_void_p * 4, C.c_void_p * 4, C.c_int32 * 4, _P, _P, _P]),
     "nb_sparsify": (C.c_int, [_P, _I32x3, _I32, _P, _P, _P, _I32, _P, _P]),
     "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
-    "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, C.POINTER(NbCull), C.c_int,
+    "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, C.POINTER(NbCull), C.c_int,
                            _P, _P, _P, _P, _P, _P, C.c_int, _P]),
     "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
     "nb_composite_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P]),

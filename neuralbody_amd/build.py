@@ -21,10 +21,10 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-I" + os.path.
          "-Wno-unused-result"] + os.environ.get("NB_EXTRA_FLAGS", "").split()
 
 
-# per-file flags.  nb_march_ms6.hip: hipcc's SLP vectoriser packs the gather's and the heads' scalar fp32 FMAs into v_pk_fma_f32,
+# per-file flags.  nb_march_fold.hip: hipcc's SLP vectoriser packs the gather's and the heads' scalar fp32 FMAs into v_pk_fma_f32,
 # which on gfx950 costs an order of magnitude more issue time than the two v_fma_f32 it replaces (MI355X_MICROARCH.md,
 # "price of one filler": +22 cycles per v_pk_fma_f32) and needs aligned register pairs (33 spilled registers with, 0 without)
-FILE_FLAGS = {"nb_march_ms6.hip": ["-fno-slp-vectorize"], "nb_march_fold.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
+FILE_FLAGS = {"nb_march_fold.hip": ["-fno-slp-vectorize", "-Wno-inline-asm"]}
 
 
 def sources():

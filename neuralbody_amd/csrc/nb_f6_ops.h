@@ -1,5 +1,5 @@
-// nb_f6_ops.h — operand conversions of the "f16f6" arithmetic shared by the ring kernel (nb_march_f16.hip, -DF_SIX) and
-// the M-split kernel (nb_march_ms6.hip):  W.X ~= W_h.X_h (fp16 MFMA) + fp6(W_h).bf6(X_l) + fp6(W_l).bf6(X_h) (scaled K=64 MFMA).
+// nb_f6_ops.h — operand conversions of the "f16f6" arithmetic (nb_march_fold.hip):
+//     W.X ~= W_h.X_h (fp16 MFMA) + fp6(W_h).bf6(X_l) + fp6(W_l).bf6(X_h) (scaled K=64 MFMA).
 #pragma once
 #include "nb_march_common.h"
 

@@ -228,11 +228,16 @@ __global__ __launch_bounds__(256) void nb_march_kernel(MarchArgs a) {
     const int lane = threadIdx.x & 63, j = lane & 31, hi = lane >> 5;
     const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
     const long long wave = (long long)grp * 4 + (threadIdx.x >> 6);
-    if (wave * 32 >= a.n_rays) return;  // wave-uniform
+    if (wave * 32 >= (a.ray_order ? a.n_slots : a.n_rays)) return;  // wave-uniform
     long long ray = wave * 32 + j;
-    const bool valid = ray < a.n_rays;
+    bool valid = ray < a.n_rays;
     if (!valid) ray = a.n_rays - 1;
-    if (a.ray_order) ray = a.ray_order[ray];
+    if (a.ray_order) {
+        if (a.ray_order[wave * 32] == NB_SLOT_DEAD) return;  // an empty group of slots (wave-uniform)
+        const int v = a.ray_order[wave * 32 + j];
+        valid = v >= 0;
+        ray = valid ? v : -(long long)v - 1;
+    }
     const int S = a.n_samples;
     const float ox = a.ray_o[ray * 3 + 0], oy = a.ray_o[ray * 3 + 1], oz = a.ray_o[ray * 3 + 2];
     const float dx = a.ray_d[ray * 3 + 0], dy = a.ray_d[ray * 3 + 1], dz = a.ray_d[ray * 3 + 2];
@@ -428,13 +433,10 @@ __global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__
 
 extern "C" {
 
-static long long ms6_stream_off() { return PACK_SIZE + nbm::bf16_stream_floats(); }
-static long long f16_stream_off() { return ms6_stream_off() + nbm::ms6_stream_floats(); }
-static long long f6_stream_off() { return f16_stream_off() + nbm::f16_stream_floats(); }
-static long long fold_stream_off() { return f6_stream_off() + nbm::f6_stream_floats(); }
+static long long fold_stream_off() { return PACK_SIZE; }
 int64_t nb_mlp_pack_size(void) { return fold_stream_off() + nbm::fold_stream_floats(); }
 int64_t nb_mlp_latent_bias_size(void) { return 384; }
-int64_t nb_mlp_six_bit_stats_offset(void) { return f6_stream_off() + nbm::f6_stream_floats() - 16; }
+int64_t nb_mlp_six_bit_stats_offset(void) { return nb_mlp_pack_size() - 8; }
 
 static int check_params(const nb_mlp_params *p) {
     NB_REQUIRE(p != nullptr, "nb_mlp_params is NULL");
@@ -455,16 +457,7 @@ int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, vo
     // the fp32 section is always written: the other streams read the merged feature/latent layer from it
     hipLaunchKernelGGL(nb_pack_kernel, dim3(nb_ceil_div(PACK_SIZE, 256)), dim3(256), 0, (hipStream_t)stream, *p, packed);
     NB_CHECK_LAUNCH("nb_pack_kernel");
-    if (sections & NB_PACK_BF16X3)
-        if (int rc = nbm::pack_bf16_stream(p, packed, (hipStream_t)stream)) return rc;
     if (sections & NB_PACK_F16F6)
-        if (int rc = nbm::pack_ms6_stream(p, packed, ms6_stream_off(), (hipStream_t)stream)) return rc;
-    if (sections & NB_PACK_F16F8)
-        if (int rc = nbm::pack_f16_stream(p, packed, f16_stream_off(), (hipStream_t)stream)) return rc;
-    // the ring-organised six-bit stream: NB_PREC_F16F6R, culled marches of NB_PREC_F16F6, and the small-element statistic
-    if (sections & (NB_PACK_F16F6 | NB_PACK_F16F6R))
-        if (int rc = nbm::pack_f6_stream(p, packed, f6_stream_off(), (hipStream_t)stream)) return rc;
-    if (sections & NB_PACK_F16F6V)
         if (int rc = nbm::pack_fold_stream(p, packed, fold_stream_off(), (hipStream_t)stream)) return rc;
     return NB_OK;
 }
@@ -485,10 +478,8 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
     if (n == 0) return NB_OK;
     NB_REQUIRE(wpts && raw_out, "nb_decode_points: NULL wpts / raw_out");
     NB_REQUIRE(density_only || (viewdir && latent_bias), "nb_decode_points: viewdir / latent_bias required");
-    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6V,
-               "nb_decode_points: precision %d", precision);
-    NB_REQUIRE(!(dbg && (precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6V)),
-               "nb_decode_points: NB_PREC_F16F6 / NB_PREC_F16F6V have no activation tap (use NB_PREC_F32)");
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_F16F6, "nb_decode_points: precision %d", precision);
+    NB_REQUIRE(!(dbg && precision == NB_PREC_F16F6), "nb_decode_points: NB_PREC_F16F6 has no activation tap (use NB_PREC_F32)");
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
     a.pk = packed;
@@ -500,15 +491,11 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
     a.dbg = dbg;
     const dim3 grid(nb_ceil_div(n, 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (precision == NB_PREC_F16F6V) {
+    if (precision == NB_PREC_F16F6) {
         if (int rc = fill_fold(scene, &a.fold)) return rc;
         return nbm::launch_points_fold(a, density_only, fold_stream_off(), st);
     }
-    if (precision == NB_PREC_F16F6) return nbm::launch_points_ms6(a, density_only, ms6_stream_off(), st);
-    if (precision == NB_PREC_BF16X3) {
-        if (!a.lb) a.lb = packed + OFF_B2;  // density only: the (unused) colour head still needs a readable bias
-        return nbm::launch_points_bf16(a, density_only, st);
-    }
+    for (int l = 0; l < 4; ++l) NB_REQUIRE(scene->vol[l] != nullptr, "nb_decode_points: NB_PREC_F32 reads nb_scene.vol[%d]", l);
     if (density_only) hipLaunchKernelGGL((nb_points_kernel<true, false>), grid, block, 0, st, a);
     else if (dbg) hipLaunchKernelGGL((nb_points_kernel<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((nb_points_kernel<false, false>), grid, block, 0, st, a);
@@ -518,7 +505,7 @@ int nb_decode_points(const nb_scene *scene, const float *packed, const float *la
 
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias, const float *ray_o,
              const float *ray_d, const float *near, const float *far, int64_t n_rays, int32_t n_samples,
-             const float *t_vals, const float *t_rand, const int32_t *ray_order, const nb_cull *cull, int white_bkgd,
+             const float *t_vals, const float *t_rand, const int32_t *ray_order, int64_t n_slots, const nb_cull *cull, int white_bkgd,
              float *rgb_map, float *disp_map,
              float *acc_map, float *weights, float *depth_map, float *raw, int precision, void *stream) {
     NB_REQUIRE(scene && packed && latent_bias, "nb_march: NULL scene / weights");
@@ -526,24 +513,22 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     if (n_rays == 0) return NB_OK;
     NB_REQUIRE(ray_o && ray_d && near && far && t_vals, "nb_march: NULL ray input");
     NB_REQUIRE(rgb_map && disp_map && acc_map && weights && depth_map, "nb_march: NULL output");
+    NB_REQUIRE(!ray_order || (n_slots >= 64 && n_slots % 64 == 0 && n_slots < (1ll << 31)), "nb_march: ray_order with n_slots = %lld (a positive multiple of 64)",
+               (long long)n_slots);
     MarchArgs a = {};
     if (int rc = fill_scene(scene, &a.sc)) return rc;
     if (int rc = fill_cull(cull, &a.cull)) return rc;
     fill_march_args(a, packed, latent_bias, ray_o, ray_d, near, far, n_rays, n_samples, t_vals, t_rand, ray_order,
                     white_bkgd,
                     rgb_map, disp_map, acc_map, weights, depth_map, raw);
-    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_BF16X3 || precision == NB_PREC_F16F6R || precision == NB_PREC_F16F8 ||
-                   precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6V,
-               "nb_march: precision %d", precision);
-    if (precision == NB_PREC_F16F6V) {
+    a.n_slots = ray_order ? n_slots : 0;
+    if (ray_order) a.n_wave_groups = nb_ceil_div(n_slots, 128);
+    NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_F16F6, "nb_march: precision %d", precision);
+    if (precision == NB_PREC_F16F6) {
         if (int rc = fill_fold(scene, &a.fold)) return rc;
         return nbm::launch_march_fold(a, fold_stream_off(), (hipStream_t)stream);
     }
-    if (precision == NB_PREC_F16F8) return nbm::launch_march_f16(a, f16_stream_off(), (hipStream_t)stream);
-    // the M-split kernel has no sample culling: culled marches take the ring kernel (same arithmetic, same packed section)
-    if (precision == NB_PREC_F16F6 && !a.cull.n_views) return nbm::launch_march_ms6(a, ms6_stream_off(), (hipStream_t)stream);
-    if (precision == NB_PREC_F16F6 || precision == NB_PREC_F16F6R) return nbm::launch_march_f6(a, f6_stream_off(), (hipStream_t)stream);
-    if (precision != NB_PREC_F32) return nbm::launch_march_bf16(a, (hipStream_t)stream);
+    for (int l = 0; l < 4; ++l) NB_REQUIRE(scene->vol[l] != nullptr, "nb_march: NB_PREC_F32 reads nb_scene.vol[%d]", l);
     hipLaunchKernelGGL(nb_march_kernel, dim3(a.n_wave_groups), dim3(256), 0, (hipStream_t)stream, a);
     NB_CHECK_LAUNCH("nb_march_kernel");
     return NB_OK;

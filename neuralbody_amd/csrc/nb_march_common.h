@@ -1,6 +1,6 @@
-// nb_march_common.h — device code shared by the f32 (nb_march.hip) and split-bf16 (nb_march_bf16.hip)
-// decode / march kernels: scene + argument structs, feature-vector layout, trilinear gather,
-// positional encoding, sampling helpers, XCD-aware block remap.
+// nb_march_common.h — device code shared by the exact-fp32 (nb_march.hip) and the fc_0-folded f16f6 (nb_march_fold.hip)
+// decode / march kernels: scene + argument structs, feature-vector layout, the fp32 kernel's trilinear gather,
+// positional encoding, sampling helpers, compositing, XCD-aware block remap.
 #pragma once
 #include "nb_common.h"
 
@@ -84,7 +84,7 @@ struct SceneDev {
                                  // them itself keeps the results in VGPRs across its depth loop)
 };
 
-// fc_0 folded into the volumes (nb_fold, NB_PREC_F16F6V): rows of 256 fp16 heads + 256 fp16 remainders, index grids
+// fc_0 folded into the volumes (nb_fold, NB_PREC_F16F6): rows of 256 fp16 heads + 256 fp16 remainders, index grids
 struct FoldDev {
     const char *urows;
     const int *grid[4];
@@ -149,7 +149,8 @@ struct MarchArgs {
     const float *lb;
     // ray mode
     const float *ray_o, *ray_d, *near, *far, *t_vals, *t_rand;
-    const int *ray_order;  // optional slot -> ray permutation
+    const int *ray_order;  // optional slot -> ray list (nb_hip.h: >= 0 ray, -(r + 1) padding slot, NB_SLOT_DEAD empty)
+    long long n_slots;     // its length (ray_order != NULL), a multiple of 64
     float *rgb_map, *disp_map, *acc_map, *weights, *depth_map, *raw;
     long long n_rays;
     int n_samples;
@@ -430,101 +431,6 @@ __device__ __forceinline__ void gather_level_coop(const SceneDev &sc, const Grid
     }
 }
 
-// ---- the cooperative gather in two stages, so that the tile fetches of ALL levels can be in flight together:
-//   coop_issue<L>  : index box of the wave, up to BUF_BYTES / 1024 coalesced 16-byte fetches per lane into registers
-//   coop_finish<L> : registers -> wave-private LDS tile, then every lane blends its 8 corners from the tile
-// (falls back to the per-lane gather when the box does not fit, like gather_level_coop)
-template <int BUF_BYTES>
-struct CoopFetch {
-    f32x4 t[BUF_BYTES / 1024];
-    int xlo, ylo, zlo, xhi, yhi, zhi, pieces;
-};
-
-template <int L, int BUF_BYTES>
-__device__ __forceinline__ void coop_issue(const SceneDev &sc, const WaveBox &wb, int lane, CoopFetch<BUF_BYTES> &cf) {
-    constexpr int C = lvl_c(L), PC = C / 4;
-    constexpr int MAX_IT = BUF_BYTES / 1024;
-    const int D = sc.dhw[L][0], H = sc.dhw[L][1], W = sc.dhw[L][2];
-    cf.xlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gw, W)), 0), W - 1));
-    cf.ylo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gh, H)), 0), H - 1));
-    cf.zlo = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.lo.gd, D)), 0), D - 1));
-    cf.xhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gw, W)) + 1, 0), W - 1));
-    cf.yhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gh, H)) + 1, 0), H - 1));
-    cf.zhi = __builtin_amdgcn_readfirstlane(min(max((int)floorf(unnorm_clamped(wb.hi.gd, D)) + 1, 0), D - 1));
-    const int nx = cf.xhi - cf.xlo + 1, ny = cf.yhi - cf.ylo + 1, nz = cf.zhi - cf.zlo + 1;
-    cf.pieces = nx * ny * nz * PC;
-    if (cf.pieces > BUF_BYTES / 16) return;  // wave-uniform: coop_finish takes the per-lane path
-    const float rcp_xy = __builtin_amdgcn_rcpf((float)(nx * ny)), rcp_x = __builtin_amdgcn_rcpf((float)nx);  // v + 0.5 absorbs 1 ulp
-#pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-        if (it * 64 < cf.pieces) {  // wave-uniform
-            const int p = min(it * 64 + lane, cf.pieces - 1);
-            const int v = p / PC, q = p % PC;
-            const int vz = (int)(((float)v + 0.5f) * rcp_xy);
-            const int r = v - vz * nx * ny;
-            const int vy = (int)(((float)r + 0.5f) * rcp_x);
-            const int vx = r - vy * nx;
-            const size_t lin = ((size_t)((cf.zlo + vz) * H + (cf.ylo + vy))) * W + (cf.xlo + vx);
-            cf.t[it] = *reinterpret_cast<const f32x4 *>(sc.vol[L] + lin * C + q * 4);
-        }
-    }
-}
-
-template <int L, int BUF_BYTES>
-__device__ __forceinline__ void coop_finish(const SceneDev &sc, const GridCoord &g, const CoopFetch<BUF_BYTES> &cf, int hi, int lane,
-                                            char *buf, float (&out)[lvl_c(L) / 2]) {
-    constexpr int C = lvl_c(L), HALF = C / 2;
-    constexpr int MAX_IT = BUF_BYTES / 1024;
-    const int D = sc.dhw[L][0], H = sc.dhw[L][1], W = sc.dhw[L][2];
-    if (cf.pieces > BUF_BYTES / 16) {
-        gather_level<L>(sc, g, hi, out);
-        return;
-    }
-#pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-        if (it * 64 < cf.pieces) {
-            const int p = it * 64 + lane;
-            if (p < cf.pieces) *reinterpret_cast<f32x4 *>(buf + p * 16) = cf.t[it];
-        }
-    }
-    const int xlo = cf.xlo, ylo = cf.ylo, zlo = cf.zlo, xhi = cf.xhi, yhi = cf.yhi, zhi = cf.zhi;
-    const int nx = xhi - xlo + 1, ny = yhi - ylo + 1;
-    const float ix = unnorm_clamped(g.gw, W), iy = unnorm_clamped(g.gh, H), iz = unnorm_clamped(g.gd, D);
-    const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
-    const int x0 = (int)fx, y0 = (int)fy, z0 = (int)fz;
-    const float wx[2] = {(fx + 1.f) - ix, ix - fx};
-    const float wy[2] = {(fy + 1.f) - iy, iy - fy};
-    const float wz[2] = {(fz + 1.f) - iz, iz - fz};
-    const f32x4 *cp[8];
-    float cw[8];
-#pragma unroll
-    for (int corner = 0; corner < 8; ++corner) {
-        const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
-        const int xx = x0 + dx, yy = y0 + dy, zz = z0 + dz;
-        const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
-        cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
-        const int xc = min(max(xx, xlo), xhi), yc = min(max(yy, ylo), yhi), zc = min(max(zz, zlo), zhi);
-        const int lv = ((zc - zlo) * ny + (yc - ylo)) * nx + (xc - xlo);
-        cp[corner] = reinterpret_cast<const f32x4 *>(buf + (lv * C + hi * HALF) * 4);
-    }
-#pragma unroll
-    for (int q = 0; q < HALF / 4; ++q) {
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int corner = 0; corner < 8; ++corner) {
-            const f32x4 v = cp[corner][q];
-            a.x = fmaf(cw[corner], v.x, a.x);
-            a.y = fmaf(cw[corner], v.y, a.y);
-            a.z = fmaf(cw[corner], v.z, a.z);
-            a.w = fmaf(cw[corner], v.w, a.w);
-        }
-        out[q * 4 + 0] = a.x;
-        out[q * 4 + 1] = a.y;
-        out[q * 4 + 2] = a.z;
-        out[q * 4 + 3] = a.w;
-    }
-}
-
 // all four levels through the cooperative gather (tile = wave-private LDS of TILE bytes)
 template <int TILE>
 __device__ __forceinline__ void gather_features(const SceneDev &sc, float px, float py, float pz, int hi, int lane,
@@ -649,7 +555,7 @@ inline int fill_scene(const nb_scene *s, SceneDev *d) {
 // fold != NULL is required (and checked) by the kernels that read it only
 inline int fill_fold(const nb_scene *s, FoldDev *d) {
     const nb_fold *f = s->fold;
-    NB_REQUIRE(f != nullptr, "nb_scene.fold is NULL: NB_PREC_F16F6V marches the fc_0-folded planes of nb_fold_build");
+    NB_REQUIRE(f != nullptr, "nb_scene.fold is NULL: NB_PREC_F16F6 marches the fc_0-folded planes of nb_fold_build");
     NB_REQUIRE(f->urows != nullptr && f->zero_row >= 0 && f->zero_row < (1 << 21), "nb_fold: urows NULL or zero_row %d out of range",
                f->zero_row);
     d->urows = reinterpret_cast<const char *>(f->urows);
@@ -705,28 +611,11 @@ inline void fill_march_args(MarchArgs &a, const float *packed, const float *late
     a.n_wave_groups = nb_ceil_div(n_rays, 128);
 }
 
-// split-bf16 kernel family (nb_march_bf16.hip)
-long long bf16_stream_floats();
-int pack_bf16_stream(const nb_mlp_params *p, float *packed, hipStream_t st);
-int launch_points_bf16(const MarchArgs &a, int density_only, hipStream_t st);
-int launch_march_bf16(const MarchArgs &a, hipStream_t st);
-// M-split fp16 + scaled-6-bit march (nb_march_ms6.hip); stream_off = float offset of its weight stream inside the packed blob
-long long ms6_stream_floats();
-int pack_ms6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
-int launch_march_ms6(MarchArgs a, long long stream_off, hipStream_t st);
-int launch_points_ms6(MarchArgs a, int density_only, long long stream_off, hipStream_t st);
-// fc_0 folded into the volumes, fp16 + scaled-6-bit for the remaining layers (nb_march_fold.hip)
+// fc_0 folded into the volumes, fp16 + scaled-6-bit for the remaining layers (nb_march_fold.hip); stream_off = float offset of
+// its weight stream inside the packed blob, stats: 6 ints behind it (nb_mlp_six_bit_stats_offset)
 long long fold_stream_floats();
 int pack_fold_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
 int launch_march_fold(MarchArgs a, long long stream_off, hipStream_t st);
 int launch_points_fold(MarchArgs a, int density_only, long long stream_off, hipStream_t st);
-// fp16 + scaled-8-bit march (nb_march_f16.hip)
-long long f16_stream_floats();
-int pack_f16_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
-int launch_march_f16(const MarchArgs &a, long long stream_off, hipStream_t st);
-// fp16 + scaled-6-bit march (nb_march_f6.hip = nb_march_f16.hip with -DF_SIX)
-long long f6_stream_floats();
-int pack_f6_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st);
-int launch_march_f6(const MarchArgs &a, long long stream_off, hipStream_t st);
 
 }  // namespace nbm

@@ -8,9 +8,9 @@
 //     H1_pre [256 features x 64 samples]  =  U^T [256 x K voxels] . Wt [K x 64]
 // with K = the workgroup's voxel list (padded to 16), U_h.Wt_h + U_h.Wt_l + U_l.Wt_h on v_mfma_f32_32x32x16_f16 (fp16 head +
 // fp16 remainder of both operands: products exact, fp32 accumulation, the dropped term is 2^-22): fp32-level accuracy.
-// Against the gather + fc_0 of nb_march_ms6.hip this removes the 2816 gather FMAs and 352 operand conversions per sample, 96 of
-// the 272 weight pieces per wave and depth step, and two thirds of fc_0's MFMAs (12 per 16 voxels and wave instead of 144 per
-// step).  Everything behind fc_0 is the M-split f16f6 organisation of nb_march_ms6.hip unchanged:
+// Against a per-sample gather + fc_0 (round 3's kernel) this removes the 2816 gather FMAs and 352 operand conversions per sample,
+// 96 of 272 weight pieces per wave and depth step, and two thirds of fc_0's MFMAs (12 per 16 voxels and wave instead of 144 per
+// step).  Everything behind fc_0 is the "M-split" f16f6 organisation:
 //
 //   * a workgroup (4 waves) marches 64 rays; wave w owns a QUARTER OF EVERY LAYER'S OUTPUT FEATURES for all 64 samples; a weight
 //     fragment feeds 2 MFMAs and comes straight from L2 into a register ring;
@@ -367,22 +367,24 @@ __device__ __forceinline__ int mad24(int a, int b, int c) {
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-template <int MASK>
-__device__ __forceinline__ int swz_xor_i(int v) {
-    return __builtin_amdgcn_ds_swizzle(v, 0x1f | (MASK << 10));
+// min / max over the 16 lanes of a DPP row (= the 16 samples of one (wave, level)): row rotations, plain VALU instructions —
+// the ds_swizzle butterflies they replace are LDS-crossbar round trips behind an lgkmcnt wait each
+template <int N>
+__device__ __forceinline__ int row_ror(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, 0x120 | N, 0xf, 0xf, false);
 }
 __device__ __forceinline__ int red_min16i(int v) {
-    v = min(v, swz_xor_i<8>(v));
-    v = min(v, swz_xor_i<4>(v));
-    v = min(v, swz_xor_i<2>(v));
-    v = min(v, swz_xor_i<1>(v));
+    v = min(v, row_ror<8>(v));
+    v = min(v, row_ror<4>(v));
+    v = min(v, row_ror<2>(v));
+    v = min(v, row_ror<1>(v));
     return v;
 }
 __device__ __forceinline__ int red_max16i(int v) {
-    v = max(v, swz_xor_i<8>(v));
-    v = max(v, swz_xor_i<4>(v));
-    v = max(v, swz_xor_i<2>(v));
-    v = max(v, swz_xor_i<1>(v));
+    v = max(v, row_ror<8>(v));
+    v = max(v, row_ror<4>(v));
+    v = max(v, row_ror<2>(v));
+    v = max(v, row_ror<1>(v));
     return v;
 }
 
@@ -621,43 +623,95 @@ __device__ __forceinline__ f16x8 tr_frag(const char *p) {
     typedef short s8v __attribute__((ext_vector_type(8)));
     return __builtin_bit_cast(f16x8, s8v{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]});
 }
-// acc += U^T . Wt over the step's K list: per chunk 4 A fragments (2 tiles x heads, remainders) and 4 B fragments feed 12 MFMAs
-__device__ __forceinline__ void fold_mfma(const MarchArgs &a, char *actz, int lane, int wave, const UCfg &u, f32x16 (&acc)[2][2]) {
-    const int l15 = lane & 15, g4 = lane >> 4;
-    const int tro = (g4 >> 1) * 512 + (g4 & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
-    const char *wt = actz + lane * 16;
-    int slot = 0;
-    for (int c = 0; c < u.nch; ++c) {
-        if (c == 0 || c >= u.R) dma_wait();
-        const char *ub = actz + u.ring_off + slot * U_CHUNK + tro;
-        f16x8 ah[2], al[2];
-        i32x4 bh[2], bl[2];
+// acc += U^T . Wt over the step's K list: per chunk 4 A fragments (2 tiles x heads, remainders) and 4 B fragments feed 12 MFMAs.
+// Software-pipelined: the fragments of chunk c + 1 are read from LDS (and, beyond the R resident chunks, its DMA awaited with
+// a COUNTED vmcnt: 4 instructions per younger chunk) before the MFMAs of chunk c are issued; the slot of chunk c is refilled
+// with chunk c + R as soon as its reads have returned.
+struct FoldFrags {
+    f16x8 ah[2], al[2];
+    i32x4 bh[2], bl[2];
+};
+__device__ __forceinline__ void fold_wait(int younger) {  // the chunk with `younger` chunks issued behind it has landed
+    if (younger >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (younger == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void fold_read(FoldFrags &f, const char *ub, const char *wtc) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            ah[m] = tr_frag(ub + m * 1024);
-            al[m] = tr_frag(ub + 2048 + m * 1024);
-        }
+    for (int m = 0; m < 2; ++m) {
+        f.ah[m] = tr_frag(ub + m * 1024);
+        f.al[m] = tr_frag(ub + 2048 + m * 1024);
+    }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            bh[n] = *reinterpret_cast<const i32x4 *>(wt + c * WT_CHUNK + n * 1024);
-            bl[n] = *reinterpret_cast<const i32x4 *>(wt + c * WT_CHUNK + 2048 + n * 1024);
-        }
-        if (c + u.R < u.nch) {  // uniform: refill this slot; its reads must have returned
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[0]), "+v"(ah[1]), "+v"(al[0]), "+v"(al[1])::"memory");
-            dma_chunk(a, actz, lane, wave, c + u.R, u.ring + slot * U_CHUNK);
-        }
+    for (int n = 0; n < 2; ++n) {
+        f.bh[n] = *reinterpret_cast<const i32x4 *>(wtc + n * 1024);
+        f.bl[n] = *reinterpret_cast<const i32x4 *>(wtc + 2048 + n * 1024);
+    }
+}
+__device__ __forceinline__ void fold_mma(const FoldFrags &f, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p)  // U_h.Wt_h, U_h.Wt_l, U_l.Wt_h: four independent accumulators per product
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], __builtin_bit_cast(f16x8, bh[n]), acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], __builtin_bit_cast(f16x8, bl[n]), acc[m][n], 0, 0, 0);
-                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], __builtin_bit_cast(f16x8, bh[n]), acc[m][n], 0, 0, 0);
-            }
+            for (int n = 0; n < 2; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p == 2 ? f.al[m] : f.ah[m], __builtin_bit_cast(f16x8, p == 1 ? f.bl[n] : f.bh[n]),
+                                                                   acc[m][n], 0, 0, 0);
+}
+__device__ __forceinline__ void fold_mfma(const MarchArgs &a, char *actz, int lane, int wave, const UCfg &u, f32x16 (&acc)[2][2],
+                                          unsigned *tbuf = nullptr) {
+    if (u.nch == 0) return;  // uniform
+#ifdef FOLD_TIMING
+#define FOLD_SUB(i)                                                     \
+    do {                                                                \
+        if (tbuf) {                                                     \
+            const unsigned long long t__ = __builtin_readcyclecounter(); \
+            if (lane == 0) tbuf[(i)] = (unsigned)t__;                   \
+        }                                                               \
+    } while (0)
+#else
+#define FOLD_SUB(i) do { } while (0)
+#endif
+    FOLD_SUB(17);
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int tro = (g4 >> 1) * 512 + (g4 & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
+    const char *wt = actz + lane * 16;
+    const char *ring = actz + u.ring_off + tro;
+    int issued = u.R - 1;  // highest chunk whose DMA has been issued
+    FoldFrags f0, f1;
+    fold_wait(issued);
+    FOLD_SUB(18);
+    fold_read(f0, ring, wt);
+#ifdef FOLD_TIMING
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0.ah[0]), "+v"(f0.bl[1])::"memory");
+#endif
+    FOLD_SUB(19);
+    auto step = [&](FoldFrags &cur, FoldFrags &nxt, int c, int slot) {
+        if (c + u.R < u.nch) {  // uniform: refill this chunk's slot; its reads must have returned
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur.ah[0]), "+v"(cur.ah[1]), "+v"(cur.al[0]), "+v"(cur.al[1])::"memory");
+            dma_chunk(a, actz, lane, wave, c + u.R, u.ring + slot * U_CHUNK);
+            issued = c + u.R;
+        }
+        if (c + 1 < u.nch) {
+            const int ns = slot + 1 == u.R ? 0 : slot + 1;
+            fold_wait(issued - (c + 1));
+            fold_read(nxt, ring + ns * U_CHUNK, wt + (c + 1) * WT_CHUNK);
+        }
+        fold_mma(cur, acc);
+    };
+    int slot = 0;
+    for (int c = 0; c < u.nch; c += 2) {
+        step(f0, f1, c, slot);
         slot = slot + 1 == u.R ? 0 : slot + 1;
+        if (c + 1 < u.nch) {
+            step(f1, f0, c + 1, slot);
+            slot = slot + 1 == u.R ? 0 : slot + 1;
+        }
     }
 #pragma unroll
     for (int m = 0; m < 2; ++m) asm volatile("" : "+v"(acc[m][0]), "+v"(acc[m][1]));
+    FOLD_SUB(20);
+    if (tbuf && lane == 0) tbuf[21] = (unsigned)u.nch;
 }
 
 // compositing state of the weights output: 16 consecutive depth steps of a ray = 64 bytes, 4 steps per owner lane
@@ -677,60 +731,44 @@ struct WeightStore4 {
     }
 };
 
-// Heads and compositing of ONE finished depth step for this lane's sample, in slices: raw2outputs (nerf_net_utils.py:19-46)
-// exactly as RayAccum::add, state in the LDS ray record.
-struct CompState {
-    float out[4], dist, w, sig_r, sig_g, sig_b;
-    RayAccum ra;
-};
-template <int T>
-__device__ __forceinline__ void composite_slice(CompState &c, const char *actz, const float *pk, int sample, int part, float z_step,
-                                                float z_after, bool last, const MarchArgs &a, long long ray, int sidx, int S, bool valid,
-                                                WeightStore4 &wstore, bool ins) {
-    const f32x4 *rec = reinterpret_cast<const f32x4 *>(actz + RAY_OFF) + sample * (RAY_FLOATS / 4);
-    if constexpr (T == 0) {
-        const f32x4 pa = *reinterpret_cast<const f32x4 *>(actz + SCR_A + sample * 16);
-        c.out[3] = ((pa.x + pa.y) + (pa.z + pa.w)) + pk[P_AB];
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const f32x4 pc = *reinterpret_cast<const f32x4 *>(actz + SCR_C + (ch * 64 + sample) * 16);
-            c.out[ch] = ((pc.x + pc.y) + (pc.z + pc.w)) + pk[P_RB + ch];
-        }
-        if (!ins) c.out[0] = c.out[1] = c.out[2] = c.out[3] = 0.f;  // culled sample: raw = 0 (if_clight_renderer_mmsk.py:54-59)
-    } else if constexpr (T == 1) {
-        const float d = last ? 1e10f : __fsub_rn(z_after, z_step);
-        c.dist = __fmul_rn(d, rec[2].w);
-        const f32x4 c0 = rec[3], c1 = rec[4];
-        c.ra.T = c0.x; c.ra.cr = c0.y; c.ra.cg = c0.z; c.ra.cb = c0.w; c.ra.depth = c1.x; c.ra.accw = c1.y;
-    } else if constexpr (T == 2) {
-        const float sig = fmaxf(c.out[3], 0.f);
-        const float alpha = 1.f - expf(-sig * c.dist);
-        c.w = alpha * c.ra.T;
-        c.ra.T = c.ra.T * (__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
-    } else if constexpr (T == 3) {
-        c.sig_r = 1.f / (1.f + expf(-c.out[0]));
-    } else if constexpr (T == 4) {
-        c.sig_g = 1.f / (1.f + expf(-c.out[1]));
-    } else if constexpr (T == 5) {
-        c.sig_b = 1.f / (1.f + expf(-c.out[2]));
-    } else if constexpr (T == 6) {
-        c.ra.cr = fmaf(c.w, c.sig_r, c.ra.cr);
-        c.ra.cg = fmaf(c.w, c.sig_g, c.ra.cg);
-        c.ra.cb = fmaf(c.w, c.sig_b, c.ra.cb);
-        c.ra.depth = fmaf(c.w, z_step, c.ra.depth);
-        c.ra.accw += c.w;
-        if (part == 0) {
-            f32x4 *recw = reinterpret_cast<f32x4 *>(const_cast<char *>(actz) + RAY_OFF) + sample * (RAY_FLOATS / 4);
-            recw[3] = f32x4{c.ra.T, c.ra.cr, c.ra.cg, c.ra.cb};
-            recw[4] = f32x4{c.ra.depth, c.ra.accw, 0.f, 0.f};
-        }
-    } else if constexpr (T == 7) {
-        wstore.push(a, ray, sidx, S, part, valid, c.w);
-#ifndef FOLD_TAP
-        if (valid && part == 0 && a.raw)
-            *reinterpret_cast<f32x4 *>(a.raw + (ray * S + sidx) * 4) = f32x4{c.out[0], c.out[1], c.out[2], c.out[3]};
-#endif
+// Heads and compositing of ONE finished depth step for this lane's sample: raw2outputs (nerf_net_utils.py:19-46) exactly as
+// RayAccum::add, state in the LDS ray record, the work split over the sample's four owner lanes — every lane forms sigma,
+// alpha and the weight; part 0 carries transmittance, depth and opacity, parts 1..3 one colour channel each (its logit, its
+// sigmoid, its accumulator); `ins` false (culled sample): raw = 0 (if_clight_renderer_mmsk.py:54-59).
+__device__ __forceinline__ float head_sum(const char *actz, int off, float bias) {
+    const f32x4 p = *reinterpret_cast<const f32x4 *>(actz + off);
+    return ((p.x + p.y) + (p.z + p.w)) + bias;
+}
+__device__ __forceinline__ void composite_step(char *actz, const float *pk, int sample, int part, float z_step, float z_after, bool last,
+                                               const MarchArgs &a, long long ray, int sidx, int S, bool valid, WeightStore4 &wstore, bool ins) {
+    float *recf = reinterpret_cast<float *>(actz + RAY_OFF) + sample * RAY_FLOATS;
+    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(recf + 12);  // T r g b
+    const float sigma_raw = ins ? head_sum(actz, SCR_A + sample * 16, pk[P_AB]) : 0.f;
+    const float d = last ? 1e10f : __fsub_rn(z_after, z_step);
+    const float dist = __fmul_rn(d, recf[11]);
+    const float sig = fmaxf(sigma_raw, 0.f);
+    const float alpha = 1.f - expf(-sig * dist);
+    const float w = alpha * c0.x;
+    if (part == 0) {
+        const float depth = recf[16], accw = recf[17];
+        recf[12] = c0.x * (__fadd_rn(__fsub_rn(1.f, alpha), 1e-10f));
+        recf[16] = fmaf(w, z_step, depth);
+        recf[17] = accw + w;
+    } else {
+        const int ch = part - 1;
+        const float o = ins ? head_sum(actz, SCR_C + (ch * 64 + sample) * 16, pk[P_RB + ch]) : 0.f;
+        const float col = part == 1 ? c0.y : (part == 2 ? c0.z : c0.w);
+        recf[12 + part] = fmaf(w, 1.f / (1.f + expf(-o)), col);
     }
+    wstore.push(a, ray, sidx, S, part, valid, w);
+#if !defined(FOLD_TAP) && !defined(FOLD_TIMING)
+    if (a.raw && valid && part == 0) {  // uniform in a.raw
+        float o3[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o3[ch] = ins ? head_sum(actz, SCR_C + (ch * 64 + sample) * 16, pk[P_RB + ch]) : 0.f;
+        *reinterpret_cast<f32x4 *>(a.raw + (ray * S + sidx) * 4) = f32x4{o3[0], o3[1], o3[2], sigma_raw};
+    }
+#endif
 }
 
 // view_fc column of encoding slot `slot` (0..31) of axis a: [x, (sin, cos)(x 2^k) k<10, v, (sin, cos)(v 2^k) k<4, 0, 0]; -1 = zero pad
@@ -761,6 +799,19 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 #else
 #define FOLD_DUMP(LAYER, MT_)
 #endif
+// FOLD_TIMING (experiment builds, tools/experiments/fold_phase_times.py): wave 0 of the first 32 workgroups stamps the cycle
+// counter at the phase boundaries of every depth step into the `raw` output as [workgroup][step][32]
+#ifdef FOLD_TIMING
+#define FOLD_STAMP(i)                                                   \
+    do {                                                                \
+        if (tbuf) {                                                     \
+            const unsigned long long t__ = __builtin_readcyclecounter(); \
+            if (lane == 0) tbuf[(i)] = (unsigned)t__;                   \
+        }                                                               \
+    } while (0)
+#else
+#define FOLD_STAMP(i) do { } while (0)
+#endif
 // MODE 0: rays (nb_march).  MODE 1 / 2: explicit points (nb_decode_points, raw [n,4] / density [n,1]): a point with its view
 // direction is a one-sample "ray" (origin = the point, direction = the view direction taken as given, z = 0) whose decoder
 // output is stored instead of composited; MODE 2 stops behind alpha_fc.
@@ -779,9 +830,14 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
     const int grp = xcd_remap(blockIdx.x, a.n_wave_groups);
     long long ray = (long long)grp * 64 + 16 * wave + (lane & 15);
     const long long n_units = POINTS ? a.n_pts : a.n_rays;
-    const bool valid = ray < n_units;
+    bool valid = ray < n_units;
     if (!valid) ray = n_units - 1;
-    if (!POINTS && a.ray_order) ray = a.ray_order[ray];
+    if (!POINTS && a.ray_order) {
+        if (a.ray_order[(long long)grp * 64] == NB_SLOT_DEAD) return;  // an empty group of slots (workgroup-uniform, before any barrier)
+        const int v = a.ray_order[(long long)grp * 64 + 16 * wave + (lane & 15)];
+        valid = v >= 0;
+        ray = valid ? v : -(long long)v - 1;  // a padding slot marches that ray's data and stores nothing
+    }
     const int S = POINTS ? 1 : a.n_samples;
     {
         float ox, oy, oz, dx, dy, dz, near, far, dn, vx, vy, vz;
@@ -906,14 +962,23 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
         const bool ins_cur = ins;
         float z_next = 0.f;
         int tier_next = 0, active_next = 1;
+#ifdef FOLD_TIMING
+        unsigned *tbuf = (blockIdx.x < 32 && wave == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + ((size_t)blockIdx.x * S + s) * 32 : nullptr;
+#endif
+        FOLD_STAMP(0);
         __syncthreads();  // Wt is visible
+        FOLD_STAMP(1);
         if (!CULL || active) {
             f32x16 acc[2][2];
             // ---- fc_0 folded into the volume: H1_pre = b0 + U^T . Wt over the step's voxel list
             init_bias<2>(pk + P_B0, 2 * wave, hi, acc);
             if (tier == 0) {
                 const UCfg u = ucfg(actz, lds_base, wave);
+#ifdef FOLD_TIMING
+                fold_mfma(a, actz, lane_i, wave, u, acc, tbuf);
+#else
                 fold_mfma(a, actz, lane_i, wave, u, acc);
+#endif
             } else {
                 // rays far apart: sample groups of 16 (one wave's) or single samples, each through boxes -> table -> U -> Wt -> MFMA
                 const Lvl lv = load_lvl(actz, part);
@@ -936,17 +1001,18 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
                 }
             }
             FOLD_DUMP(0, 2)
+            FOLD_STAMP(2);
             ring_prime<P_L1>(wl, ring);
             publish_s(actz, lane_i, wave, acc);
+            FOLD_STAMP(3);
             // ---- fc_1, fc_2
             init_bias<2>(pk + P_B1, 2 * wave, hi, acc);
             // The positional encodings of this step (lane (sample, axis a = part < 3): x_a, (sin, cos)(x_a 2^k) k < 10, v_a, (sin,
-            // cos)(v_a 2^k) k < 4, two zeros; part 3: zeros) and their conversion into operands ride behind fc_1's MFMAs, one slice
+            // cos)(v_a 2^k) k < 4, two zeros; part 3: unused) and their conversion into operands ride behind fc_1's MFMAs, one slice
             // per MFMA step; the finished half-block waits in registers until the view layer has released the activation buffers.
             Conv6 pec;
             {
                 const f32x4 ro = rec[0], rd = rec[1], rv = rec[2];  // ox oy oz near | dx dy dz far | vx vy vz |d|
-                const float keep = part < 3 ? 1.f : 0.f;
                 const float xa = part == 0 ? __fadd_rn(ro.x, __fmul_rn(rd.x, z_cur))
                                            : (part == 1 ? __fadd_rn(ro.y, __fmul_rn(rd.y, z_cur)) : __fadd_rn(ro.z, __fmul_rn(rd.z, z_cur)));
                 const float va = part == 0 ? rv.x : (part == 1 ? rv.y : rv.z);
@@ -967,8 +1033,9 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
                         sincos_rev2<t - 11>(tv, e[2 * t], e[2 * t + 1]);
                     } else if constexpr (t >= 16) {
                         constexpr int i = t - 16;
-                        conv6_pair<2 * i>(pec, e[4 * i] * keep, e[4 * i + 1] * keep);
-                        conv6_pair<2 * i + 1>(pec, e[4 * i + 2] * keep, e[4 * i + 3] * keep);
+                        // (part 3 converts the z axis once more: its slots meet zero weights, pe_slot_col)
+                        conv6_pair<2 * i>(pec, e[4 * i], e[4 * i + 1]);
+                        conv6_pair<2 * i + 1>(pec, e[4 * i + 2], e[4 * i + 3]);
                     }
                 };
                 if constexpr (DENSITY_ONLY) layer_s<P_L1, 2, 4, true>(wl, actz, lane_i, ring, acc);
@@ -977,10 +1044,13 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
             HalfBlock peh;
             if constexpr (!DENSITY_ONLY) peh = conv6_finish(pec);
             FOLD_DUMP(1, 2)
+            FOLD_STAMP(4);
             publish_s(actz, lane_i, wave, acc);
+            FOLD_STAMP(5);
             init_bias<2>(pk + P_B2, 2 * wave, hi, acc);
             layer_s<P_L2, 2, 4, true>(wl, actz, lane_i, ring, acc);
             FOLD_DUMP(2, 2)
+            FOLD_STAMP(6);
             // ---- the next step's sample: depth, grid coordinates, silhouette test, (wave, level) boxes — published by the
             // barriers of the publish below
             if (more) {
@@ -993,6 +1063,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
                 const Lvl lv = load_lvl(actz, part);
                 prep_boxes(actz, lv, g, ins, wave, true, os, part);
             }
+            FOLD_STAMP(7);
             if constexpr (DENSITY_ONLY) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
@@ -1003,6 +1074,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
             } else {
                 publish_s(actz, lane_i, wave, acc);  // acc now holds relu(h3)
             }
+            FOLD_STAMP(8);
             // ---- alpha_fc: partial dot product over this wave's 64 features, finished by the owner lanes
             {
 #pragma unroll
@@ -1039,10 +1111,12 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
                     if (tier_next == 0) tl = tbl_issue(pr, lv, wave, os);
                     lvl_store(actz, pr, tid, os, part);
                 }
+                FOLD_STAMP(9);
                 // ---- the colour head's linear part as ONE layer (feature_fc . latent_fc . view_fc folded at pack time, bias:
                 // second block of nb_mlp_latent_bias): one tile per wave, K phase over fc_2's outputs, then over the encodings
                 init_bias<1>(pk + P_LB, wave, hi, acc);
                 layer_s<P_VG, 1, 4, false>(wl, actz, lane_i, ring, acc);
+                FOLD_STAMP(10);
                 if (more && tier_next == 0) {
                     const Lvl lv = load_lvl(actz, part);
                     tbl_store(actz, tl, lv, a.fold.zero_off, k_next, tid);
@@ -1051,7 +1125,9 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
                 ring_prime<P_VP>(wl, ring);
                 store_halfblock(actz, part >> 1, part & 1, sn, ss, peh);  // the encodings converted behind fc_1
                 __syncthreads();
+                FOLD_STAMP(11);
                 layer_s<P_VP, 1, 2, false>(wl, actz, lane_i, ring, acc);
+                FOLD_STAMP(12);
                 FOLD_DUMP(3, 1)
                 // ---- rgb_fc partial sums over this wave's 32 view features
                 {
@@ -1083,26 +1159,35 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
             tier_next = tier;
             active_next = active;
         }
+        FOLD_STAMP(13);
         __syncthreads();  // the activation buffers are free; the heads' partial sums, the next step's table and boxes are visible
+        FOLD_STAMP(14);
         // ---- the next step's U rows and trilinear weights: in flight / built under this step's heads and compositing
         if (more) {
             tier = tier_next;
             active = active_next;
             fetch_and_weights(lane_i);
         }
+        FOLD_STAMP(15);
         // ---- owner lanes: finish the heads; composite (rays) or hand the decoder output over (points)
         {
-            CompState cs;
             if constexpr (POINTS) {
-                composite_slice<0>(cs, actz, pk, sample, part, z_cur, z_next, true, a, ray, s, S, valid, wstore, true);
                 if (valid && part == 0) {
-                    if constexpr (DENSITY_ONLY) a.raw_out[ray] = cs.out[3];
-                    else *reinterpret_cast<f32x4 *>(a.raw_out + ray * 4) = f32x4{cs.out[0], cs.out[1], cs.out[2], cs.out[3]};
+                    const float sigma = head_sum(actz, SCR_A + sample * 16, pk[P_AB]);
+                    if constexpr (DENSITY_ONLY) {
+                        a.raw_out[ray] = sigma;
+                    } else {
+                        float o3[3];
+#pragma unroll
+                        for (int ch = 0; ch < 3; ++ch) o3[ch] = head_sum(actz, SCR_C + (ch * 64 + sample) * 16, pk[P_RB + ch]);
+                        *reinterpret_cast<f32x4 *>(a.raw_out + ray * 4) = f32x4{o3[0], o3[1], o3[2], sigma};
+                    }
                 }
             } else {
-                sfor<0, 8>([&](auto tc) { composite_slice<decltype(tc)::value>(cs, actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore, !CULL || ins_cur); });
+                composite_step(actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore, !CULL || ins_cur);
             }
         }
+        FOLD_STAMP(16);
         z_cur = z_next;
     }
     if (!POINTS && valid && (lane >> 4) == 0) {
@@ -1139,7 +1224,7 @@ __device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const floa
 }
 
 // one thread per (wave, piece, lane): the lane's 16 bytes
-__global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, unsigned *__restrict__ out) {
+__global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, unsigned *__restrict__ out, int *__restrict__ stats) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 4 * P_TOTAL * 64) return;
     const int lane = t & 63, piece = (t >> 6) % P_TOTAL, w = (t >> 6) / P_TOTAL;
@@ -1190,6 +1275,18 @@ __global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f
         }
         w8[6] = (unsigned)(127 + ex);
         for (int q = 0; q < 4; ++q) w32[q] = w8[4 * half + q];
+        // statistic behind nb_mlp_six_bit_stats_offset(): how many non-zero head weights sit below 1/8 of their block's
+        // maximum, i.e. in e2m3's subnormal range where they keep fewer than 3 bits (per layer: small, non-zero)
+        if (k == 0 && half == 0) {
+            int small = 0, nz = 0;
+            for (int e = 0; e < 32; ++e) {
+                nz += wv[e] != 0.f;
+                small += wv[e] != 0.f && fabsf(wv[e]) < 0.125f * amax;
+            }
+            const int layer = ph < 2 ? ph : 2;  // fc_1, fc_2, the folded colour head (both of its K phases)
+            atomicAdd(&stats[2 * layer], small);
+            atomicAdd(&stats[2 * layer + 1], nz);
+        }
     }
     unsigned *dst = out + ((size_t)(w * P_TOTAL + piece) * 64 + lane) * 4;
     for (int q = 0; q < 4; ++q) dst[q] = w32[q];
@@ -1199,18 +1296,20 @@ __global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f
 
 namespace nbm {
 
-long long fold_stream_floats() { return (long long)4 * P_TOTAL * 1024 / 4; }
+long long fold_stream_floats() { return (long long)4 * P_TOTAL * 1024 / 4 + 8; }  // + the six-bit statistic (6 ints, 2 pad)
 
 int pack_fold_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st) {
     const long long n = (long long)4 * P_TOTAL * 64;
+    int *stats = reinterpret_cast<int *>(packed + stream_off + (long long)4 * P_TOTAL * 1024 / 4);
+    NB_REQUIRE(hipMemsetAsync(stats, 0, 8 * sizeof(int), st) == hipSuccess, "pack_fold_stream: hipMemsetAsync failed");
     hipLaunchKernelGGL(nb_pack_fold_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, st, *p, packed,
-                       reinterpret_cast<unsigned *>(packed + stream_off));
+                       reinterpret_cast<unsigned *>(packed + stream_off), stats);
     NB_CHECK_LAUNCH("nb_pack_fold_kernel");
     return NB_OK;
 }
 
 int launch_march_fold(MarchArgs a, long long stream_off, hipStream_t st) {
-    a.n_wave_groups = (int)nb_ceil_div(a.n_rays, 64);
+    a.n_wave_groups = (int)nb_ceil_div(a.ray_order ? a.n_slots : a.n_rays, 64);
     const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
     if (a.cull.n_views) hipLaunchKernelGGL((nb_march_fold_kernel<0, true>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     else hipLaunchKernelGGL((nb_march_fold_kernel<0, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);

@@ -33,17 +33,13 @@ DENSE_AFTER = ("conv1", "conv2", "conv3", "conv4")  # latent_xyzc.py:188-201
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
 DEFAULT_PRECISION = "auto"
 ENC_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # encoder convolutions with >= 32 input channels on the 16-bit matrix pipe
-SIX_BIT_MAX_SMALL = 0.5
-# precision 'auto': the first march of at least this many rays times both organisations of the f16f6 arithmetic (ring and
-# M-split kernel) on its own inputs and keeps the faster one for the life of the Network; NB_AUTO_TUNE=0 = always M-split
-AUTO_TUNE_MIN_RAYS = 1 << 17
-AUTO_TUNE = os.environ.get("NB_AUTO_TUNE", "1") != "0"
+SIX_BIT_MAX_SMALL = 0.5  # precision 'auto': largest per-layer share of weights six-bit blocks cannot hold before it takes 'f32'
 
 
 class FeatureVolumes(list):
     """The four volumes of `Network.encode_sparse_voxels` ([1,C,D,H,W] views of channels-last storage, as the reference
     returns them) together with the index structures they were scattered from: `sparse[l]` = (index grid [D,H,W] int32, linear
-    voxel index of every active row, device-side row count [1], row capacity).  Precision 'f16f6v' builds its fc_0-folded
+    voxel index of every active row, device-side row count [1], row capacity).  Precision 'f16f6' builds its fc_0-folded
     planes from them (`fold`: (fc_0 weight key, ops.fold_build result), rebuilt when the weight changes); a plain list of
     volumes from elsewhere gets its active set from ops.sparsify."""
 
@@ -171,15 +167,13 @@ _MLP_NAMES = {"fc0": "fc_0", "fc1": "fc_1", "fc2": "fc_2", "alpha": "alpha_fc", 
 class Network(nn.Module):
     def __init__(self, num_train_frame, voxel_size=(0.005, 0.005, 0.005), xyz_res=10, view_res=4, precision=None):
         super().__init__()
-        # decoder GEMM arithmetic: "bf16x3" (split-bf16 MFMA, 3 products, fp32 accumulate) or "f32" (exact
-        # fp32 MFMA); both stay inside the 1e-4 RGB parity budget, see DESIGN.md
+        # decoder arithmetic: 'f16f6' (fc_0 folded into the volume + fp16 / six-bit cross-term MFMAs), 'f32' (exact fp32
+        # MFMA, the reference's precision) or 'auto' = 'f16f6' unless the weights have blocks six bits cannot hold
         self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
-        if self.precision not in ("auto", "f32", "bf16x3", "f16f6r", "f16f8", "f16f6", "f16f6v"):
-            raise ValueError("precision must be 'auto', 'f32', 'bf16x3', 'f16f6r', 'f16f8', 'f16f6' or 'f16f6v'")
-        self._auto = None  # (weight key, chosen arithmetic) of precision 'auto'
+        if self.precision not in ("auto", "f32", "f16f6"):
+            raise ValueError("precision must be 'auto', 'f32' or 'f16f6'")
+        self._auto = None  # (weight key, chosen arithmetic, statistic) of precision 'auto'
         self._lb_cache = None  # (latent_index tensor, versions, bias) of latent_bias()
-        self._auto_org = None  # 'f16f6' / 'f16f6r': the measured choice of precision 'auto' (None: not measured yet)
-        self._auto_times = None  # {organisation: ms} of that measurement
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -203,7 +197,7 @@ class Network(nn.Module):
     # the packed blobs and their keys (storages!) are caches of the parameters: they are neither copied nor pickled
     def __getstate__(self):
         st = dict(self.__dict__)
-        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None, _auto_org=None)
+        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None)
         return st
 
     def __deepcopy__(self, memo):
@@ -229,41 +223,34 @@ class Network(nn.Module):
 
     def _point_precision(self):
         """Arithmetic of nb_decode_points (stand-alone points: calculate_density, calculate_density_color, get_pixel_value,
-        RendererMesh): exact fp32, split bf16, or — the default — the march's f16f6 arithmetic on the same M-split kernel
-        (every point a one-sample ray).  'f16f8' and 'f16f6r' exist as march organisations only: their points take split bf16,
-        and so do the points of an 'auto' network whose weights made the march fall back to 'f16f8'."""
-        if self.precision in ("f32", "bf16x3", "f16f6", "f16f6v"):
-            return self.precision
-        if self.precision == "auto":
-            return "f16f6" if self.march_precision() == "f16f6" else "bf16x3"
-        return "bf16x3"
+        RendererMesh): the march's (every point is a one-sample ray of the same kernel)."""
+        return self.march_precision()
 
     def march_precision(self):
-        """Arithmetic of the fused march.  'auto' = the f16f6 arithmetic (cross terms in six bits) on whichever of its two
-        organisations is faster HERE — 'f16f6' (M-split kernel) until the first march of >= AUTO_TUNE_MIN_RAYS rays has timed
-        both (render_rays; the ring kernel 'f16f6r' is 2-3 % faster on the fast boxes of the pool, the M-split kernel 10 % on
-        the slow-memory ones: profiles/r03_march_kernels.md) — unless the weights have
-        blocks fp6 cannot hold: more than SIX_BIT_MAX_SMALL of a layer's non-zero weights below 1/8 of their block maximum
-        (normally distributed weights: ~0.2; the wide-dynamic-range stress case of tools/experiments/precision_sweep.py:
-        ~0.75, where six-bit weights triple the error) — then 'f16f8'.  Decided once per weight version (one 5-float
-        read-back after packing)."""
+        """Arithmetic of the fused march.  'auto' = 'f16f6' unless the weights have blocks fp6 cannot hold: more than
+        SIX_BIT_MAX_SMALL of a layer's non-zero weights below 1/8 of their (row, 32 K) block maximum (normally distributed
+        weights: ~0.2; the wide-dynamic-range stress case of tools/experiments/precision_sweep.py: ~0.75, where six-bit cross
+        terms triple the error) — then the exact 'f32' kernel, with a warning (it is ~6x slower).  A function of the weights
+        alone — decided once per weight version (one 3-float read-back after packing), the same on every rank, no timing."""
         if self.precision != "auto":
             return self.precision
         packed = self.packed_weights("f16f6")
         if self._auto is None or self._auto[0] is not self._packed_key:
             worst = float(ops.six_bit_small_fraction(packed).max())
-            self._auto = (self._packed_key, "f16f6" if worst <= SIX_BIT_MAX_SMALL else "f16f8", worst)
-        if self._auto[1] == "f16f6" and self._auto_org is not None:
-            return self._auto_org
+            choice = "f16f6" if worst <= SIX_BIT_MAX_SMALL else "f32"
+            if choice == "f32":
+                import warnings
+
+                warnings.warn("neuralbody_amd: %.0f %% of a decoder layer's weights lie below 1/8 of their 32-wide block maximum; "
+                              "precision 'auto' takes the exact fp32 kernel for these weights" % (100 * worst))
+            self._auto = (self._packed_key, choice, worst)
         return self._auto[1]
 
     def packed_weights(self, precision=None):
         """MFMA-ordered decoder blob, rebuilt (on device) whenever a parameter changed; only the sections of the
         arithmetics asked for since the last change are (re)written — a training step repacks every iteration and only
         ever decodes with 'f32'."""
-        need = {self.march_precision(), self._point_precision()} if precision is None else {precision}
-        if "f16f6" in need:
-            need.discard("f16f6r")  # the 'f16f6' section holds both weight streams (ring and M-split)
+        need = {self.march_precision()} if precision is None else {precision}
         d = self._mlp_param_dict()
         # keyed on the parameters' storages, which the entry keeps alive (so an address cannot be recycled under the
         # key), and on their version counters (optimizer steps and load_state_dict write in place)
@@ -274,10 +261,10 @@ class Network(nn.Module):
         if self._packed is None or not same:
             self._packed = ops.mlp_pack(d, self._packed, precisions=need)
             self._packed_key = key
-            self._packed_have = set(need) | {"f32"} | ({"f16f6r"} if "f16f6" in need else set())
+            self._packed_have = set(need) | {"f32"}
         elif not need <= self._packed_have:
             ops.mlp_pack(d, self._packed, precisions=need - self._packed_have)
-            self._packed_have |= need | ({"f16f6r"} if "f16f6" in need else set())
+            self._packed_have |= need
         return self._packed
 
     def latent_bias(self, latent_index):
@@ -308,7 +295,7 @@ class Network(nn.Module):
         """nb_scene of one frame.  R / Th / bounds stay on the device (ops.make_pose packs them into the 15-float
         block the kernels read): no host copy, no sync and — unlike round 1's address-keyed host cache — nothing
         that could hand frame k+1 the pose of frame k when the allocator recycles the batch's addresses.
-        precision 'f16f6v' marches the fc_0-folded planes of the volumes (ops.fold_build): built once per (volumes, fc_0
+        precision 'f16f6' marches the fc_0-folded planes of the volumes (ops.fold_build): built once per (volumes, fc_0
         weight version) and kept on the FeatureVolumes object."""
         vols = []
         for v in feature_volume:
@@ -317,7 +304,7 @@ class Network(nn.Module):
         if R.numel() != 9 or bounds.numel() != 6:
             raise NotImplementedError("batch size 1 only (train.batch_size / test batch are 1 in every shipped config)")
         out_sh = [int(s) for s in sp_input["out_sh"]]
-        fold = self._fold_planes(feature_volume, vols) if precision == "f16f6v" else None
+        fold = self._fold_planes(feature_volume, vols) if precision == "f16f6" else None
         return ops.make_scene(vols, ops.make_pose(R, Th, bounds, device=vols[0].device), self.voxel_size, out_sh, fold=fold)
 
     def _fold_planes(self, feature_volume, vols):
@@ -384,41 +371,6 @@ class Network(nn.Module):
         if t_vals is None:
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._t_vals[key] = t_vals
-        if (self.precision == "auto" and prec == "f16f6" and self._auto_org is None and AUTO_TUNE and cull is None
-                and ray_o.shape[0] >= AUTO_TUNE_MIN_RAYS):
-            prec = self._auto_org = self._time_organisations(scene, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd,
-                                                             ray_order)
         return ops.march(scene, self.packed_weights(prec), lb, ray_o, ray_d, near, far, t_vals, t_rand,
                          white_bkgd=white_bkgd, want_raw=want_raw, precision=prec, ray_order=ray_order,
                          cull=cull)
-
-    def _time_organisations(self, scene, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd, ray_order):
-        """One warm and two timed launches of each organisation of the f16f6 arithmetic on the caller's own rays, the timed ones
-        alternating (HIP events on the current stream, one host wait: ~0.1 s, once per Network).  Both compute the same arithmetic with a different
-        summation order (parity tests run both); which one is faster is a property of the box."""
-        packed = self.packed_weights("f16f6")  # holds both weight streams
-        saved, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None  # bench.py's per-launch events: not these
-        orgs = ("f16f6", "f16f6r")
-        times = {org: 0.0 for org in orgs}
-        try:
-            def launch(org):
-                ops.march(scene, packed, lb, ray_o, ray_d, near, far, t_vals, t_rand, white_bkgd=white_bkgd, precision=org,
-                          ray_order=ray_order)
-
-            for org in orgs:  # warm: code objects, clocks
-                launch(org)
-            spans = []
-            for _ in range(2):  # alternating, so that neither organisation is timed on the cooler chip
-                for org in orgs:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    launch(org)
-                    e1.record()
-                    spans.append((org, e0, e1))
-            spans[-1][2].synchronize()
-            for org, e0, e1 in spans:
-                times[org] += e0.elapsed_time(e1) / 2
-        finally:
-            ops.MARCH_EVENTS = saved
-        self._auto_times = times
-        return min(times, key=times.get)

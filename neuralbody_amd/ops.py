@@ -81,7 +81,7 @@ def sparsify(volume_cl):
 
 
 def fold_build(volumes_cl, sparse, fc0_w):
-    """nb_fold_build: the fc_0-folded planes of one frame (precision 'f16f6v').  volumes_cl: the four channels-last
+    """nb_fold_build: the fc_0-folded planes of one frame (precision 'f16f6').  volumes_cl: the four channels-last
     volumes; sparse: per level (grid, rows_lin, n_rows[1], n_rows_max) — the encoder's index structures, or `sparsify`'s;
     fc0_w [256,352(,1)].  Returns (NbFold, keepalive)."""
     if fc0_w.dim() == 3:
@@ -116,7 +116,7 @@ def fold_build(volumes_cl, sparse, fc0_w):
 
 def make_scene(volumes_cl, pose, voxel_size, out_sh, fold=None):
     """volumes_cl: four contiguous [D,H,W,C] fp32 device tensors; pose: the 15-float DEVICE block of make_pose;
-    voxel_size (3, dhw) and out_sh (3) are HOST sequences; fold: `fold_build`'s result (precision 'f16f6v').
+    voxel_size (3, dhw) and out_sh (3) are HOST sequences; fold: `fold_build`'s result (precision 'f16f6').
     Returns (NbScene, keepalive)."""
     sc = NbScene()
     if len(volumes_cl) != 4:
@@ -173,17 +173,17 @@ def mlp_pack(params, out=None, precisions=None):
     if out is None:
         out = torch.zeros(mlp_pack_size(), dtype=torch.float32, device=dev)  # sections not asked for stay zero, never stale
     _req(out, torch.float32, (mlp_pack_size(),), "packed")
-    bits = 31 if precisions is None else (1 | sum(_lib.PACK_SECTIONS[q] for q in set(precisions)))
+    bits = 3 if precisions is None else (1 | sum(_lib.PACK_SECTIONS[q] for q in set(precisions)))
     check(_lib.lib().nb_mlp_pack_sections(C.byref(p), ptr(out), int(bits), _stream()), "nb_mlp_pack_sections")
     return out
 
 
 def six_bit_small_fraction(packed):
-    """Per layer of the 'f16f6' kernel (fc_0, fc_1, fc_2, the folded feature_fc / latent_fc / view_fc layer): the share of
-    non-zero weights below 1/8 of their (row, 32 K) block's maximum, counted while that section was packed
-    (nb_mlp_six_bit_stats_offset).  Device tensor [4]."""
+    """Per layer the 'f16f6' kernel runs with six-bit cross terms (fc_1, fc_2, the folded feature_fc / latent_fc / view_fc
+    layer): the share of non-zero weights below 1/8 of their (row, 32 K) block's maximum, counted while that section was
+    packed (nb_mlp_six_bit_stats_offset).  Device tensor [3]."""
     off = int(_lib.lib().nb_mlp_six_bit_stats_offset())
-    c = packed[off:off + 8].view(torch.int32).reshape(4, 2).to(torch.float32)
+    c = packed[off:off + 6].view(torch.int32).reshape(3, 2).to(torch.float32)
     return c[:, 0] / c[:, 1].clamp_min(1.0)
 
 
@@ -231,8 +231,12 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
     S = t_vals.shape[0]
     if t_rand is not None:
         _req(t_rand, torch.float32, (n, S), "t_rand")
+    n_slots = 0
     if ray_order is not None:
-        _req(ray_order, torch.int32, (n,), "ray_order")
+        _req(ray_order, torch.int32, (None,), "ray_order")
+        n_slots = int(ray_order.shape[0])
+        if n_slots == 0 or n_slots % 64:
+            raise ValueError("ray_order holds %d slots: a positive multiple of 64 (ops.tile_slots)" % n_slots)
     dev = ray_o.device
     rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     disp = torch.empty((n,), dtype=torch.float32, device=dev)
@@ -245,7 +249,7 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
     check(_lib.lib().nb_march(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(ray_o), ptr(ray_d), ptr(near), ptr(far),
-                              n, S, ptr(t_vals), ptr(t_rand), ptr(ray_order),
+                              n, S, ptr(t_vals), ptr(t_rand), ptr(ray_order), n_slots,
                               C.byref(cull[0]) if cull is not None else None, 1 if white_bkgd else 0, ptr(rgb), ptr(disp),
                               ptr(acc),
                               ptr(weights), ptr(depth), ptr(raw), _lib.PRECISIONS[precision], _stream()), "nb_march")
@@ -491,18 +495,42 @@ def image_assemble(mask_at_box, rgb_map, depth_map=None, white_bkgd=False, bgr=F
     return img, depth
 
 
-def tile_order(pix, width, tile=8, block=4):
-    """Permutation (int32) that groups rays into tile x tile pixel tiles made of block x block pixel blocks: `pix` are the
-    linear pixel ids (row-major, image `width`) of the rays.  64 consecutive slots = one compact 8 x 8 tile (what a workgroup
-    of the fused march takes: the voxels its 64 samples touch at a depth step are then a few small boxes), every 16
-    consecutive slots = one 4 x 4 block (one wave's samples), every 32 = an 8 x 4 half tile."""
-    py, px = torch.div(pix, width, rounding_mode="floor"), pix % width
-    n_tx = (width + tile - 1) // tile
-    per = tile // block
-    blk = torch.div(py % tile, block, rounding_mode="floor") * per + torch.div(px % tile, block, rounding_mode="floor")
-    inner = blk * (block * block) + (py % block) * block + (px % block)
-    key = (torch.div(py, tile, rounding_mode="floor") * n_tx + torch.div(px, tile, rounding_mode="floor")) * (tile * tile) + inner
-    return torch.argsort(key).to(torch.int32)
+TILE = 8  # rays are marched in 8 x 8 pixel tiles (64 slots = one workgroup of the fused march), made of four 4 x 4 blocks
+
+
+def tile_pixels(H, W, device):
+    """Static part of the slot list of an H x W image: slot -> pixel id (row-major), -1 where the tile sticks out of the image.
+    Slot s = 64 * tile + 16 * block + 4 * (y % 4) + (x % 4), tiles row-major, blocks row-major inside a tile: 64 consecutive
+    slots = one compact 8 x 8 tile (the voxels its samples touch at a depth step are a few small boxes), every 16 = one 4 x 4
+    block (one wave's samples), every 32 = an 8 x 4 half tile."""
+    ht, wt = (H + TILE - 1) // TILE, (W + TILE - 1) // TILE
+    s = torch.arange(ht * wt * 64, device=device)
+    tile, inner = torch.div(s, 64, rounding_mode="floor"), s % 64
+    blk, r = torch.div(inner, 16, rounding_mode="floor"), inner % 16
+    py = torch.div(tile, wt, rounding_mode="floor") * TILE + torch.div(blk, 2, rounding_mode="floor") * 4 + torch.div(r, 4, rounding_mode="floor")
+    px = (tile % wt) * TILE + (blk % 2) * 4 + r % 4
+    pix = py * W + px
+    return torch.where((py < H) & (px < W), pix, torch.full_like(pix, -1))
+
+
+def tile_slots(mask, slot_pixels, begin=0, end=None):
+    """The `ray_order` of nb_march (include/nb_hip.h) for the rays of an image: `mask` [H*W] bool/uint8 = which pixels have a
+    ray (the rays are the mask's non-zeros in pixel order, batch['mask_at_box']), `slot_pixels` = tile_pixels(H, W), [begin, end)
+    = the range of rays to march (a rank's share).  Every tile keeps its own 64 slots: missing pixels become padding slots
+    (they march the tile's first ray and store nothing), tiles without a ray are dead.  No host synchronisation: cumulative
+    sum + gathers on the device.  int32 [tiles * 64]; entries index the rays of the range (ray - begin)."""
+    m = mask.reshape(-1) != 0
+    idx = torch.cumsum(m.to(torch.int32), 0, dtype=torch.int32) - 1  # ray index of every pixel that has one
+    ok = m & (idx >= begin)
+    if end is not None:
+        ok = ok & (idx < end)
+    p = slot_pixels.clamp_min(0)
+    ok_s = ok[p] & (slot_pixels >= 0)
+    ray = idx[p] - begin
+    big = 1 << 30
+    first = torch.where(ok_s, ray, torch.full_like(ray, big)).view(-1, 64).amin(1, keepdim=True)
+    fill = torch.where(first < big, -(first + 1), torch.full_like(first, _lib.SLOT_DEAD))
+    return torch.where(ok_s.view(-1, 64), ray.view(-1, 64), fill).reshape(-1).to(torch.int32).contiguous()
 
 
 # --------------------------------------------------------------------------------- backward pass

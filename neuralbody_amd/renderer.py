@@ -19,7 +19,7 @@ class RenderConfig:
 
     def __init__(self, N_samples=64, perturb=0.0, raw_noise_std=0.0, white_bkgd=False, H=None, W=None, mesh_th=50.0):
         # H, W (optional): image size of the view the rays come from (cfg.H * cfg.ratio in the reference); when
-        # batch['mask_at_box'] covers H*W pixels, rays are grouped into 8x4 pixel tiles per wavefront
+        # batch['mask_at_box'] covers H*W pixels, rays are marched in 8x8 pixel tiles
         self.H, self.W = H, W
         self.N_samples = int(N_samples)
         self.perturb = float(perturb)
@@ -175,39 +175,39 @@ class Renderer:
         return None
 
     def _tile_order(self, batch, n_pixel, b, e):
-        """slot -> ray permutation grouping the rays [b, e) into 8x4 pixel tiles (None when the image geometry
-        is unknown: the march then takes the rays in list order).  Pure index plumbing; results do not change."""
+        """The slot list that marches the rays [b, e) in 8 x 8 pixel tiles (ops.tile_slots; None when the image geometry is
+        unknown: the march then takes the rays in list order, 64 consecutive rays per workgroup).  Results do not depend on it
+        beyond rounding: it decides which rays share a workgroup, i.e. a voxel list."""
         H, W = getattr(self.cfg, "H", None), getattr(self.cfg, "W", None)
         mask = batch.get("mask_at_box")
         if not H or not W or mask is None or mask.numel() != int(H) * int(W) or e - b < 64:
             return None
-        # cached on the mask tensor's IDENTITY: the entry holds the tensor itself, so its address cannot be recycled
-        # for another frame's mask while the entry lives (round 1 keyed on data_ptr/_version, which a freed-and-
-        # reallocated batch reproduces).  A caller that rewrites the same tensor in place through a raw pointer
-        # (nb_raygen) bumps nothing, so the frame token `batch.get("frame_token")` is part of the key when given.
-        if n_pixel == int(H) * int(W):
-            # every pixel of the image is a ray (in pixel order: the list is the mask's non-zeros): the permutation depends on
-            # the image geometry only — no torch.nonzero (a host sync) and no argsort per view
+        H, W, dev = int(H), int(W), mask.device
+        geo = getattr(self, "_slot_pixels", None)
+        if geo is None or geo[0] != (H, W, str(dev)):
+            geo = self._slot_pixels = ((H, W, str(dev)), ops.tile_pixels(H, W, dev))
+        if n_pixel == H * W:
+            # every pixel of the image is a ray: the list depends on the image geometry and the ray range only
             full = getattr(self, "_order_full", None)
             if full is None:
                 full = self._order_full = {}
-            key = (int(H), int(W), b, e, str(mask.device))
+            key = (H, W, b, e, str(dev))
             if key not in full:
                 while len(full) >= 8:  # a handful of geometries / ray ranges per process; callers that vary them must not grow it
                     full.pop(next(iter(full)))
-                full[key] = ops.tile_order(torch.arange(b, e, device=mask.device), int(W))
+                full[key] = ops.tile_slots(torch.ones(H * W, dtype=torch.bool, device=dev), geo[1], b, e)
             else:
                 full[key] = full.pop(key)  # most recently used last
             return full[key]
+        # cached on the mask tensor's IDENTITY: the entry holds the tensor itself, so its address cannot be recycled for
+        # another frame's mask while the entry lives.  A caller that rewrites the same tensor in place through a raw pointer
+        # (nb_raygen) bumps nothing, so the frame token `batch.get("frame_token")` is part of the key when given.
         cached = getattr(self, "_order_cache", None)
         token = batch.get("frame_token")
-        if cached is not None and cached[0] is mask and cached[1] == (mask._version, int(W), b, e, token):
+        if cached is not None and cached[0] is mask and cached[1] == (mask._version, W, b, e, token):
             return cached[2]
-        pix = torch.nonzero(mask.reshape(-1), as_tuple=False).reshape(-1)
-        if pix.numel() != n_pixel:
-            return None
-        order = ops.tile_order(pix[b:e], int(W))
-        self._order_cache = (mask, (mask._version, int(W), b, e, token), order)
+        order = ops.tile_slots(mask, geo[1], b, e)  # the ray count is whatever the mask holds: no read-back
+        self._order_cache = (mask, (mask._version, W, b, e, token), order)
         return order
 
 

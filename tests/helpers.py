@@ -71,7 +71,7 @@ def assert_close(a, b, tol, name="", rel=True):
 
 # arithmetics whose summation order depends on WHICH rays share a workgroup (the fc_0-folded march contracts over the
 # workgroup's voxel list): regrouping the rays moves results by rounding, not bit for bit
-GROUP_DEPENDENT = ("f16f6v", "f16f6", "auto")
+GROUP_DEPENDENT = ("f16f6", "auto")
 
 
 def same_result(a, b, precision, tol=2e-6):

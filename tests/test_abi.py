@@ -26,7 +26,8 @@ def test_library_exports_every_header_symbol(lib):
 
 def test_sizes_and_struct_layout(lib):
     # 8*44*256 + 256 + 2*(8*32*256 + 256) + 256 + 4 + 8*32*256 + 4*44*256 + 128 + 384 + 4
-    assert lib.nb_mlp_pack_size() == 333320 + 650 * 2048 // 4 + 4 * 272 * 1024 // 4 + 2 * (540 * 2048 // 4 + 16) + 4 * 176 * 1024 // 4  # fp32 fragments + bf16 ring stream + M-split f16f6 streams + ring f16f8 and f16f6 streams with their scale words + the fc_0-folded kernel's stream
+    assert lib.nb_mlp_pack_size() == 333320 + 4 * 176 * 1024 // 4 + 8  # fp32 fragments + the f16f6 stream (4 waves x 176 KiB) + its six-bit statistic
+    assert lib.nb_mlp_six_bit_stats_offset() == lib.nb_mlp_pack_size() - 8
     assert lib.nb_mlp_latent_bias_size() == 384
     assert C.sizeof(_lib.NbMlpParams) == 16 * 8
     assert lib.nb_scan_scratch_size(0) >= 256 and lib.nb_scan_scratch_size(1 << 20) >= 2 * 4 * (1 << 20)
@@ -58,7 +59,7 @@ def test_ctypes_structs_match_the_header_compiled_by_gcc(tmp_path):
 
 def test_error_codes_without_touching_a_device(lib):
     # NULL scene -> NB_EINVAL and a message, no crash, no launch
-    rc = lib.nb_march(None, None, None, None, None, None, None, 10, 64, None, None, None, None, 0, None, None, None,
+    rc = lib.nb_march(None, None, None, None, None, None, None, 10, 64, None, None, None, 0, None, 0, None, None, None,
                       None, None, None, 0, None)
     assert rc == -1
     assert b"nb_march" in lib.nb_last_error()

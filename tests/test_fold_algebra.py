@@ -1,4 +1,4 @@
-"""The algebra the f16f8 / f16f6 march kernels rest on (CPU, float64): feature_fc, latent_fc and view_fc have no activation
+"""The algebra the f16f6 march kernel rests on (CPU, float64): feature_fc, latent_fc and view_fc have no activation
 between them (lib/networks/latent_xyzc.py:105-119), so they are ONE linear layer of fc_2's output and the encodings,
     view_w[:, :256] . latent_w[:, :256] . feature_w                      (128 x 256, over net)
     view_w[:, 256:]                                                      (128 x 90, over [viewdir PE | xyz PE])

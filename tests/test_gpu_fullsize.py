@@ -44,7 +44,7 @@ def _check(size, n_samples, n_check, precision):
     okn = ok.numpy()
     all_err = np.abs(out["rgb_map"][0, sel.to(dev)].cpu().numpy() - ref["rgb_map"][0].numpy()).max(1)
     for i in np.nonzero(~okn)[0]:
-        bound = H.RGB_TOL if precision in ("f32", "bf16x3") and abs(float(sigma_last[i])) > 2e-5 else float(t_last[i]) + H.RGB_TOL
+        bound = H.RGB_TOL if precision == "f32" and abs(float(sigma_last[i])) > 2e-5 else float(t_last[i]) + H.RGB_TOL
         assert all_err[i] <= bound, "ill-conditioned ray %d: err %.3e > %.3e (sigma_last %.2e, T_last %.2e)" % (
             i, all_err[i], bound, float(sigma_last[i]), t_last[i])
     err = H.assert_close(out["rgb_map"][0, seld].cpu().numpy(), ref["rgb_map"][0].numpy()[okn], H.RGB_TOL, "rgb_map", rel=False)
@@ -57,12 +57,12 @@ def _check(size, n_samples, n_check, precision):
     return err
 
 
-@pytest.mark.parametrize("precision", ["f16f6v", "f16f6", "f16f6r", "f16f8", "bf16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16f6", "f32"])
 def test_headline_view_512x512x64_train_mode(precision):
     _check(512, 64, 4096, precision)
 
 
-@pytest.mark.parametrize("precision", ["f16f6v", "f16f6", "f16f8", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f16f6"])
 def test_config3_view_1024x1024x128(precision):
     _check(1024, 128, 1024, precision)
 
@@ -94,30 +94,19 @@ def test_full_size_encoder_matrix_pipe_kernels_match_the_fp32_kernels(monkeypatc
         assert torch.equal(a.abs().sum(1) > 0, b.abs().sum(1) > 0)  # the same active voxels
 
 
-def test_auto_times_both_organisations_once_and_keeps_the_faster():
-    """precision='auto': the first full-size march times the ring and the M-split kernel of the f16f6 arithmetic on its own
-    rays and the Network keeps the faster one (network.AUTO_TUNE_MIN_RAYS); the render of that call and of every later one is
-    the chosen kernel's, bit for bit."""
+def test_auto_is_a_function_of_the_weights_and_renders_reproducibly():
+    """precision='auto' picks its kernel from the packed weights alone (no timing): two Networks with the same
+    weights pick the same one, and re-rendering a view gives the same bits."""
     dev = torch.device(DEV)
     sd, body, net, rend, bd, n = bench.build_scene(dev, 512, 512, 64, None)
-    assert net.precision == "auto" and net.march_precision() == "f16f6" and net._auto_org is None
+    assert net.precision == "auto" and net.march_precision() == "f16f6"
+    net.eval()  # (train-mode BatchNorm sums its statistics with atomics: the volumes then differ by rounding between two encodes)
     with torch.no_grad():
         first = rend.render(bd)["rgb_map"].clone()
-        org = net._auto_org
-        assert org in ("f16f6", "f16f6r") and net.march_precision() == org
-        print("measured: %s -> %s" % ({k: round(v, 2) for k, v in net._auto_times.items()}, org))
-        assert min(net._auto_times.values()) == net._auto_times[org]
         again = rend.render(bd)["rgb_map"]
-        assert net._auto_org == org
-        sd2, body2, net2, rend2, bd2, _ = bench.build_scene(dev, 512, 512, 64, org)
-        explicit = rend2.render(bd2)["rgb_map"]
     assert torch.equal(first, again)
-    assert float((first - explicit).abs().max()) <= 1e-6  # (another Network object: its encoder sums BatchNorm statistics with atomics)
-    # small marches (training batches, the fixtures) never trigger the measurement
-    sd3, body3, net3, rend3, bd3, _ = bench.build_scene(dev, 64, 64, 8, None)
-    with torch.no_grad():
-        rend3.render(bd3)
-    assert net3._auto_org is None and net3.march_precision() == "f16f6"
+    sd2, body2, net2, rend2, bd2, _ = bench.build_scene(dev, 64, 64, 8, None)
+    assert net2.march_precision() == "f16f6"
 
 
 def test_full_size_training_gradients_matrix_pipe_vs_fp32_kernels(monkeypatch):

@@ -19,8 +19,8 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 ALL = list(scenes.SCENES)
-PRECISIONS = ["f32", "bf16x3", "f16f6r", "f16f8", "f16f6", "f16f6v"]  # nb_march kernel families
-POINT_PRECISIONS = ["f32", "bf16x3", "f16f6", "f16f6v"]  # nb_decode_points kernel families (the f16 arithmetics are march-only)
+PRECISIONS = ["f32", "f16f6"]  # nb_march / nb_decode_points arithmetics
+POINT_PRECISIONS = PRECISIONS
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -77,14 +77,14 @@ def test_decode_points_stages_against_oracle(precision):
         dens = orc.calculate_density(sdt, w, vols, sp_cpu)[0]
     scene = net.make_scene(vols_dev, sp, precision)
     lb = net.latent_bias(bd["latent_index"])
-    tap = precision not in ("f16f6", "f16f6v")  # the f16f6 point decoder is the march kernel (every point a one-sample ray): no activation tap
+    tap = precision != "f16f6"  # the f16f6 point decoder is the march kernel (every point a one-sample ray): no activation tap
     res = ops.decode_points(scene, net.packed_weights(precision), lb, w[0].to(DEV).contiguous(), v[0].to(DEV).contiguous(),
                             debug=tap, precision=precision)
     out, dbg = res if tap else (res, None)
     torch.cuda.synchronize()
     assert np.abs(feat.numpy()).max() > 0.1 and (np.abs(feat.numpy()).sum(1) == 0).any()
-    # raw logits reach |20| with the synthetic alpha_fc x20 / rgb_fc x8 gains; the split-bf16 path carries ~2^-16
-    # relative error per GEMM term (dropped lo.lo product), the fp32 path only summation-order noise
+    # raw logits reach |20| with the synthetic alpha_fc x20 / rgb_fc x8 gains; the six-bit cross terms carry ~2^-15
+    # relative error per GEMM term, the fp32 path only summation-order noise
     tol_h, tol_raw = (1e-4, 2e-4) if precision == "f32" else (3e-4, 1e-3)
     e_h = float("nan")
     if tap:
@@ -235,10 +235,24 @@ def test_render_with_trained_weights_matches_reference(precision):
     H.assert_close(out["depth_map"].cpu().numpy(), g["depth_map"], 2e-4, "depth_map")
     extra = ""
     if precision == "auto":
+        import json
+        import warnings
+
         from neuralbody_amd import ops
+        from neuralbody_amd.network import SIX_BIT_MAX_SMALL
 
         frac = ops.six_bit_small_fraction(net.packed_weights("f16f6")).cpu().numpy()
-        extra = " (auto -> %s, six-bit small fraction per layer %s)" % (net.march_precision(), np.round(frac, 3))
+        extra = " (auto -> %s, six-bit small fraction per layer [fc_1, fc_2, colour head] %s)" % (net.march_precision(), np.round(frac, 3))
+        # the statistic the 'auto' policy rests on, for optimiser-shaped weights: asserted, and recorded where the round's
+        # records keep it (a warning survives `pytest -q`; the JSON lands in gpurun_out/ when run through gpurun)
+        assert net.march_precision() == "f16f6" and float(frac.max()) < 0.7 * SIX_BIT_MAX_SMALL, frac
+        rec = {"fixture": "scene_small_trained.npz", "six_bit_small_fraction": {"fc_1": float(frac[0]), "fc_2": float(frac[1]),
+               "colour_head": float(frac[2])}, "threshold": SIX_BIT_MAX_SMALL, "rgb_linf_vs_reference": err}
+        warnings.warn("trained-like weights: " + json.dumps(rec))
+        out_dir = os.path.join(os.path.dirname(H.GOLDEN), "..", "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, "trained_six_bit_fraction.json"), "w") as f:
+                json.dump(rec, f)
     print("trained/%s: rgb L-inf vs reference %.2e%s" % (precision, err, extra))
     assert float(g["rgb_map"].max() - g["rgb_map"].min()) > 0.2, "fixture is degenerate"
 
@@ -262,11 +276,11 @@ def test_march_on_oracle_volumes_matches_reference(name, precision):
     # disp = 1 / (depth / acc): a quotient of two sums that both vanish on rays grazing the body, so it amplifies the weights'
     # error there (the worst pixel of small_eval has acc 0.03); the six-bit cross terms get 5e-4 for it, everything else
     # keeps the common tolerances
-    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 5e-4 if precision in ("f16f6", "f16f6r", "f16f6v") else 3e-4, "disp_map")
+    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 5e-4 if precision == "f16f6" else 3e-4, "disp_map")
     assert float(g["rgb_map"].max()) > 0.1, "fixture is degenerate"
 
 
-@pytest.mark.parametrize("precision", ["f16f6", "f16f6r", "f16f8", "f16f6v"])
+@pytest.mark.parametrize("precision", ["f16f6"])
 def test_activations_beyond_fp16_range_saturate_instead_of_turning_into_nan(precision):
     """the fp16 head of an activation is the one place where the f16 arithmetics have less range than fp32.  With
     MODE.FP16_OVFL set by the kernels (nb_f6_ops.h) a layer output above 65504 saturates; without it it became inf, the
@@ -292,8 +306,9 @@ def test_activations_beyond_fp16_range_saturate_instead_of_turning_into_nan(prec
 
 
 def test_auto_precision_picks_six_bits_unless_the_weight_blocks_are_wide():
-    """Network(precision='auto') = 'f16f6' for ordinary weights and 'f16f8' when a layer's (row, 32 K) blocks span a wide
-    dynamic range (the statistic nb_mlp_pack_sections leaves behind the f16f6 stream, nb_mlp_six_bit_stats_offset)."""
+    """Network(precision='auto') = 'f16f6' for ordinary weights and the exact 'f32' kernel (with a warning) when a layer's
+    (row, 32 K) blocks span a wide dynamic range (the statistic nb_mlp_pack_sections leaves behind the f16f6 stream,
+    nb_mlp_six_bit_stats_offset).  A function of the weights alone: no timing, the same answer on every rank."""
     from neuralbody_amd import ops
     from neuralbody_amd.network import SIX_BIT_MAX_SMALL
 
@@ -302,7 +317,7 @@ def test_auto_precision_picks_six_bits_unless_the_weight_blocks_are_wide():
     assert net.march_precision() == "f16f6"
     frac = ops.six_bit_small_fraction(net.packed_weights("f16f6")).cpu().numpy()
     print("share of weights below 1/8 of their block maximum, per layer:", np.round(frac, 3))
-    assert frac.shape == (4,) and (frac > 0.05).all() and (frac < 0.35).all()
+    assert frac.shape == (3,) and (frac > 0.05).all() and (frac < 0.35).all()
     # per-column gains of 2^-6..2^6 on fc_1 (compensated on fc_0's rows: the function is unchanged)
     rs = np.random.RandomState(5)
     gain = np.exp2(rs.uniform(-6, 6, 256)).astype(np.float32)
@@ -311,7 +326,8 @@ def test_auto_precision_picks_six_bits_unless_the_weight_blocks_are_wide():
     wide["fc_0.bias"] = (np.array(sd["fc_0.bias"]) * gain).astype(np.float32)
     wide["fc_1.weight"] = (np.array(sd["fc_1.weight"]) / gain[None, :, None]).astype(np.float32)
     net2 = H.make_network(wide, DEV, True, "auto")
-    assert net2.march_precision() == "f16f8"
+    with pytest.warns(UserWarning, match="exact fp32 kernel"):
+        assert net2.march_precision() == "f32"
     assert float(ops.six_bit_small_fraction(net2.packed_weights("f16f6")).max()) > SIX_BIT_MAX_SMALL
     # the choice follows the weights: loading the ordinary ones back flips it
     net2.load_state_dict(net.state_dict())
@@ -335,9 +351,15 @@ def test_march_edge_cases(precision):
         for k in full:
             assert part[k].shape[0] == n
             assert H.same_result(part[k], full[k][:n], precision, 1e-4 if k == "disp_map" else 2e-6), (k, n)
-    # an explicit identity / reversed ray_order changes nothing
+    # an explicit slot list (nb_hip.h ray_order: the rays reversed, padded to whole groups of 64 with padding slots that march
+    # the last ray again and store nothing, plus a dead group) changes nothing
+    from neuralbody_amd._lib import SLOT_DEAD
+
     perm = torch.arange(n_all - 1, -1, -1, dtype=torch.int32, device=DEV)
-    rev = net.render_rays(ro, rd, ne, fa, vols_dev, sp, 64, white_bkgd=True, ray_order=perm)
+    pad = -(perm[-1:].expand((-n_all) % 64) + 1)
+    dead = torch.full((64,), SLOT_DEAD, dtype=torch.int32, device=DEV)
+    slots = torch.cat([dead, perm, pad]).contiguous()
+    rev = net.render_rays(ro, rd, ne, fa, vols_dev, sp, 64, white_bkgd=True, ray_order=slots)
     assert H.same_result(rev["rgb_map"], full["rgb_map"], precision) and H.same_result(rev["weights"], full["weights"], precision)
     # other sample counts against the oracle
     sub = slice(0, 160)
@@ -483,9 +505,9 @@ def test_render_end_to_end_matches_reference(name, precision):
         vols = net.encode_sparse_voxels(sp) if r["mode"] != "train" else None
         if vols is not None:
             pv = rend.get_pixel_value(bd["ray_o"], bd["ray_d"], bd["near"], bd["far"], vols, sp, bd)
-            # the unfused path decodes points with the split-bf16 kernels whatever the march arithmetic is: for 'f16f8' the
-            # two sides round differently (each within its own budget against the reference), otherwise they agree closely
-            H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 6e-5 if precision in ("f16f8", "f16f6", "f16f6r", "f16f6v") else 1e-5,
+            # the unfused path decodes every sample as a one-sample ray of the same kernel, in other groups (points of one
+            # depth step share a workgroup there, samples of 64 rays here): the two sides differ by rounding
+            H.assert_close(pv["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 6e-5 if precision == "f16f6" else 1e-5,
                            "fused vs unfused rgb")
 
 
@@ -537,7 +559,7 @@ def test_density_cube_matches_reference(precision, monkeypatch):
     assert cube.is_cuda and tuple(cube.shape) == g["cube"].shape
     # densities reach |20|; 'f16f6' carries ~4e-4 of absolute density error (its measured sigma error, bench.ILL_SIGMA), the
     # exact and split-bf16 decoders stay below 2e-4
-    err = H.assert_close(cube.cpu().numpy(), g["cube"], 1e-3 if precision in ("f16f6", "f16f6v") else 2e-4, "cube")
+    err = H.assert_close(cube.cpu().numpy(), g["cube"], 1e-3 if precision == "f16f6" else 2e-4, "cube")
     # the iso-surface decision marching cubes makes is the same everywhere except within the tolerance of the threshold
     ours, ref = cube.cpu().numpy() > 5.0, g["cube"] > 5.0
     assert np.array_equal(ours[np.abs(g["cube"] - 5.0) > 1e-2], ref[np.abs(g["cube"] - 5.0) > 1e-2])

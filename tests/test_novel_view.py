@@ -127,7 +127,7 @@ def test_image_assemble_matches_numpy():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16f6"])
 def test_novel_view_loop_matches_oracle(precision):
     """gen_path camera -> nb_raygen -> Renderer.render -> nb_image_assemble == oracle image_rays + render + scatter."""
     from oracle import neuralbody_oracle as orc

@@ -12,40 +12,64 @@ def _renderer(H, W):
     return Renderer(Network(num_train_frame=3), RenderConfig(N_samples=8, perturb=0.0, H=H, W=W))
 
 
+def _check_slots(order, mask, H, W, b, e):
+    """A slot list of ops.tile_slots: every ray of [b, e) exactly once as a non-negative entry; 64 consecutive slots = one 8 x 8
+    tile (16: a 4 x 4 block); padding slots reference a ray of their own tile; dead groups are entirely dead."""
+    from neuralbody_amd._lib import SLOT_DEAD
+
+    order = order.long()
+    assert order.numel() == ((H + 7) // 8) * ((W + 7) // 8) * 64
+    pix = torch.nonzero(mask.reshape(-1)).reshape(-1)[b:e]  # pixel of every ray of the range
+    real = order[order >= 0]
+    assert torch.equal(torch.sort(real).values, torch.arange(e - b))
+    for g in range(order.numel() // 64):
+        grp = order[64 * g:64 * g + 64]
+        if (grp == SLOT_DEAD).any():
+            assert (grp == SLOT_DEAD).all()
+            continue
+        rays = torch.where(grp >= 0, grp, -grp - 1)
+        py, px = pix[rays] // W, pix[rays] % W
+        assert int(py.max() - py.min()) <= 7 and int(px.max() - px.min()) <= 7 and int(py.min()) // 8 == int(py.max()) // 8
+        assert (grp >= 0).any() and set((-grp[grp < 0] - 1).tolist()) <= set(grp[grp >= 0].tolist())
+        for q in range(4):
+            blk = grp[16 * q:16 * q + 16]
+            r = blk[blk >= 0]
+            if r.numel():
+                assert int((pix[r] // W).max() - (pix[r] // W).min()) <= 3 and int((pix[r] % W).max() - (pix[r] % W).min()) <= 3
+
+
 def test_tile_order_of_a_full_coverage_view_needs_no_mask_readback():
-    """Every pixel a ray: the order is a function of the image geometry; it equals what the general path (non-zeros of the
-    mask -> tile keys -> argsort) gives, is a permutation, is computed once per geometry / ray range, and 64 consecutive slots
-    hold one 8x8 pixel tile (32: an 8x4 half, 16: a 4x4 block)."""
+    """Every pixel a ray: the slot list is a function of the image geometry and the ray range; computed once per (geometry,
+    range); 64 consecutive slots hold one 8 x 8 pixel tile; a rank's share of the rays leaves the other tiles dead."""
     H, W = 16, 24
     r = _renderer(H, W)
     n = H * W
-    full = r._tile_order({"mask_at_box": torch.ones(1, n, dtype=torch.bool)}, n, 0, n)
-    ref = ops.tile_order(torch.nonzero(torch.ones(n, dtype=torch.bool)).reshape(-1), W)
-    assert torch.equal(full, ref) and full.dtype == torch.int32
-    assert torch.equal(torch.sort(full.long()).values, torch.arange(n))
-    tile = full[:64].long()
-    assert int((tile // W).max() - (tile // W).min()) == 7 and int((tile % W).max() - (tile % W).min()) == 7
-    tile = full[:32].long()
-    assert int((tile // W).max() - (tile // W).min()) == 3 and int((tile % W).max() - (tile % W).min()) == 7
-    for half in (full[:16].long(), full[16:32].long()):  # every 16 slots: one 4 x 4 pixel block (one wave's samples in the fused march)
-        assert int((half // W).max() - (half // W).min()) == 3 and int((half % W).max() - (half % W).min()) == 3
+    mask = torch.ones(n, dtype=torch.bool)
+    full = r._tile_order({"mask_at_box": mask[None]}, n, 0, n)
+    assert full.dtype == torch.int32 and int((full < 0).sum()) == 0
+    _check_slots(full, mask, H, W, 0, n)
     again = r._tile_order({"mask_at_box": torch.ones(1, n, dtype=torch.bool)}, n, 0, n)  # another mask tensor, same geometry
     assert again is full
     part = r._tile_order({"mask_at_box": torch.ones(1, n, dtype=torch.bool)}, n, 64, 320)  # a rank's share of the rays
-    assert torch.equal(torch.sort(part.long()).values, torch.arange(256)) and part is not full
+    assert part is not full
+    _check_slots(part, mask, H, W, 64, 320)
 
 
 def test_tile_order_of_a_partial_mask_follows_the_mask():
-    H, W = 16, 24
+    """Pixels without a ray become padding slots of their tile (the tile's rays stay one workgroup), tiles without a ray are
+    dead; image sizes that are no multiple of 8 are padded the same way."""
+    H, W = 19, 27
     r = _renderer(H, W)
     mask = torch.zeros(H, W, dtype=torch.bool)
     mask[2:14, 3:20] = True
+    mask[5, 7] = False
     n = int(mask.sum())
     batch = {"mask_at_box": mask.reshape(1, -1)}
     order = r._tile_order(batch, n, 0, n)
-    assert torch.equal(order, ops.tile_order(torch.nonzero(mask.reshape(-1)).reshape(-1), W))
+    _check_slots(order, mask, H, W, 0, n)
     assert r._tile_order(batch, n, 0, n) is order          # same tensor object, same version: cached
-    assert r._tile_order(batch, n - 1, 0, n - 1) is None   # ray count and mask disagree: list order
+    assert r._tile_order(batch, 40, 0, 40) is None         # fewer than 64 rays: list order
+    _check_slots(r._tile_order(batch, n, 17, 150), mask, H, W, 17, 150)
 
 
 def test_out_sh_is_read_once_per_tensor_version():
