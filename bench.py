@@ -496,16 +496,15 @@ def main():
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     per_rank = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # what every rank spent in its march launches and in the RCCL all-gather of the RGB tiles (HIP events on its stream)
+        # MAX over the ranks of the elapsed time; what every rank spent in its march launches and in the RCCL all-gather of the
+        # RGB tiles (HIP events on its stream); all ranks must have run the same arithmetic
+        from neuralbody_amd import _lib
+        from neuralbody_amd.parallel import reduce_timings
+
         ag_ms = float(np.mean([a.elapsed_time(b) for a, b in gather_events])) if gather_events else float("nan")
-        mine = torch.tensor([march_ms, ag_ms, step_ms[len(step_ms) // 2]], dtype=torch.float64, device=dev)
-        allr = torch.empty(world * 3, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, mine)
-        per_rank = [{"rank": r, "march_ms": float(allr[3 * r]), "allgather_ms": float(allr[3 * r + 1]), "median_step_ms": float(allr[3 * r + 2])}
-                    for r in range(world)]
+        elapsed, rows = reduce_timings(elapsed, [march_ms, ag_ms, step_ms[len(step_ms) // 2]], _lib.PRECISIONS[net.march_precision()],
+                                       dist.group.WORLD, dev)
+        per_rank = [{"rank": r, "march_ms": row[0], "allgather_ms": row[1], "median_step_ms": row[2]} for r, row in enumerate(rows)]
 
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload

@@ -9,6 +9,8 @@
 //   nb_relu_bwd / nb_colsum   elementwise mask and bias-gradient reductions (stand-alone forms)
 //   nb_trilinear_bwd   dF [N,352] -> gradients of the ACTIVE voxel rows of the four feature volumes
 //                      (grid_sample backward restricted to active voxels: inactive sites are constants)
+#include <stdlib.h>
+
 #include "nb_march_common.h"
 #include "nb_trread.h"
 
@@ -671,6 +673,16 @@ int nb_sgemm(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float al
     return nb_gemm_fused(trans_a, trans_b, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, nullptr, 0, nullptr, stream);
 }
 
+// NB_BWD_SPLIT=0 in the environment (read once) keeps every GEMM on the exact-fp32 kernels: an exact training step for A/B
+// runs and debugging; the default sends the large shapes to the 16-bit matrix pipe with bf16 pairs (~2^-16)
+static bool bwd_split_enabled() {
+    static const bool on = [] {
+        const char *e = getenv("NB_BWD_SPLIT");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, float alpha, const float *a, int32_t lda,
                   const float *b, int32_t ldb, float beta, float *c, int32_t ldc, const float *mask_y, int32_t ldy,
                   float *colsum, void *stream) {
@@ -686,7 +698,7 @@ int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, flo
             return NB_OK;
         }
         // weight-gradient shapes (M, N >= 32, thousands of rows, 16-byte aligned rows): bf16 pairs on the 16-bit matrix pipe
-        if (m >= 32 && n >= 32 && k >= 1024 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0) {
+        if (bwd_split_enabled() && m >= 32 && n >= 32 && k >= 1024 && lda % 4 == 0 && ldb % 4 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0) {
             hipLaunchKernelGGL(gemm_tn16_kernel, dim3(nb_ceil_div(m, 128), nb_ceil_div(n, 128), nb_ceil_div(k, TN16_ROWS)), dim3(256), 0,
                                st, a, lda, b, ldb, (long long)k, m, n, alpha, c, ldc);
             NB_CHECK_LAUNCH("gemm_tn16_kernel");
@@ -702,7 +714,7 @@ int nb_gemm_fused(int trans_a, int trans_b, int32_t m, int32_t n, int32_t k, flo
     // kernel pre-loads its first operand panels before looking at k
     const bool aligned = k > 0 && k % 16 == 0 && lda % 4 == 0 && ((uintptr_t)a % 16) == 0 && ldb % 4 == 0 && ((uintptr_t)b % 16) == 0;
     // the MLP backward's dX products (thousands of rows, K a multiple of 32, op(B) = B): bf16 pairs on the 16-bit matrix pipe
-    if (aligned && !trans_b && k % 32 == 0 && m >= 1024) {
+    if (bwd_split_enabled() && aligned && !trans_b && k % 32 == 0 && m >= 1024) {
         hipLaunchKernelGGL(gemm_rows16_kernel, grid, block, 0, st, a, lda, b, ldb, (long long)m, k, n, alpha, beta, c, ldc, mask_y, ldy,
                            colsum);
         NB_CHECK_LAUNCH("gemm_rows16_kernel");

@@ -18,12 +18,13 @@ __device__ __forceinline__ unsigned lane_offset(int lane, int pitch) {
     const int l15 = lane & 15, g = lane >> 4;
     return (unsigned)((8 * (g >> 1) + (l15 >> 2)) * pitch + (16 * (g & 1) + 4 * (l15 & 3)) * 2);
 }
-// the fragment: rows +0..3 at `addr`, rows +4..7 at `addr + 4 pitch` (LDS byte addresses).  Inline asm: the compiler does not
-// count these reads — wait with an `s_waitcnt lgkmcnt(0)` asm that names every fragment register as "+v" before the MFMAs
+// the fragment: rows +0..3 at `addr`, rows +4..7 at `addr + 4 pitch` (LDS byte addresses).  The compiler's own builtin: it
+// counts the reads on lgkmcnt and places the wait in front of the first consumer (rounds 1-3 issued them from inline asm,
+// where correctness hung on how the register allocator treated the asm outputs: ADVICE r03)
+typedef __attribute__((address_space(3))) s4 *lds_s4_ptr;
 __device__ __forceinline__ bf8 frag(unsigned addr_lo4, unsigned addr_hi4) {
-    s4 a, b;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a) : "v"(addr_lo4));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b) : "v"(addr_hi4));
+    const s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(unsigned long long)addr_lo4);
+    const s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(unsigned long long)addr_hi4);
     const s8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_bit_cast(bf8, v);
 }

@@ -202,8 +202,9 @@ class NovelViewRenderer:
             nxt = next(it, None)
             if nxt is not None:
                 launched = self._launch_rays(nxt[0], nxt[1], nxt[2])
-            with torch.no_grad():
-                yield self._render_batch(batch, bgr, scale, None)
+            with torch.no_grad():  # the render runs without autograd; the consumer's loop body keeps ITS grad mode (yielding from
+                out = self._render_batch(batch, bgr, scale, None)  # inside the block would leak no_grad into it: ADVICE r03)
+            yield out
             cur = nxt
 
     def render_view(self, K, RT, can_bounds, frame, bgr=False, scale=1.0, t_rand=None):

@@ -56,3 +56,25 @@ def render_sharded(renderer, batch, group=None, keys=("rgb_map",)):
         return {k: part[k] for k in keys}
     sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
     return {k: all_gather_tiles(part[k][0], group, sizes)[None] for k in keys}
+
+
+def reduce_timings(elapsed_s, local, precision_code, group=None, device=None):
+    """The cross-rank bookkeeping of bench.py: the MAX over the ranks of the elapsed wall time (the whole-job time of the bench
+    contract) by one all_reduce, and every rank's `local` floats (march ms, all-gather ms, median step ms ...) in rank order
+    by one all_gather.  Raises if the ranks did not all run the same arithmetic (`precision_code`: its number in
+    _lib.PRECISIONS) — an image stitched from tiles of different arithmetic would still be inside the tolerance, but it is not
+    what a single GPU renders.  Without a process group: (elapsed_s, [local])."""
+    local = [float(v) for v in local]
+    if not (dist.is_available() and dist.is_initialized()):
+        return float(elapsed_s), [local]
+    world = dist.get_world_size(group)
+    t = torch.tensor([float(elapsed_s)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    mine = torch.tensor(local + [float(precision_code)], dtype=torch.float64, device=device)
+    allr = torch.empty(world * mine.numel(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(allr, mine, group=group)
+    allr = allr.view(world, mine.numel()).cpu()
+    codes = sorted(set(int(c) for c in allr[:, -1].tolist()))
+    if len(codes) != 1:
+        raise RuntimeError("the ranks of this job ran different decoder arithmetics: precision codes %s" % codes)
+    return float(t.item()), [[float(v) for v in row[:-1]] for row in allr.tolist()]

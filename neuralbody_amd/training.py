@@ -6,8 +6,12 @@ F | h1 | h2 | h3 | G | V | PE per point) and composites with `nb_composite`; the
     d rgb_map --nb_composite_bwd--> d raw --MLP backward (fp32 MFMA GEMMs with fused ReLU-mask / bias-sum epilogues)-->
     parameter gradients + dF --nb_trilinear_bwd--> gradients of the active rows of the four feature volumes
 
-All arithmetic is fp32.  The merged feature_fc/latent_fc layer of the inference kernels is NOT used here: gradients are
-taken layer by layer exactly as the reference modules are written (lib/networks/latent_xyzc.py:99-121).
+The forward is exact fp32.  The backward's large GEMMs (weight gradients with >= 1024 rows, input gradients with >= 1024 rows
+and K % 32 == 0) and the encoder's >= 32-channel backward convolutions run on the 16-bit matrix pipe with both operands as bf16
+head + remainder pairs (three products, fp32 accumulation: ~2^-16 relative per product; measured gradient error against float64
+autograd 1.2e-5); `NB_BWD_SPLIT=0` / `NB_ENC_SPLIT=0` in the environment keep the decoder GEMMs / the encoder
+convolutions on the exact-fp32 kernels.  The merged feature_fc/latent_fc layer of the inference kernels is NOT used here:
+gradients are taken layer by layer exactly as the reference modules are written (lib/networks/latent_xyzc.py:99-121).
 """
 import os
 

@@ -179,3 +179,11 @@ def test_novel_view_loop_matches_oracle(precision):
         assert a["n_rays"] == b["n_rays"] and torch.equal(a["img"], b["img"]) and torch.equal(a["depth"], b["depth"])
         assert torch.equal(a["mask_at_box"], b["mask_at_box"])
     assert list(nvr.render_views(iter(()))) == []
+    # the generator does not leak its no_grad into the consumer's loop body, nor past an abandoned iteration
+    assert torch.is_grad_enabled()
+    gen = nvr.render_views((K0, RT, body["can_bounds"], frame) for RT in path[:2])
+    for _view in gen:
+        assert torch.is_grad_enabled()
+        break
+    assert torch.is_grad_enabled()
+    gen.close()

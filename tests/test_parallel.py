@@ -54,6 +54,15 @@ def _worker(rank, world, port, n, out_dir):
         assert cat.shape == (sum(sizes), 2)
         off = sum(sizes[:rank])
         assert torch.equal(cat[off:off + sizes[rank]], t)
+        # bench.py's cross-rank bookkeeping: MAX-reduced elapsed time, per-rank rows in rank order, one arithmetic per job
+        elapsed, rows = parallel.reduce_timings(1.0 + rank, [10.0 * rank, 0.5, 7.0 + rank], precision_code=1)
+        assert elapsed == float(world) and len(rows) == world
+        assert all(rows[r] == [10.0 * r, 0.5, 7.0 + r] for r in range(world))
+        try:
+            parallel.reduce_timings(1.0, [0.0], precision_code=rank)  # the ranks disagree
+            raise AssertionError("ranks with different arithmetics must be refused")
+        except RuntimeError as e:
+            assert "different decoder arithmetics" in str(e)
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.ones(1))
     finally:
         dist.destroy_process_group()
@@ -66,6 +75,10 @@ def test_sharded_render_gloo_world2(tmp_path, n):
     mp.spawn(_worker, args=(world, port, n, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert os.path.exists(tmp_path / ("ok_%d.npy" % r))
+
+
+def test_reduce_timings_without_a_process_group():
+    assert parallel.reduce_timings(2.5, [1.0, 2.0], 1) == (2.5, [[1.0, 2.0]])
 
 
 def test_shard_range_tiles_exactly():
