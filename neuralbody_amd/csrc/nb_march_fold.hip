@@ -80,6 +80,7 @@ constexpr int ACT_BYTES = ACT6_OFF + ACT6_BYTES;  // the folded first layer uses
 constexpr int WT_CHUNK = 4096;                 // Wt of 16 voxels: [form: heads, remainders][N tile] B fragments
 constexpr int U_CHUNK = 4096;                  // one wave's 64 features of 16 voxels: [form][M tile] x 1 KiB transposable image
 constexpr int K_CAP = 128;                     // voxels per pass (8 chunks)
+constexpr int KM_CAP = 1024;                   // longest voxel list marched in several passes (tier 3)
 constexpr int SCR_A = ACT_BYTES;               // alpha_fc partial sums [64 samples][4 waves] floats
 constexpr int SCR_C = SCR_A + 1024;            // rgb_fc partial sums [3][64][4] floats
 constexpr int WBOX_OFF = SCR_C;                // ... and, between two uses of those, the (wave, level) boxes: 16 x 8 ints
@@ -443,7 +444,8 @@ __device__ __forceinline__ void prep_boxes(char *actz, const Lvl &lv, const Grid
 struct Prep {
     int xlo, ylo, zlo, nx, nxy, n, k0;
     int K;     // uniform
-    int tier;  // uniform: 0 = one pass over all 64 samples, 1 = groups of 16 samples (one wave's), 2 = single samples
+    int tier;  // uniform: 0 = one pass over all 64 samples, 3 = the same list in passes of K_CAP voxels, 1 = groups of 16 samples
+               // (one wave's), 2 = single samples
     int any;   // uniform: at least one sample takes part
 };
 __device__ __forceinline__ int box_count(int xlo, int ylo, int zlo, int xhi, int yhi, int zhi) {
@@ -474,7 +476,9 @@ __device__ __forceinline__ Prep prep_wg(const char *actz, int part) {
     p.tier = 0;
     p.any = any;
     if constexpr (NW > 1) {
-        if (p.K > K_CAP) {  // uniform
+        if (p.K > K_CAP && p.K <= KM_CAP) {  // uniform
+            p.tier = 3;
+        } else if (p.K > K_CAP) {
             int worst = 0;
 #pragma unroll
             for (int w = 0; w < NW; ++w)
@@ -517,6 +521,32 @@ __device__ __forceinline__ void tbl_store(char *actz, const TblLoad &t, const Lv
         if (t.idx[q] >= 0) tbl[t.idx[q]] = t.rid[q] < 0 ? zero_off : (unsigned)(lv.rbase + t.rid[q]) << 10;
     if (tid < 16 && K + tid < ((K + 15) & ~15)) tbl[K + tid] = zero_off;  // the padding of the last chunk
 }
+// table of ONE PASS of a long voxel list (tier 3): thread t < 128 looks up K-list position k_lo + t — its level from the
+// levels' offsets, then the voxel of that level's box
+__device__ __forceinline__ void tbl_pass(char *actz, unsigned zero_off, int k_lo, int K, int tid) {
+    if (tid >= K_CAP) return;
+    unsigned *tbl = reinterpret_cast<unsigned *>(actz + TBL_OFF);
+    const int k = k_lo + tid;
+    unsigned e = zero_off;
+    if (k < K) {
+        const int k1 = *reinterpret_cast<const int *>(actz + LVL_OFF + 1 * 32 + 20), k2 = *reinterpret_cast<const int *>(actz + LVL_OFF + 2 * 32 + 20),
+                  k3 = *reinterpret_cast<const int *>(actz + LVL_OFF + 3 * 32 + 20);
+        const int L = (k >= k1) + (k >= k2) + (k >= k3);
+        const i32x4 *lp = reinterpret_cast<const i32x4 *>(actz + LVL_OFF + L * 32);
+        const i32x4 b0 = lp[0], b1 = lp[1];  // xlo ylo zlo nx | nxy k0 n -
+        const Lvl lv = load_lvl(actz, L);
+        const int j = k - b1.y;
+        const float rcp_xy = __builtin_amdgcn_rcpf((float)max(b1.x, 1)), rcp_x = __builtin_amdgcn_rcpf((float)max(b0.w, 1));
+        const int vz = (int)(((float)j + 0.5f) * rcp_xy);
+        const int r = mad24(vz, -b1.x, j);
+        const int vy = (int)(((float)r + 0.5f) * rcp_x);
+        const int vx = mad24(vy, -b0.w, r);
+        const int lin = mad24(mad24(b0.z + vz, lv.H, b0.y + vy), lv.W, b0.x + vx);
+        const int rid = lv.grid[lin];
+        if (rid >= 0) e = (unsigned)(lv.rbase + rid) << 10;
+    }
+    tbl[tid] = e;
+}
 __device__ __forceinline__ void lvl_store(char *actz, const Prep &p, int tid, int os, int part) {
     if (tid < 64 && os == 0) {
         i32x4 *d = reinterpret_cast<i32x4 *>(actz + LVL_OFF + part * 32);
@@ -532,9 +562,12 @@ struct UCfg {
     unsigned ring;  // LDS byte address of the wave's region
     int ring_off;   // the same as an offset into the workgroup's LDS
 };
+__device__ __forceinline__ UCfg ucfg_k(int K, unsigned lds_base, int wave);
 __device__ __forceinline__ UCfg ucfg(const char *actz, unsigned lds_base, int wave) {
+    return ucfg_k(__builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(actz + HDR_OFF)), lds_base, wave);
+}
+__device__ __forceinline__ UCfg ucfg_k(int K, unsigned lds_base, int wave) {
     UCfg u;
-    const int K = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(actz + HDR_OFF));
     u.nch = (K + 15) >> 4;
     u.R = u.nch <= 3 ? u.nch : (u.nch == 4 ? 3 : 2);  // (64 KiB - 4 KiB nch) / (4 waves x 4 KiB)
     u.ring_off = WT_CHUNK * u.nch + wave * u.R * U_CHUNK;
@@ -576,7 +609,9 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // that `take`s part scatters the 8 corner weights of its level.  Element k of sample column n (N tile nt): chunk k >> 4, fragment
 // lane 32 ((k >> 3) & 1) + n, element k & 7; heads at form 0, remainders 2 KiB behind.  LDS executes a wave's instructions in
 // order, so the scatter lands on the zeros without a barrier in between.
-__device__ __forceinline__ void wt_build(char *actz, const Lvl &lv, const GridCoord &g, bool take, int wave, int os, int part, int nch) {
+// (k_lo: first K-list position of the pass being built; corners outside [k_lo, k_lo + 16 nch) write nothing)
+__device__ __forceinline__ void wt_build(char *actz, const Lvl &lv, const GridCoord &g, bool take, int wave, int os, int part, int nch,
+                                         int k_lo = 0) {
     const int nt = wave >> 1, n = 16 * (wave & 1) + os;
     {
         char *z = actz + (part >> 1) * 2048 + nt * 1024 + ((part & 1) * 32 + n) * 16;
@@ -590,7 +625,7 @@ __device__ __forceinline__ void wt_build(char *actz, const Lvl &lv, const GridCo
         const float wx[2] = {(fx + 1.f) - q.ix, q.ix - fx};
         const float wy[2] = {(fy + 1.f) - q.iy, q.iy - fy};
         const float wz[2] = {(fz + 1.f) - q.iz, q.iz - fz};
-        const int kbase = b1.y + mad24(q.z0 - b0.z, b1.x, mad24(q.y0 - b0.y, b0.w, q.x0 - b0.x));
+        const int kbase = b1.y - k_lo + mad24(q.z0 - b0.z, b1.x, mad24(q.y0 - b0.y, b0.w, q.x0 - b0.x));
         const int sbase = nt * 1024 + n * 16;
         float cw[8];
         int ad[8];
@@ -602,7 +637,7 @@ __device__ __forceinline__ void wt_build(char *actz, const Lvl &lv, const GridCo
             cw[corner] = (wx[dx] * wy[dy]) * wz[dz];
             const int k = kbase + dx + dy * b0.w + dz * b1.x;
             const int off = ((k << 8) & ~0xfff) | ((k << 6) & 0x200) | ((k << 1) & 0xe);
-            ad[corner] = inb ? off + sbase : DUMMY_OFF;
+            ad[corner] = (inb && (unsigned)k < (unsigned)(16 * nch)) ? off + sbase : DUMMY_OFF;
         }
 #pragma unroll
         for (int cp = 0; cp < 4; ++cp) {
@@ -979,6 +1014,21 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
 #else
                 fold_mfma(a, actz, lane_i, wave, u, acc);
 #endif
+            } else if (tier == 3) {
+                // a list of up to KM_CAP voxels (points that are neighbours but not dense, wide pixel footprints): the same boxes,
+                // marched in passes of K_CAP voxels, each through table -> U -> Wt -> MFMA
+                const Lvl lv = load_lvl(actz, part);
+                const int K = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(actz + HDR_OFF));
+                for (int k_lo = 0; k_lo < K; k_lo += K_CAP) {
+                    tbl_pass(actz, a.fold.zero_off, k_lo, K, tid);
+                    __syncthreads();
+                    const UCfg u = ucfg_k(min(K - k_lo, K_CAP), lds_base, wave);
+                    dma_initial(a, actz, lane_i, wave, u);
+                    wt_build(actz, lv, g, ins_cur, wave, os, part, u.nch, k_lo);
+                    __syncthreads();
+                    fold_mfma(a, actz, lane_i, wave, u, acc);
+                    __syncthreads();
+                }
             } else {
                 // rays far apart: sample groups of 16 (one wave's) or single samples, each through boxes -> table -> U -> Wt -> MFMA
                 const Lvl lv = load_lvl(actz, part);

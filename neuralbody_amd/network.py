@@ -332,24 +332,49 @@ class Network(nn.Module):
         # logical layout [1,C,D,H,W] like spconv's .dense(); storage stays channels-last
         return FeatureVolumes([v.permute(3, 0, 1, 2)[None] for v in vols], vols.sparse)
 
+    SORT_MIN_POINTS = 4096  # below this a spatial sort of the points costs more than it saves
+
+    def _spatial_order(self, p, sp_input):
+        """Permutation that makes consecutive points spatial neighbours (index plumbing, no arithmetic of the path): the
+        'f16f6' decoder marches 64 consecutive points per workgroup over the union of the voxels they touch, so points in
+        ray-major or scan-line order (64 samples of one ray: metres apart) would fall back to one sample at a time.  Key =
+        4 cm block of the SMPL-space grid (row-major) x Morton position of the 1 cm voxel inside it; one device sort."""
+        R = sp_input["R"].reshape(3, 3).to(p)
+        Th = sp_input["Th"].reshape(-1)[:3].to(p)
+        bmin = sp_input["bounds"].reshape(-1, 3)[0].to(p)
+        q = torch.matmul(p - Th, R)  # latent_xyzc.py:43-46
+        vs = torch.tensor([self.voxel_size[2], self.voxel_size[1], self.voxel_size[0]], dtype=p.dtype, device=p.device)
+        v = torch.floor((q - bmin) / (2.0 * vs)).clamp_(0, 1023).to(torch.int64)  # level-1 voxel (x, y, z), 10 bits each
+        blk = ((v[:, 2] >> 2) << 16) | ((v[:, 1] >> 2) << 8) | (v[:, 0] >> 2)
+        x, y, z = v[:, 0] & 3, v[:, 1] & 3, v[:, 2] & 3
+        loc = ((z >> 1) << 5) | ((y >> 1) << 4) | ((x >> 1) << 3) | ((z & 1) << 2) | ((y & 1) << 1) | (x & 1)
+        return torch.argsort((blk << 6) | loc)
+
+    def _decode(self, wpts, viewdir, feature_volume, sp_input, density_only):
+        prec = self._point_precision()
+        scene = self.make_scene(feature_volume, sp_input, prec)
+        p = wpts.reshape(-1, 3).float().contiguous()
+        v = None if density_only else viewdir.reshape(-1, 3).float().contiguous()
+        lb = None if density_only else self.latent_bias(sp_input["latent_index"])
+        packed = self.packed_weights(prec)
+        if prec == "f16f6" and p.shape[0] >= self.SORT_MIN_POINTS:
+            order = self._spatial_order(p, sp_input)
+            out_s = ops.decode_points(scene, packed, lb, p[order].contiguous(), None if v is None else v[order].contiguous(),
+                                      density_only=density_only, precision=prec)
+            out = torch.empty_like(out_s)
+            out[order] = out_s
+            return out
+        return ops.decode_points(scene, packed, lb, p, v, density_only=density_only, precision=prec)
+
     def calculate_density(self, wpts, feature_volume, sp_input):
         if wpts.shape[0] != 1:
             raise NotImplementedError("batch size 1 only")
-        scene = self.make_scene(feature_volume, sp_input, self._point_precision())
-        p = wpts.reshape(-1, 3).float().contiguous()
-        out = ops.decode_points(scene, self.packed_weights(self._point_precision()), None, p, None, density_only=True,
-                                precision=self._point_precision())
-        return out.view(1, -1, 1)
+        return self._decode(wpts, None, feature_volume, sp_input, True).view(1, -1, 1)
 
     def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
         if wpts.shape[0] != 1:
             raise NotImplementedError("batch size 1 only")
-        scene = self.make_scene(feature_volume, sp_input, self._point_precision())
-        p = wpts.reshape(-1, 3).float().contiguous()
-        v = viewdir.reshape(-1, 3).float().contiguous()
-        lb = self.latent_bias(sp_input["latent_index"])
-        out = ops.decode_points(scene, self.packed_weights(self._point_precision()), lb, p, v, precision=self._point_precision())
-        return out.view(1, -1, 4)
+        return self._decode(wpts, viewdir, feature_volume, sp_input, False).view(1, -1, 4)
 
     def forward(self, sp_input, grid_coords, viewdir, light_pts):
         """Working equivalent of the reference's (broken, latent_xyzc.py:128-163) forward: `viewdir`

@@ -104,11 +104,11 @@ def test_foreign_dense_volumes_decode_like_the_encoders():
     assert H.same_bits(a, b)
 
 
-@pytest.mark.parametrize("kind", ["lattice", "lines", "scattered"])
+@pytest.mark.parametrize("kind", ["lattice", "lines", "clusters", "scattered"])
 def test_points_on_every_marching_tier_match_the_fp32_kernel(kind):
-    """64 points per workgroup whose voxel list (a) fits one pass (a 4 x 4 x 4 lattice of 3 mm pitch), (b) overflows it but fits
-    per 16 points (a 5 mm line of 64 points), (c) is scattered over the whole volume (single samples; some outside the volume):
-    raw and density against the exact-fp32 kernel."""
+    """64 points per workgroup whose voxel list (a) fits one pass (a 4 x 4 x 4 lattice of 3 mm pitch), (b) is up to 1024 voxels long
+    (a 5 mm line of 64 points: passes of 128), (c) is the union of four distant clusters of 16 points (groups of 16), (d) is
+    scattered over the whole volume (single samples; some outside the volume): raw and density against the exact-fp32 kernel."""
     from neuralbody_amd import ops
 
     r, sd, body, net, bd, rend = _small()
@@ -127,6 +127,10 @@ def test_points_on_every_marching_tier_match_the_fp32_kernel(kind):
         elif kind == "lines":
             line = torch.arange(64.0, device=DEV)[:, None] * torch.tensor([0.0, 0.0, 0.005], device=DEV)
             pts = (ctr[:8, None] - torch.tensor([0, 0, 0.1], device=DEV) + line[None]).reshape(-1, 3)
+        elif kind == "clusters":
+            lat = torch.stack(torch.meshgrid(torch.arange(4.0), torch.arange(4.0), torch.arange(1.0), indexing="ij"), -1).reshape(-1, 3).to(DEV) * 0.004
+            far = verts[torch.from_numpy(rs.choice(verts.shape[0], 96)).to(DEV)]  # 24 workgroups x 4 clusters, anywhere on the body
+            pts = (far[:, None] + lat[None]).reshape(-1, 3)
         else:
             lo, hi = torch.from_numpy(body["can_bounds"][0]).to(DEV), torch.from_numpy(body["can_bounds"][1]).to(DEV)
             pts = lo + (hi - lo) * torch.rand(64 * 9 + 13, 3, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1))

@@ -96,7 +96,8 @@ def test_decode_points_stages_against_oracle(precision):
     # public API paths
     raw_api = net.calculate_density_color(w.to(DEV), v.to(DEV), vols_dev, sp)
     assert raw_api.shape == (1, w.shape[1], 4)
-    assert torch.equal(raw_api[0], out)  # same points, same grouping: bit for bit
+    assert H.same_result(raw_api[0], out, precision, 2e-4)  # ('f16f6': the API sorts the points spatially first: other groups, and
+    # a six-bit quantisation step that falls differently moves a logit of |20| by ~1e-3)
     dens_api = net.calculate_density(w.to(DEV), vols_dev, sp)
     assert dens_api.shape == (1, w.shape[1], 1)
     H.assert_close(dens_api[0].cpu().numpy(), dens.numpy(), tol_raw, "calculate_density")
