@@ -20,7 +20,11 @@ Schemes (per layer):
              per (row, 32 K), activations bf6 e3m2 with a run-time E8M0 scale per (sample, 32 K) from the block's maximum;
              the remainder block reuses the head block's scale - 11
 
-Run:  python tools/experiments/precision_sweep.py [--wide]      (CPU, ~1 min)
+    fold     (fc_0 only, round 4) fc_0 folded into the volume: U_l = fc_0[:, level l] . V_l per voxel in fp32, stored as fp16 head +
+             fp16 remainder, interpolated with fp32 weights (the kernel's three fp16 products U_h.Wt_h + U_h.Wt_l + U_l.Wt_h
+             drop only the 2^-22 term U_l.Wt_l); fold_h: the head alone (what a single fp16 plane per voxel would give)
+
+Run:  python tools/experiments/precision_sweep.py [--wide | --quick | --levels | --fold]      (CPU, ~1 min)
 The same table measured on the HIP kernels is produced by tools/experiments/precision_gpu.py.
 """
 import argparse
@@ -161,12 +165,22 @@ def mm(W, X, scheme):
     raise ValueError(scheme)
 
 
-def decode(sd, feat, wpts, viewdir, latent_index, mix):
+def decode(sd, feat, wpts, viewdir, latent_index, mix, fold=None):
     """raw [N,4] from gathered features [N,352]; `mix` maps layer -> scheme.  Merged feature/latent layer as in
     nb_mlp_pack (fp64 product rounded to fp32, latent folded into the bias)."""
     w = {k: v[..., 0] if v.dim() == 3 else v for k, v in sd.items()}
     x = feat.T
-    if "fc_0_levels" in mix:  # per pyramid level (32 | 64 | 128 | 128 input channels) schemes for fc_0
+    if mix["fc_0"] in ("fold", "fold_h"):  # round 4: fc_0 . interp(V) = interp(fc_0 . V), the planes as fp16 pairs (or heads only)
+        acc, c0 = 0.0, 0
+        for vol in fold["vols"]:
+            nch = vol.shape[1]
+            u = torch.einsum("fc,bcdhw->bfdhw", w["fc_0.weight"][:, c0:c0 + nch], vol)
+            uh = _f16(u)
+            uq = uh + _f16(u - uh) if mix["fc_0"] == "fold" else uh
+            acc = acc + torch.nn.functional.grid_sample(uq, fold["g"], padding_mode="zeros", align_corners=True).reshape(256, -1)
+            c0 += nch
+        h = torch.relu(acc + w["fc_0.bias"][:, None])
+    elif "fc_0_levels" in mix:  # per pyramid level (32 | 64 | 128 | 128 input channels) schemes for fc_0
         acc, c0 = 0.0, 0
         for nch, sch in zip((32, 64, 128, 128), mix["fc_0_levels"]):
             acc = acc + mm(w["fc_0.weight"][:, c0:c0 + nch].contiguous(), x[c0:c0 + nch].contiguous(), sch)
@@ -215,12 +229,12 @@ def scene_inputs(name, widen=None):
         g = orc.get_grid_coords(pp, torch.from_numpy(batch["bounds"]), out_sh, (0.005,) * 3)[:, None, None]
         feat = orc.interpolate_features(g, vols)[0].T.contiguous()
     return dict(r=r, sdt=sdt, feat=feat, w=w, v=v, z=z.reshape(-1, ns), rd=ray_d.reshape(-1, 3),
-                li=int(batch["latent_index"][0]))
+                li=int(batch["latent_index"][0]), fold=dict(vols=vols, g=g))
 
 
 def rgb_of(s, mix):
     with torch.no_grad():
-        raw = decode(s["sdt"], s["feat"], s["w"], s["v"], s["li"], mix)
+        raw = decode(s["sdt"], s["feat"], s["w"], s["v"], s["li"], mix, s["fold"])
         rgb, *_ = orc.raw2outputs(raw.reshape(-1, s["r"]["n_samples"], 4), s["z"], s["rd"], s["r"]["white_bkgd"])
     return rgb.numpy()
 
@@ -252,6 +266,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true", help="only the candidate shipping mixes")
     ap.add_argument("--levels", action="store_true", help="fc_0 sensitivity per pyramid level (one or both cross terms dropped)")
+    ap.add_argument("--fold", action="store_true", help="round 4: fc_0 folded into the volume (fp16 head + remainder planes; heads only)")
     a = ap.parse_args()
     torch.set_num_threads(8)
     names = list(scenes.SCENES)
@@ -272,6 +287,22 @@ def main():
 
     print("| mix | " + " | ".join(data) + " | worst |")
     print("|---|" + "---|" * (len(data) + 1))
+    if a.fold:
+        for f0, tag in (("f16c6", "round 3: gather + fc_0 as f16f6"), ("fold", "SHIPPED round 4: fc_0 folded, fp16 head + remainder planes"),
+                        ("fold_h", "fc_0 folded, fp16 heads only"), ("f32", "fc_0 exact")):
+            mix = {k: "f16c6" for k in LAYERS}
+            mix["fold"] = True
+            mix["fc_0"] = f0
+            report("%s; fc_1, fc_2, folded colour head f16f6" % tag, mix)
+        mix = {k: "f32" for k in LAYERS}
+        mix["fc_0"] = "fold"
+        report("fc_0 folded (pairs), everything else exact fp32", mix)
+        mix["fc_0"] = "fold_h"
+        report("fc_0 folded (heads only), everything else exact fp32", mix)
+        if a.out:
+            with open(a.out, "w") as f:
+                f.write("\n".join(lines) + "\n")
+        return
     if a.levels:
         for lv in range(4):
             for sch in ("f16x1", "f16x2w", "f16x2x"):
