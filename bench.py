@@ -150,6 +150,18 @@ def parity_linf(sd, net, rend, batch, n_samples, n_check=4096):
     return r["linf"], r["n"], r["n_ill"]
 
 
+def _port_vs_reference():
+    """The port timed beside the reference ITSELF on the build container's cores (`--mode cpu-reference`, where /root/reference
+    exists): the committed record, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_cpu_baseline_reference.json")) as f:
+            r = json.load(f)
+        return {"port_over_reference": r["port_over_reference"], "rgb_linf": r["rgb_linf_port_vs_reference_first_chunk"],
+                "source": "profiles/r04_cpu_baseline_reference.json (bench.py --mode cpu-reference, %d threads)" % r["cpu_baseline"]["cores"]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(sd, bd, vols, n_samples, budget_s=12.0, max_rays=8192):
     """The oracle (CPU restatement of the reference, chunked by 2048 rays like if_clight_renderer.py:107)
     marching a bounded sample of the bench rays through the same feature volumes.  torch's CPU thread
@@ -187,11 +199,74 @@ def cpu_baseline(sd, bd, vols, n_samples, budget_s=12.0, max_rays=8192):
         if t_total > budget_s:
             break
     return {"value": done * n_samples / t_total, "unit": "ray-samples/s", "cores": best, "host_cores": ncpu,
-            "kind": "port", "rays_per_s": done / t_total,
+            "kind": "port", "rays_per_s": done / t_total, "port_vs_reference": _port_vs_reference(),
             "thread_probe_s_per_256_rays": {str(k): round(v, 3) for k, v in probe.items()},
             "sample": "%d of the bench rays x %d samples, march only (K2-K8) on precomputed feature volumes, "
                       "%.1f s of oracle/neuralbody_oracle.py (torch CPU %s, %d threads)"
                       % (done, n_samples, t_total, torch.__version__, best)}
+
+
+def cpu_reference_baseline(args, budget_s=15.0, max_rays=8192):
+    """`--mode cpu-reference`: the UNMODIFIED reference (lib/networks/renderer/if_clight_renderer.py:62 get_pixel_value in chunks
+    of 2048 rays, :107) timed on the host's cores through oracle/ref_harness.py, beside oracle/neuralbody_oracle.py on the same
+    rays and the same feature volumes.  Runs WITHOUT a GPU and only where /root/reference exists (the build container): the
+    tree cannot travel to the GPU box, where `cpu_baseline.kind` stays "port".  This run pins the port's speed to the
+    reference's on the same host: the JSON it prints is committed under profiles/."""
+    from neuralbody_amd import synthetic as syn
+    from oracle import neuralbody_oracle as orc
+    from oracle import ref_harness as rh
+
+    if not rh.available():
+        raise SystemExit("--mode cpu-reference needs the reference tree at %s" % rh.REF_ROOT)
+    H = W = args.size
+    S = args.samples
+    sd = syn.make_weights(0, num_train_frame=230)
+    body = syn.make_body(seed=0)
+    K, R, T = syn.full_coverage_camera(body, H, W)
+    ro, rd, near, far, mask = syn.host_image_rays(H, W, K, R, T, body["can_bounds"])
+    sel = np.linspace(0, ro.shape[0] - 1, max_rays).astype(np.int64)
+    batch = syn.make_batch(body, ro[sel], rd[sel], near[sel], far[sel], mask)
+    ns = rh.load()
+    ns.cfg.N_samples, ns.cfg.perturb = S, 0
+    net = rh.make_reference_network(sd, train_mode=True)
+    rend = rh.make_reference_renderer(net)
+    bt = rh.torch_batch(batch)
+    sdt = orc.tensor_state_dict(sd)
+    nt = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(nt)
+    with torch.no_grad():
+        sp = rend.prepare_sp_input(bt)
+        vols = net.encode_sparse_voxels(sp)  # once, untimed: the march is what is measured
+
+        def ref_chunk(i):
+            return rend.get_pixel_value(bt["ray_o"][:, i:i + 2048], bt["ray_d"][:, i:i + 2048], bt["near"][:, i:i + 2048],
+                                        bt["far"][:, i:i + 2048], vols, sp, bt)["rgb_map"]
+
+        def port_chunk(i):
+            bb = dict(bt)
+            for k in ("ray_o", "ray_d", "near", "far"):
+                bb[k] = bt[k][:, i:i + 2048]
+            return orc.render(dict(sdt), bb, n_samples=S, training=True, feature_volume=vols)["rgb_map"]
+
+        out = {}
+        for name, fn in (("reference", ref_chunk), ("port", port_chunk)):
+            fn(0)[:, :1]  # warm-up
+            done, t_total, first = 0, 0.0, None
+            for i in range(0, max_rays, 2048):
+                t0 = time.perf_counter()
+                r = fn(i)
+                t_total += time.perf_counter() - t0
+                first = r if first is None else first
+                done += r.shape[1]
+                if t_total > budget_s:
+                    break
+            out[name] = (done * S / t_total, done, t_total, first)
+    diff = float((out["reference"][3].double() - out["port"][3].double()).abs().max())
+    v, done, t_total, _ = out["reference"]
+    return {"cpu_baseline": {"value": v, "unit": "ray-samples/s", "cores": nt, "host_cores": os.cpu_count(), "kind": "reference",
+                             "sample": "%d of the %dx%d bench rays x %d samples, march only on precomputed feature volumes, %.1f s of the "
+                                       "reference's Renderer.get_pixel_value (torch CPU %s, %d threads)" % (done, H, W, S, t_total, torch.__version__, nt)},
+            "port_value": out["port"][0], "port_over_reference": out["port"][0] / v, "rgb_linf_port_vs_reference_first_chunk": diff}
 
 
 def train_bench(args, dev):
@@ -231,6 +306,14 @@ def train_bench(args, dev):
     return ({"metric": "train_step_ms", "value": dt * 1e3, "unit": "ms", "higher_is_better": False, "n_gpus": 1,
                       "steps": args.steps, "warmup": args.warmup, "rays_per_step": 1024, "samples_per_ray": args.samples,
                       "ray_samples_per_sec": 1024 * args.samples / dt, "final_loss": float(loss.detach()),
+                      # decoder forward + the two backward products = 3 x the forward flops, on the exact-fp32 MFMA kernels; the
+                      # step is ~600 launches of 5-30 us and the encoder, so this fraction states how far a 1024-ray step is from
+                      # being a matrix-pipe problem at all, not a kernel quality
+                      "roofline": {"bound": "mfma", "achieved": 3 * FLOP_PER_SAMPLE * 1024 * args.samples / dt / 1e12,
+                                   "peak": PRECISION_INFO["f32"][3], "unit": "TFLOP/s",
+                                   "frac": 3 * FLOP_PER_SAMPLE * 1024 * args.samples / dt / 1e12 / PRECISION_INFO["f32"][3],
+                                   "traffic": None, "flop_per_step": 3 * FLOP_PER_SAMPLE * 1024 * args.samples,
+                                   "note": "whole step (host clock), decoder algebra only; launch- and encoder-bound"},
                       "config": {"workload": "synthetic training step: 1024 random rays, forward + backward (decoder GEMMs and encoder "
                                              "kernels all in libnb_hip.so, no vendor BLAS) + clip_grad_value_(40) + Adam"}})
 
@@ -280,7 +363,7 @@ def extras(args, dev):
     a.steps, a.warmup = 6, 2
     tr = train_bench(a, dev)
     ex = {"turntable_ms_per_view": tt["ms_per_view"], "turntable_rays_per_sec": tt["rays_per_sec"],
-          "train_step_ms": tr["value"], "train_ray_samples_per_sec": tr["ray_samples_per_sec"],
+          "train_step_ms": tr["value"], "train_ray_samples_per_sec": tr["ray_samples_per_sec"], "train_roofline": tr["roofline"],
           "note": "8 spiral views (512x512x64, each view: nb_raygen + encoder + march + nb_image_assemble) / 6 training steps "
                   "(1024 random rays x 64 jittered samples, forward + backward + clip + Adam); *_ms_per_view / *_march_ms: the timed "
                   "view of this run rendered with the other arithmetics (3 steps each), roofline fraction of each against ITS peak"}
@@ -414,12 +497,15 @@ def main():
                          "strong: one view per step, its rays split over the GPUs")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational turntable / train-step legs of the JSON line")
     ap.add_argument("--reuse-volumes", action="store_true", help="turntable mode: encode the frame once for all views")
-    ap.add_argument("--mode", default="render", choices=["render", "train", "turntable"])
+    ap.add_argument("--mode", default="render", choices=["render", "train", "turntable", "cpu-reference"])
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.mode == "cpu-reference":  # the one mode without a GPU: times the reference itself where its tree exists
+        print(json.dumps(cpu_reference_baseline(args)))
+        return
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
                          % (args.gpus, world))
