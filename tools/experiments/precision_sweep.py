@@ -139,7 +139,7 @@ def mm(W, X, scheme):
         return _bf16(W) @ _bf16(X)
     if scheme == "f16x1":
         return _f16(W) @ _f16(X)
-    if scheme in ("bf16x3", "f16x3", "f16x2w", "f16x2x", "f16c8", "f16c8s", "f16c8b", "f16c6", "f16c6w", "f16c6x"):
+    if scheme in ("bf16x3", "f16x3", "f16x2w", "f16x2x", "f16c8", "f16c8s", "f16c8b", "f16c6", "f16c6w", "f16c6x", "f16c6-wl", "f16c6-xl"):
         r = _bf16 if scheme == "bf16x3" else _f16
         Wh, Xh = r(W), r(X)
         Wl, Xl = r(W - Wh), r(X - Xh)
@@ -154,6 +154,10 @@ def mm(W, X, scheme):
         if scheme == "f16c6":
             q_xh, q_xl = _bf6_acts(Xh, Xl)
             return Wh @ Xh + _fp6_weights(Wh) @ q_xl + _fp6_weights(Wl) @ q_xh
+        if scheme == "f16c6-wl":  # the W_l cross term dropped (weights rounded to fp16)
+            return Wh @ Xh + _fp6_weights(Wh) @ _bf6_acts(Xh, Xl)[1]
+        if scheme == "f16c6-xl":  # the X_l cross term dropped (activations rounded to fp16)
+            return Wh @ Xh + _fp6_weights(Wl) @ _bf6_acts(Xh, Xl)[0]
         if scheme == "f16c6w":  # only the weights in six bits (activations bf8 as shipped)
             return Wh @ Xh + _fp6_weights(Wh) @ _bf8_static(Xl, 12) + _fp6_weights(Wl) @ _bf8_static(Xh, 0)
         if scheme == "f16c6x":  # only the activations in six bits
@@ -266,6 +270,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--quick", action="store_true", help="only the candidate shipping mixes")
     ap.add_argument("--levels", action="store_true", help="fc_0 sensitivity per pyramid level (one or both cross terms dropped)")
+    ap.add_argument("--drop", action="store_true", help="round 4: one cross term of one layer dropped")
     ap.add_argument("--fold", action="store_true", help="round 4: fc_0 folded into the volume (fp16 head + remainder planes; heads only)")
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -299,6 +304,19 @@ def main():
         report("fc_0 folded (pairs), everything else exact fp32", mix)
         mix["fc_0"] = "fold_h"
         report("fc_0 folded (heads only), everything else exact fp32", mix)
+        if a.out:
+            with open(a.out, "w") as f:
+                f.write("\n".join(lines) + "\n")
+        return
+    if a.drop:  # round 4: which cross term of which layer could go (each is 16 of a layer's 96 MFMAs per wave and step)?
+        for layer in ("fc_1", "fc_2", "view_fc", "view_pe"):
+            for sc in ("f16c6-wl", "f16c6-xl", "f16x1"):
+                mix = {k: "f16c6" for k in LAYERS}
+                mix["fold"] = True
+                mix["fc_0"] = "fold"
+                mix["view_pe"] = "f16c6"
+                mix[layer] = sc
+                report("shipped round 4 except %s = %s" % (layer, sc), mix)
         if a.out:
             with open(a.out, "w") as f:
                 f.write("\n".join(lines) + "\n")
