@@ -495,6 +495,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one view per GPU per step (views shard with no collective but the tile all-gather); "
                          "strong: one view per step, its rays split over the GPUs")
+    ap.add_argument("--no-overlap", action="store_true", help="encode and march strictly one after the other on one stream")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational turntable / train-step legs of the JSON line")
     ap.add_argument("--reuse-volumes", action="store_true", help="turntable mode: encode the frame once for all views")
     ap.add_argument("--mode", default="render", choices=["render", "train", "turntable", "cpu-reference"])
@@ -540,11 +541,20 @@ def main():
 
     gather_events = []
 
+    overlap = [not args.no_overlap]
+    ticket = [None]
+
     def step(i):
         b = poses[(i + rank) % len(poses)]
+        cur = ticket[0]
+        ticket[0] = None
+        if overlap[0]:
+            # step i + 1's encoder is enqueued on a second HIP stream before this step's march (Renderer.prefetch): every step
+            # still encodes one frame and marches one view, the encoder's ~90 small launches run in the march's shadow
+            ticket[0] = rend.prefetch(poses[(i + 1 + rank) % len(poses)])
         if args.scaling == "strong":
-            return render_sharded(rend, b, dist.group.WORLD if dist is not None else None)["rgb_map"][0]
-        out = rend.render(b)
+            return render_sharded(rend, b, dist.group.WORLD if dist is not None else None, prefetched=cur)["rgb_map"][0]
+        out = rend.render(b, prefetched=cur)
         if dist is not None:
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             g0.record()
@@ -577,6 +587,19 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         events, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
+        # the same steps strictly serial on one stream (informational: what a single render() call costs)
+        serial_ms = None
+        if overlap[0] and dist is None:
+            overlap[0] = False
+            step(0)  # takes the last prefetched frame
+            step(1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(6):
+                step(2 + i)
+            torch.cuda.synchronize()
+            serial_ms = (time.perf_counter() - t1) / 6 * 1e3
+            overlap[0] = True
     march_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
     step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
@@ -613,8 +636,12 @@ def main():
         "data": "synthetic",
         "rays_per_sec": total_rays / elapsed,
         "config": {"workload": "synthetic 6890-vertex SMPL scene, %dx%d full-coverage view, %d samples/ray, "
-                               "Renderer.render = encoder + fused march, %s; the timed region cycles through %d camera poses" % (
-                                   H, W, S, "one view per GPU per step" if args.scaling == "weak" else "one view per step, rays split over the GPUs", len(poses)),
+                               "Renderer.render = encoder + fused march, %s; the timed region cycles through %d camera poses; %s" % (
+                                   H, W, S, "one view per GPU per step" if args.scaling == "weak" else "one view per step, rays split over the GPUs", len(poses),
+                                   "every step encodes one frame and marches one view, the encoder of step i + 1 enqueued on a second HIP stream "
+                                   "before the march of step i (Renderer.prefetch; serial_ms_per_step: the same steps on one stream)"
+                                   if overlap[0] else "encoder and march one after the other on one stream"),
+                   "encoder_overlap": bool(overlap[0]),
                    "rays_per_view": n_rays, "out_sh": [int(s) for s in body["out_sh"]],
                    "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), trilinear gather on the VALU",
                                   "f16f6": "fc_0 folded into the volume (U = fc_0 . V per active voxel, fp16 head + remainder; the "
@@ -636,6 +663,8 @@ def main():
                              "colour head), so executed_frac is the matrix-pipe occupancy; compulsory HBM traffic is ~150 MB/launch "
                              "(<0.1%% of the launch time at 8 TB/s)" % (rays_per_launch * S, exec_flop)},
     }
+    if serial_ms is not None:
+        result["serial_ms_per_step"] = serial_ms
     if per_rank is not None:
         result["per_rank"] = per_rank
     if net.precision == "auto":

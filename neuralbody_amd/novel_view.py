@@ -133,6 +133,8 @@ class NovelViewRenderer:
         running-statistics side effect of the skipped passes is lost — off by default."""
         self.renderer, self.H, self.W, self.device = renderer, int(H), int(W), torch.device(device)
         self.reuse_volumes = bool(reuse_volumes)
+        # render_views: the next view's encoder is enqueued on a second HIP stream before this view's march (Renderer.prefetch)
+        self.prefetch_encoder = self.device.type == "cuda" and hasattr(renderer, "prefetch")
         self._vol_key, self._vols = None, None
 
     def _frame_volumes(self, batch):
@@ -197,13 +199,18 @@ class NovelViewRenderer:
         it = iter(views)
         cur = next(it, None)
         launched = None if cur is None else self._launch_rays(cur[0], cur[1], cur[2])
+        ticket = None
         while cur is not None:
             batch = self._finish_batch(launched, cur[3])
             nxt = next(it, None)
+            cur_ticket, ticket = ticket, None
             if nxt is not None:
                 launched = self._launch_rays(nxt[0], nxt[1], nxt[2])
+                if self.prefetch_encoder and not self.reuse_volumes:
+                    with torch.no_grad():
+                        ticket = self.renderer.prefetch(nxt[3])  # view k + 1's encoder on a second stream, beside view k's march
             with torch.no_grad():  # the render runs without autograd; the consumer's loop body keeps ITS grad mode (yielding from
-                out = self._render_batch(batch, bgr, scale, None)  # inside the block would leak no_grad into it: ADVICE r03)
+                out = self._render_batch(batch, bgr, scale, None, cur_ticket)  # inside the block would leak no_grad into it)
             yield out
             cur = nxt
 
@@ -215,12 +222,13 @@ class NovelViewRenderer:
     def _render_view(self, K, RT, can_bounds, frame, bgr, scale, t_rand):
         return self._render_batch(self.view_batch(K, RT, can_bounds, frame), bgr, scale, t_rand)
 
-    def _render_batch(self, batch, bgr, scale, t_rand):
+    def _render_batch(self, batch, bgr, scale, t_rand, prefetched=None):
         n = batch["ray_o"].shape[1]
         if n == 0:
             out = {"rgb_map": torch.zeros((1, 0, 3), device=self.device), "depth_map": torch.zeros((1, 0), device=self.device)}
         else:
-            out = self.renderer.render(batch, t_rand=t_rand, feature_volume=self._frame_volumes(batch))
+            extra = {} if prefetched is None else {"prefetched": prefetched}
+            out = self.renderer.render(batch, t_rand=t_rand, feature_volume=self._frame_volumes(batch), **extra)
         img, depth = ops.image_assemble(batch["mask_at_box"][0], out["rgb_map"][0].contiguous(), out["depth_map"][0].contiguous(),
                                         white_bkgd=self.renderer.cfg.white_bkgd, bgr=bgr, scale=scale)
         return {"img": img.view(self.H, self.W, 3), "depth": depth.view(self.H, self.W),

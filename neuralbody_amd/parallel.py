@@ -44,14 +44,16 @@ def all_gather_tiles(tile, group=None, sizes=None):
     return torch.cat([out[r * m:r * m + sizes[r]] for r in range(world)], 0)
 
 
-def render_sharded(renderer, batch, group=None, keys=("rgb_map",)):
+def render_sharded(renderer, batch, group=None, keys=("rgb_map",), prefetched=None):
     """Render one batch with its rays split across the ranks of `group`; every rank encodes the (cheap,
-    deterministic) feature volume locally, marches its ray range and receives the full maps."""
+    deterministic) feature volume locally (or takes it from `prefetched`, the ticket of renderer.prefetch(batch)), marches
+    its ray range and receives the full maps."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = batch["ray_o"].shape[1]
     b, e = shard_range(n, rank, world)
-    part = renderer.render(batch, ray_range=(b, e))
+    extra = {} if prefetched is None else {"prefetched": prefetched}  # renderers with the reference's signature stay usable
+    part = renderer.render(batch, ray_range=(b, e), **extra)
     if not dist.is_initialized():
         return {k: part[k] for k in keys}
     sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]

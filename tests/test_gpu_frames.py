@@ -96,3 +96,66 @@ def test_reuse_volumes_follows_the_frame():
             del frame, a, a2, b
     finally:
         net.encode_sparse_voxels = enc
+
+
+@pytest.mark.parametrize("precision", ["f32", H.DEFAULT_PRECISION])
+def test_prefetched_encoder_renders_the_same_frames(precision):
+    """Renderer.prefetch: frame f + 1 encoded on a second stream beside frame f's march gives the frames of the serial loop
+    (fresh batches per frame, dropped right after their render); the ticket of another frame is ignored; a frame tensor
+    modified in place after the prefetch is encoded again."""
+    from neuralbody_amd.renderer import RenderConfig, Renderer
+
+    sd = syn.make_weights(3, num_train_frame=7)
+    net = H.make_network(sd, DEV, True, precision)
+    rend = Renderer(net, RenderConfig(N_samples=64, perturb=0.0, H=16, W=16))
+    frames = [_frame(f)[1] for f in range(5)]
+    with torch.no_grad():
+        serial = [rend.render(H.device_batch(b, DEV))["rgb_map"].clone() for b in frames]
+        calls = {"n": 0}
+        enc = net.encode_sparse_voxels
+
+        def counting(sp, save=None):
+            calls["n"] += 1
+            return enc(sp, save)
+
+        net.encode_sparse_voxels = counting
+        try:
+            nxt = H.device_batch(frames[0], DEV)
+            piped = []
+            ticket = None
+            for f in range(5):
+                cur, nxt = nxt, (H.device_batch(frames[f + 1], DEV) if f + 1 < 5 else None)
+                cur_ticket, ticket = ticket, (rend.prefetch(nxt) if nxt is not None else None)
+                piped.append(rend.render(cur, prefetched=cur_ticket)["rgb_map"].clone())
+                del cur, cur_ticket
+            assert calls["n"] == 5, calls  # frame 0 inside its render(), 1..4 ahead
+            # a ticket of another frame: ignored, the rendered frame is encoded in place
+            a, b = H.device_batch(frames[1], DEV), H.device_batch(frames[2], DEV)
+            ta = rend.prefetch(a)
+            other = rend.render(b, prefetched=ta)["rgb_map"].clone()
+            assert calls["n"] == 7
+            late = rend.render(a, prefetched=ta)["rgb_map"].clone()  # its own frame, two renders later
+            assert calls["n"] == 7
+            # in-place change of a frame tensor after the prefetch: the volumes are stale, render() encodes again
+            c = H.device_batch(frames[3], DEV)
+            tc = rend.prefetch(c)
+            c["coord"].copy_(H.device_batch(frames[4], DEV)["coord"])
+            for k in ("out_sh", "bounds", "R", "Th"):
+                c[k].copy_(H.device_batch(frames[4], DEV)[k])
+            c["latent_index"].copy_(H.device_batch(frames[4], DEV)["latent_index"])
+            for k in ("ray_o", "ray_d", "near", "far", "mask_at_box"):
+                c[k] = H.device_batch(frames[4], DEV)[k]
+            changed = rend.render(c, prefetched=tc)["rgb_map"].clone()
+            assert calls["n"] == 9
+        finally:
+            net.encode_sparse_voxels = enc
+    torch.cuda.synchronize()
+    def same(x, y):  # the encoder's batch statistics are sums of atomics: equal to rounding, run to run
+        return x.shape == y.shape and float((x - y).abs().max()) <= 2e-6
+
+    for f in range(5):
+        assert same(piped[f], serial[f]), f
+        assert f == 0 or not same(serial[f], serial[f - 1]), "frames must differ for the test to see a mix-up"
+    assert same(other, serial[2]) and same(late, serial[1]) and same(changed, serial[4])
+    with pytest.raises(RuntimeError):
+        rend.prefetch(H.device_batch(frames[0], DEV))  # autograd on: the training step encodes inside its graph
