@@ -22,6 +22,7 @@
 //   BatchNorm1d(eps=1e-3) over ACTIVE rows, then ReLU;  .dense() -> zeros at inactive sites
 //   duplicate vertex coordinates: the LAST vertex wins; BN counts unique voxels
 #include "nb_scan.h"
+#include "nb_scan_dev.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -45,28 +46,56 @@ __global__ void vox_scatter_kernel(const int *__restrict__ coord, int n, Dims g,
     atomicMax(&grid[((long long)d * g.h + h) * g.w + w], v);  // last vertex wins
 }
 
-__global__ void vox_flag_kernel(const int *__restrict__ coord, int n, Dims g, const int *__restrict__ grid,
-                                int *__restrict__ flags) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    const int d = coord[v * 3], h = coord[v * 3 + 1], w = coord[v * 3 + 2];
-    int f = 0;
-    if ((unsigned)d < (unsigned)g.d && (unsigned)h < (unsigned)g.h && (unsigned)w < (unsigned)g.w)
-        f = grid[((long long)d * g.h + h) * g.w + w] == v;
-    flags[v] = f;
+// Winners (the vertex a voxel kept) flagged and counted per 1024-vertex tile, then numbered in vertex order: the exclusive scan
+// folded into the kernels on either side of it (each block of the second sums the tile counts in front of it itself).  Two
+// kernels because the numbering overwrites the grid cells the flags are read from.
+__global__ __launch_bounds__(nbscan::BLOCK) void vox_flag_count_kernel(const int *__restrict__ coord, int n, Dims g,
+                                                                       const int *__restrict__ grid, int *__restrict__ flags,
+                                                                       int *__restrict__ block_sums) {
+    const int v0 = blockIdx.x * nbscan::TILE + threadIdx.x * nbscan::ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i) {
+        const int v = v0 + i;
+        if (v >= n) break;
+        const int d = coord[v * 3], h = coord[v * 3 + 1], w = coord[v * 3 + 2];
+        int f = 0;
+        if ((unsigned)d < (unsigned)g.d && (unsigned)h < (unsigned)g.h && (unsigned)w < (unsigned)g.w)
+            f = grid[((long long)d * g.h + h) * g.w + w] == v;
+        flags[v] = f;
+        s += f;
+    }
+    int tot;
+    nbscan::block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void vox_assign_kernel(const int *__restrict__ coord, int n, Dims g, const int *__restrict__ flags,
-                                  const int *__restrict__ pos, int *__restrict__ grid, int *__restrict__ rows_vert,
-                                  int *__restrict__ rows_lin) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || !flags[v]) return;
-    const int d = coord[v * 3], h = coord[v * 3 + 1], w = coord[v * 3 + 2];
-    const int lin = (d * g.h + h) * g.w + w;
-    const int r = pos[v];
-    rows_vert[r] = v;
-    rows_lin[r] = lin;
-    grid[lin] = r;
+__global__ __launch_bounds__(nbscan::BLOCK) void vox_number_kernel(const int *__restrict__ coord, int n, Dims g,
+                                                                   const int *__restrict__ flags, const int *__restrict__ block_sums,
+                                                                   int *__restrict__ grid, int *__restrict__ rows_vert,
+                                                                   int *__restrict__ rows_lin, int *__restrict__ n_rows) {
+    const int before = nbscan::blocks_before(block_sums, blockIdx.x);
+    const int v0 = blockIdx.x * nbscan::TILE + threadIdx.x * nbscan::ITEMS;
+    int f[nbscan::ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i) {
+        f[i] = v0 + i < n ? flags[v0 + i] : 0;
+        s += f[i];
+    }
+    int tot;
+    int r = nbscan::block_excl_scan(s, &tot) + before;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i) {
+        if (!f[i]) continue;
+        const int v = v0 + i;
+        const int d = coord[v * 3], h = coord[v * 3 + 1], w = coord[v * 3 + 2];
+        const int lin = (d * g.h + h) * g.w + w;
+        rows_vert[r] = v;
+        rows_lin[r] = lin;
+        grid[lin] = r;
+        ++r;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_rows = before + tot;
 }
 
 // ------------------------------------------------------------------ strided-conv output index set
@@ -85,22 +114,41 @@ __global__ void down_mark_kernel(const int *__restrict__ in_lin, const int *__re
                     out_grid[((long long)oz[a] * go.h + oy[b]) * go.w + ox[c]] = 0;  // mark (any value >= 0)
 }
 
-__global__ void grid_flag_kernel(const int *__restrict__ grid, long long n, int *__restrict__ flags) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) flags[i] = grid[i] >= 0;
+// Marked cells counted per 1024-cell tile, then numbered in linear order (row id into the cell, the cell into out_lin, the count
+// clamped to the capacity): the scan folded into its neighbours as above; a cell is read and rewritten by one thread only.
+__global__ __launch_bounds__(nbscan::BLOCK) void grid_count_kernel(const int *__restrict__ grid, long long n,
+                                                                   int *__restrict__ block_sums) {
+    const long long i0 = (long long)blockIdx.x * nbscan::TILE + threadIdx.x * nbscan::ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i)
+        if (i0 + i < n) s += grid[i0 + i] >= 0;
+    int tot;
+    nbscan::block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
-__global__ void grid_assign_kernel(int *__restrict__ grid, long long n, const int *__restrict__ pos, int cap,
-                                   int *__restrict__ out_lin) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || grid[i] < 0) return;
-    const int r = pos[i];
-    grid[i] = r < cap ? r : -1;
-    if (r < cap) out_lin[r] = (int)i;
-}
-
-__global__ void clamp_count_kernel(int *n, int cap) {
-    if (*n > cap) *n = cap;
+__global__ __launch_bounds__(nbscan::BLOCK) void grid_number_kernel(int *__restrict__ grid, long long n,
+                                                                    const int *__restrict__ block_sums, int cap,
+                                                                    int *__restrict__ out_lin, int *__restrict__ n_out) {
+    const int before = nbscan::blocks_before(block_sums, blockIdx.x);
+    const long long i0 = (long long)blockIdx.x * nbscan::TILE + threadIdx.x * nbscan::ITEMS;
+    int f[nbscan::ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i) {
+        f[i] = i0 + i < n ? grid[i0 + i] >= 0 : 0;
+        s += f[i];
+    }
+    int tot;
+    int r = nbscan::block_excl_scan(s, &tot) + before;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i) {
+        if (!f[i]) continue;
+        grid[i0 + i] = r < cap ? r : -1;
+        if (r < cap) out_lin[r] = (int)(i0 + i);
+        ++r;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = min(before + tot, cap);
 }
 
 // ------------------------------------------------------------------ sparse 3x3x3 convolution
@@ -858,11 +906,11 @@ int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3],
     }
     int *flags, *pos, *bs;
     nb_scan_carve(scratch, n_verts, &flags, &pos, &bs);
-    const dim3 grd(nb_ceil_div(n_verts, 256)), blk(256);
-    hipLaunchKernelGGL(vox_scatter_kernel, grd, blk, 0, st, coord, n_verts, g, grid);
-    hipLaunchKernelGGL(vox_flag_kernel, grd, blk, 0, st, coord, n_verts, g, grid, flags);
-    if (int rc = nb_exclusive_scan(flags, pos, n_rows, n_verts, bs, st)) return rc;
-    hipLaunchKernelGGL(vox_assign_kernel, grd, blk, 0, st, coord, n_verts, g, flags, pos, grid, rows_vert, rows_lin);
+    (void)pos;
+    const dim3 tiles((unsigned)nb_scan_blocks(n_verts)), blk(nbscan::BLOCK);
+    hipLaunchKernelGGL(vox_scatter_kernel, dim3(nb_ceil_div(n_verts, 256)), dim3(256), 0, st, coord, n_verts, g, grid);
+    hipLaunchKernelGGL(vox_flag_count_kernel, tiles, blk, 0, st, coord, n_verts, g, grid, flags, bs);
+    hipLaunchKernelGGL(vox_number_kernel, tiles, blk, 0, st, coord, n_verts, g, flags, bs, grid, rows_vert, rows_lin, n_rows);
     NB_CHECK_LAUNCH("nb_enc_voxelize");
     return NB_OK;
 }
@@ -885,11 +933,10 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
     if (n_in_max > 0)
         hipLaunchKernelGGL(down_mark_kernel, dim3(nb_ceil_div(n_in_max, 256)), dim3(256), 0, st, in_lin, n_in, gi, go,
                            out_grid);
-    hipLaunchKernelGGL(grid_flag_kernel, dim3(nb_ceil_div(nvox, 256)), dim3(256), 0, st, out_grid, nvox, flags);
-    if (int rc = nb_exclusive_scan(flags, pos, n_out, nvox, bs, st)) return rc;
-    hipLaunchKernelGGL(grid_assign_kernel, dim3(nb_ceil_div(nvox, 256)), dim3(256), 0, st, out_grid, nvox, pos,
-                       n_out_max, out_lin);
-    hipLaunchKernelGGL(clamp_count_kernel, dim3(1), dim3(1), 0, st, n_out, n_out_max);
+    (void)flags, (void)pos;
+    const dim3 tiles((unsigned)nb_scan_blocks(nvox)), blk(nbscan::BLOCK);
+    hipLaunchKernelGGL(grid_count_kernel, tiles, blk, 0, st, out_grid, nvox, bs);
+    hipLaunchKernelGGL(grid_number_kernel, tiles, blk, 0, st, out_grid, nvox, bs, n_out_max, out_lin, n_out);
     NB_CHECK_LAUNCH("nb_enc_downsample_index");
     return NB_OK;
 }

@@ -1,41 +1,16 @@
-// Device-wide exclusive scan of int32 flags (three small kernels), used for deterministic
+// Device-wide exclusive scan of int32 flags (two small kernels, three beyond 4 M elements), used for deterministic
 // stream compaction in the encoder (active-set numbering) and in ray generation
 // (mask_at_box compaction, lib/utils/render_utils.py:128-132).
 #include "nb_scan.h"
 
+#include "nb_scan_dev.h"
+
 namespace {
 
-constexpr int SCAN_BLOCK = 256;
-constexpr int SCAN_ITEMS = 4;
-constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;  // 1024 elements per block
-
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
-
-// inclusive scan of one value per thread across a 256-thread block; returns the exclusive prefix
-// of the thread and the block total through `total`
-__device__ __forceinline__ int block_excl_scan(int v, int *total) {
-    __shared__ int wsum[SCAN_BLOCK / 64];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int incl = wave_incl_scan(v, lane);
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
-        if (i < w) base += wsum[i];
-        tot += wsum[i];
-    }
-    __syncthreads();
-    *total = tot;
-    return base + incl - v;
-}
+using nbscan::block_excl_scan;
+constexpr int SCAN_BLOCK = nbscan::BLOCK;
+constexpr int SCAN_ITEMS = nbscan::ITEMS;
+constexpr int SCAN_TILE = nbscan::TILE;
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_reduce_kernel(const int *__restrict__ in, long long n,
                                                                  int *__restrict__ block_sums) {
@@ -84,6 +59,30 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const int *__res
     }
 }
 
+// scan_apply_kernel for up to FUSED_MAX_BLOCKS blocks: every block sums the totals in front of it itself, the last one writes the
+// grand total — no pass over the block totals, one launch less in every index-set chain
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_self_kernel(const int *__restrict__ in, long long n,
+                                                                     const int *__restrict__ block_sums, int *__restrict__ out,
+                                                                     int *__restrict__ total) {
+    const int before = nbscan::blocks_before(block_sums, blockIdx.x);
+    const long long base = (long long)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_excl_scan(s, &tot) + before;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) out[base + i] = ex;
+        ex += v[i];
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = before + tot;
+}
+
 }  // namespace
 
 long long nb_scan_blocks(long long n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
@@ -95,6 +94,11 @@ int nb_exclusive_scan(const int *flags, int *out, int *total, long long n, int *
         return NB_OK;
     }
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, flags, n, block_sums);
+    if (nb <= nbscan::FUSED_MAX_BLOCKS) {
+        hipLaunchKernelGGL(scan_apply_self_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, flags, n, block_sums, out, total);
+        NB_CHECK_LAUNCH("nb_exclusive_scan");
+        return NB_OK;
+    }
     hipLaunchKernelGGL(scan_tops_kernel, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sums, nb, total);
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_BLOCK), 0, st, flags, n, block_sums, out);
     NB_CHECK_LAUNCH("nb_exclusive_scan");

@@ -96,8 +96,24 @@ class SparseConvNet(nn.Module):
         rows, batch statistics) — everything neuralbody_amd.training.encoder_backward needs."""
         dev = codes.device
         dhw = [int(s) for s in out_sh]
-        grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw)
         n_max = coord.shape[0]
+        layers = [(name, cin, cout, n, stride, j) for name, cin, cout, n, stride in ENCODER_BLOCKS for j in range(n)]
+        # ONE zero fill per element type for everything the pass needs cleared: the index buffers of the levels (rows_vert |
+        # rows_lin | n_rows, then out_lin | n_out per strided layer), and the dense volumes + the layers' fp64 statistics
+        int_sizes, dense_shapes, cap, d = [2 * max(n_max, 1) + 1], [], n_max, dhw
+        for name, cin, cout, n, stride, j in layers:
+            if stride == 2:
+                int_sizes.append(ops.down_capacity(cap, d) + 1)
+                cap, d = int_sizes[-1] - 1, ops.down_dhw(d)
+            if name in DENSE_AFTER and j == n - 1:
+                dense_shapes.append(d + [cout])
+        int_bufs = list(torch.zeros(sum(int_sizes), dtype=torch.int32, device=dev).split(int_sizes))
+        n_stats = 2 * len(layers) * 256  # fp64 [layers, 256] in front (8-byte aligned), the volumes behind it (64-float aligned)
+        dense_sizes = [(math.prod(sh) + 63) // 64 * 64 for sh in dense_shapes]
+        f32_buf = torch.zeros(n_stats + sum(dense_sizes), dtype=torch.float32, device=dev)
+        stats_all = f32_buf[:n_stats].view(torch.float64).view(len(layers), 256)
+        dense_bufs = [b[:math.prod(sh)].view(sh) for b, sh in zip(f32_buf[n_stats:].split(dense_sizes), dense_shapes)]
+        grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw, buf=int_bufs.pop(0))
         rows = ops.enc_gather_codes(codes, rows_vert, n_rows, n_max)
         if save is not None:
             save.append({"rows_vert": rows_vert, "n_rows": n_rows, "n_max": n_max})
@@ -110,15 +126,13 @@ class SparseConvNet(nn.Module):
         # next to them — the backward pass differentiates the exact-fp32 formulas on those.  NB_ENC_SPLIT=0 keeps every
         # layer on the exact-fp32 MFMA kernel.
         fast = ENC_SPLIT
-        layers = [(name, cin, cout, n, stride, j) for name, cin, cout, n, stride in ENCODER_BLOCKS for j in range(n)]
         rows_are_split = False
         rows_f32 = rows  # the fp32 form of the current layer's input rows (what the backward record keeps)
-        stats_all = torch.zeros((len(layers), 256), dtype=torch.float64, device=dev)  # one fill for every layer's statistics
         for li, (name, cin, cout, n, stride, j) in enumerate(layers):
             block = getattr(self, name)
             conv, bn = block[3 * j], block[3 * j + 1]
             if stride == 2:
-                out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw)
+                out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw, buf=int_bufs.pop(0))
             else:
                 out_grid, out_lin, n_out, n_out_max, out_dhw = grid, rows_lin, n_rows, n_max, dhw
             if rows_are_split:
@@ -129,7 +143,8 @@ class SparseConvNet(nn.Module):
                                                conv.weight.detach(), stats=stats_all[li, :2 * cout])
             dense = None
             if name in DENSE_AFTER and j == n - 1:
-                dense = torch.zeros(out_dhw + [cout], dtype=torch.float32, device=dev)
+                dense = dense_bufs.pop(0)
+                assert list(dense.shape) == out_dhw + [cout]
                 volumes.append(dense)
                 sparse.append((out_grid, out_lin, n_out, n_out_max))
             next_split = fast and li + 1 < len(layers) and cout >= 32  # the consumer of these rows is an enc_conv16
@@ -324,9 +339,13 @@ class Network(nn.Module):
         coord = sp_input["coord"]
         if int(sp_input.get("batch_size", 1)) != 1:
             raise NotImplementedError("batch size 1 only")
-        if coord.dim() == 2 and coord.shape[1] == 4:  # [N,4] = (batch idx, d, h, w), if_clight_renderer.py:33-38
-            coord = coord[:, 1:]
-        coord = coord.reshape(-1, 3).to(torch.int32).contiguous()
+        c3 = sp_input.get("_coord_dhw")  # Renderer.prepare_sp_input: the [n, 3] tensor the [n, 4] one was built from
+        if c3 is not None and c3.dim() == 2 and c3.shape == (coord.shape[0], 3) and c3.dtype == torch.int32 and c3.is_contiguous():
+            coord = c3
+        else:
+            if coord.dim() == 2 and coord.shape[1] == 4:  # [N,4] = (batch idx, d, h, w), if_clight_renderer.py:33-38
+                coord = coord[:, 1:]
+            coord = coord.reshape(-1, 3).to(torch.int32).contiguous()
         codes = self.c.weight.detach()
         vols = self.xyzc_net(codes, coord, sp_input["out_sh"], self.training, save)
         # logical layout [1,C,D,H,W] like spconv's .dense(); storage stays channels-last

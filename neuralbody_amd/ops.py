@@ -288,14 +288,19 @@ def _i3(v):
     return (C.c_int32 * 3)(int(v[0]), int(v[1]), int(v[2]))
 
 
-def enc_voxelize(coord, dhw):
-    """nb_enc_voxelize: coord [n,3] int32 (d,h,w) -> (grid [D,H,W] i32, rows_vert, rows_lin, n_rows[1])."""
+def enc_voxelize(coord, dhw, buf=None):
+    """nb_enc_voxelize: coord [n,3] int32 (d,h,w) -> (grid [D,H,W] i32, rows_vert, rows_lin, n_rows[1]).
+    buf: a ZEROED int32 [2 * max(n, 1) + 1] buffer of the caller's for the three outputs (the encoder clears the index buffers of
+    all its levels with one fill)."""
     _req(coord, torch.int32, (None, 3), "coord")
     n = coord.shape[0]
     dev = coord.device
     grid = torch.empty([int(s) for s in dhw], dtype=torch.int32, device=dev)
     m = max(n, 1)
-    buf = torch.zeros(2 * m + 1, dtype=torch.int32, device=dev)  # one fill
+    if buf is None:
+        buf = torch.zeros(2 * m + 1, dtype=torch.int32, device=dev)  # one fill
+    else:
+        _req(buf, torch.int32, (2 * m + 1,), "buf")
     rows_vert, rows_lin, n_rows = buf[:m], buf[m:2 * m], buf[2 * m:]
     scratch = scan_scratch(n, dev)
     check(_lib.lib().nb_enc_voxelize(ptr(coord), n, _i3(dhw), ptr(grid), ptr(rows_vert), ptr(rows_lin), ptr(n_rows),
@@ -307,16 +312,26 @@ def down_dhw(dhw):
     return [(int(s) - 1) // 2 + 1 for s in dhw]
 
 
-def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None):
-    """nb_enc_downsample_index -> (out_grid, out_lin, n_out[1], n_out_max, out_dhw)."""
+def down_capacity(n_in_max, in_dhw):
+    """Row capacity of the strided convolution's output index set: every input row has at most 8 parents."""
+    out_dhw = down_dhw(in_dhw)
+    return max(min(8 * int(n_in_max), out_dhw[0] * out_dhw[1] * out_dhw[2]), 1)
+
+
+def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None, buf=None):
+    """nb_enc_downsample_index -> (out_grid, out_lin, n_out[1], n_out_max, out_dhw).
+    buf: a ZEROED int32 [down_capacity(n_in_max, in_dhw) + 1] buffer of the caller's for out_lin and n_out."""
     _req(in_lin, torch.int32, (None,), "in_lin")
     _req(n_in, torch.int32, (1,), "n_in")
     dev = in_lin.device
     out_dhw = down_dhw(in_dhw)
     nvox = out_dhw[0] * out_dhw[1] * out_dhw[2]
-    n_out_max = max(min(8 * int(n_in_max), nvox), 1)
+    n_out_max = down_capacity(n_in_max, in_dhw)
     out_grid = torch.empty(out_dhw, dtype=torch.int32, device=dev)
-    buf = torch.zeros(n_out_max + 1, dtype=torch.int32, device=dev)  # one fill
+    if buf is None:
+        buf = torch.zeros(n_out_max + 1, dtype=torch.int32, device=dev)  # one fill
+    else:
+        _req(buf, torch.int32, (n_out_max + 1,), "buf")
     out_lin, n_out = buf[:n_out_max], buf[n_out_max:]
     if scratch is None:
         scratch = scan_scratch(nvox, dev)

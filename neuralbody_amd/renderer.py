@@ -55,10 +55,18 @@ class Renderer:
         # pageable host memory makes the launch thread wait for everything already enqueued (the previous view's march) —
         # the encoder's ~90 launches then cannot be enqueued under it (tools/experiments/cpu_ahead.py: 18.2 ms of host time
         # per render() instead of 1.5)
-        idx = [torch.full([sh[1]], i, dtype=batch["coord"].dtype, device=batch["coord"].device) for i in range(sh[0])]
-        idx = torch.cat(idx)
         coord = batch["coord"].view(-1, sh[-1])
-        sp_input["coord"] = torch.cat([idx[:, None], coord], dim=1)
+        if sh[0] == 1:
+            # batch size 1 (every shipped config): the batch-index column is a constant, kept per (length, dtype, device); the
+            # encoder takes the [n, 3] coordinates themselves (`_coord_dhw`) instead of cutting the column off again
+            zc = getattr(self, "_zero_col", None)
+            if zc is None or zc.shape[0] != sh[1] or zc.dtype != coord.dtype or zc.device != coord.device:
+                zc = self._zero_col = torch.zeros((sh[1], 1), dtype=coord.dtype, device=coord.device)
+            sp_input["coord"] = torch.cat([zc, coord], dim=1)
+            sp_input["_coord_dhw"] = coord
+        else:
+            idx = [torch.full([sh[1]], i, dtype=coord.dtype, device=coord.device) for i in range(sh[0])]
+            sp_input["coord"] = torch.cat([torch.cat(idx)[:, None], coord], dim=1)
         sp_input["out_sh"] = self._host_out_sh(batch["out_sh"])
         sp_input["batch_size"] = sh[0]
         sp_input["bounds"] = batch["bounds"]
