@@ -78,5 +78,72 @@ def main():
             print("... of high priority        %.3f ms per view" % timed(piped, a.steps, s1), flush=True)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--trace" not in sys.argv:
     main()
+
+
+def trace(steps=12):
+    """Where the encoder of step i + 1 actually runs: HIP events on both streams (Renderer.prefetch / render with tickets),
+    times in ms after the start of the first traced march."""
+    from neuralbody_amd import ops
+
+    dev = torch.device("cuda", 0)
+    sd, body, net, rend, bd, n_rays = bench.build_scene(dev, 512, 512, 64, None)
+    poses = bench.build_poses(dev, body, bd, 512, 512)
+    rows = []
+    marks = []  # (step, layer, event) recorded on the encoder's stream behind every BatchNorm launch
+    cur_step = [0]
+    for fname in ("enc_bn_relu", "enc_bn_relu_split"):
+        def wrap(f):
+            def g(*a, **k):
+                r = f(*a, **k)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append((cur_step[0], e))
+                return r
+            return g
+        setattr(ops, fname, wrap(getattr(ops, fname)))
+    with torch.no_grad():
+        for i in range(3):
+            rend.render(poses[i])
+        torch.cuda.synchronize()
+        ticket = None
+        orig = rend.prefetch
+
+        def traced_prefetch(batch):
+            t = orig(batch)
+            return t
+
+        for i in range(steps):
+            cur, ticket_next = ticket, None
+            side = getattr(rend, "_side_stream", None)
+            e_enc0 = torch.cuda.Event(enable_timing=True)
+            e_enc1 = torch.cuda.Event(enable_timing=True)
+            cur_step[0] = i
+            ticket_next = rend.prefetch(poses[(i + 1) % len(poses)])
+            side = rend._side_stream
+            # the ticket's ready event marks the end; a start marker cannot be inserted behind the wait inside prefetch, so the
+            # encoder's own duration is taken from a second event pair around an identical pass below
+            ops.MARCH_EVENTS = []
+            rend.render(poses[i % len(poses)], prefetched=cur)
+            (m0, m1), = ops.MARCH_EVENTS
+            ops.MARCH_EVENTS = None
+            e_enc1.record(side)
+            rows.append((m0, m1, e_enc1))
+            ticket = ticket_next
+        torch.cuda.synchronize()
+    base = rows[2][0]
+    for k in (4, 5):
+        m0, m1, _ = rows[k]
+        print("step %d: march %.3f .. %.3f; the 17 layers of the encoder enqueued with it finish at (ms after the march's start):" % (
+            k, base.elapsed_time(m0), base.elapsed_time(m1)))
+        print("   " + " ".join("%.2f" % m0.elapsed_time(e) for st, e in marks if st == k))
+    print("step | march start | march end | encoder of the next step done (side stream) | gap to the next march start")
+    for k in range(2, len(rows) - 1):
+        m0, m1, e1 = rows[k]
+        print("%4d | %10.3f | %9.3f | %9.3f | %6.3f" % (k, base.elapsed_time(m0), base.elapsed_time(m1), base.elapsed_time(e1),
+                                                          m1.elapsed_time(rows[k + 1][0])))
+
+
+if __name__ == "__main__" and "--trace" in sys.argv:
+    trace()
