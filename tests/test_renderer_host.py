@@ -136,3 +136,29 @@ def test_the_differentiable_path_refuses_what_it_does_not_differentiate():
     r.cfg.raw_noise_std = 1.0
     with pytest.raises(NotImplementedError, match="raw_noise_std != 0 on the differentiable path"):
         r.render(b)
+
+
+def test_prepare_sp_input_keeps_the_reference_layout():
+    """if_clight_renderer.py:29-52: coord [B * n, 4] = (batch index, d, h, w); batch size 1 takes the constant-column path and
+    hands the encoder the [n, 3] coordinates themselves, batch size 2 the general one — same values as the reference's recipe."""
+    r = _renderer(16, 16)
+    for B in (1, 2):
+        coord = torch.arange(B * 5 * 3, dtype=torch.int32).reshape(B, 5, 3)
+        batch = {"coord": coord, "out_sh": torch.tensor([[8, 8, 8]] * B, dtype=torch.int32), "bounds": torch.zeros(B, 2, 3),
+                 "R": torch.eye(3)[None].repeat(B, 1, 1), "Th": torch.zeros(B, 1, 3), "latent_index": torch.zeros(B, dtype=torch.long)}
+        sp = r.prepare_sp_input(batch)
+        idx = torch.cat([torch.full([5], i, dtype=torch.int32) for i in range(B)])
+        assert torch.equal(sp["coord"], torch.cat([idx[:, None], coord.view(-1, 3)], dim=1)) and sp["coord"].dtype == torch.int32
+        assert sp["batch_size"] == B and sp["out_sh"] == [8, 8, 8]
+        assert ("_coord_dhw" in sp) == (B == 1)
+        if B == 1:
+            assert sp["_coord_dhw"].data_ptr() == coord.data_ptr()
+
+
+def test_prefetch_is_an_inference_call_on_device_tensors():
+    r = _renderer(16, 16)
+    batch = {"coord": torch.zeros(1, 5, 3, dtype=torch.int32)}
+    with pytest.raises(RuntimeError, match="inference-only"):
+        r.prefetch(batch)
+    with torch.no_grad(), pytest.raises(RuntimeError, match="device tensors"):
+        r.prefetch(batch)
