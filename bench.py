@@ -308,7 +308,7 @@ def train_bench(args, dev):
                       "ray_samples_per_sec": 1024 * args.samples / dt, "final_loss": float(loss.detach()),
                       # decoder forward + the two backward products = 3 x the forward flops, on the exact-fp32 MFMA kernels; the
                       # step is ~600 launches of 5-30 us and the encoder, so this fraction states how far a 1024-ray step is from
-                      # being a matrix-pipe problem at all (DESIGN.md §4.4), not a kernel quality
+                      # being a matrix-pipe problem at all (DESIGN.md §4.5), not a kernel quality
                       "roofline": {"bound": "mfma", "achieved": 3 * FLOP_PER_SAMPLE * 1024 * args.samples / dt / 1e12,
                                    "peak": PRECISION_INFO["f32"][3], "unit": "TFLOP/s",
                                    "frac": 3 * FLOP_PER_SAMPLE * 1024 * args.samples / dt / 1e12 / PRECISION_INFO["f32"][3],
@@ -669,6 +669,8 @@ def main():
         result["per_rank"] = per_rank
     if net.precision == "auto":
         result["config"]["auto"] = {"chosen": net.march_precision(), "six_bit_small_fraction_worst_layer": net._auto[2] if net._auto else None}
+    if rank == 0 and world == 1 and not args.no_extras:
+        result["extras"] = extras(args, dev)  # before the CPU legs: their thread pools compete with the launch thread
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         par = parity_check(sd, net, rend, poses[1], S)
         result["parity_linf"] = par["linf"]
@@ -683,8 +685,6 @@ def main():
         with torch.no_grad():
             vols = net.encode_sparse_voxels(rend.prepare_sp_input(poses[0]))
         result["cpu_baseline"] = cpu_baseline(sd, poses[0], vols, S)
-    if rank == 0 and world == 1 and not args.no_extras:
-        result["extras"] = extras(args, dev)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:
