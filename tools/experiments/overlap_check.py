@@ -78,8 +78,62 @@ def main():
             print("... of high priority        %.3f ms per view" % timed(piped, a.steps, s1), flush=True)
 
 
-if __name__ == "__main__" and "--trace" not in sys.argv:
+if __name__ == "__main__" and "--trace" not in sys.argv and "--alternate" not in sys.argv:
     main()
+
+
+def alternate(steps=32):
+    """Marches alternating between two streams (the head of march i + 1 in the tail of march i), encoders two frames ahead on a
+    third: ms per view against the one-stream pipeline of main()."""
+    dev = torch.device("cuda", 0)
+    sd, body, net, rend, bd, n_rays = bench.build_scene(dev, 512, 512, 64, None)
+    poses = bench.build_poses(dev, body, bd, 512, 512)
+    enc_s = torch.cuda.Stream(device=dev)
+    ms = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def encode(b):
+        sp = rend.prepare_sp_input(b)
+        fv = net.encode_sparse_voxels(sp)
+        net.make_scene(fv, sp, net.march_precision())
+        return fv
+
+    def run(n, depth):
+        ready, fvs, done = {}, {}, {}
+
+        def prefetch(j, after):
+            with torch.cuda.stream(enc_s):
+                if after is not None:
+                    enc_s.wait_event(after)
+                fvs[j] = encode(poses[j % len(poses)])
+                ready[j] = torch.cuda.Event()
+                ready[j].record(enc_s)
+
+        for j in range(depth):
+            prefetch(j, None)
+        outs = []
+        for i in range(n):
+            prefetch(i + depth, done.get(i - 1))
+            s = ms[i % 2] if depth > 1 else ms[0]
+            with torch.cuda.stream(s):
+                s.wait_event(ready.pop(i))
+                outs.append(rend.render(poses[i % len(poses)], feature_volume=fvs.pop(i))["rgb_map"])
+                done[i] = torch.cuda.Event()
+                done[i].record(s)
+            del outs[:-4]
+        torch.cuda.synchronize()
+        return outs[-1]
+
+    with torch.no_grad():
+        ref = rend.render(poses[(steps - 1) % len(poses)])["rgb_map"].clone()
+        torch.cuda.synchronize()
+        for rep in range(2):
+            for depth in (1, 2):
+                run(6, depth)
+                t0 = time.perf_counter()
+                out = run(steps, depth)
+                dt = (time.perf_counter() - t0) / steps * 1e3
+                print("marches on %s, encoders %d ahead: %.3f ms per view (max |rgb - serial| %.1e)" % (
+                    "two alternating streams" if depth > 1 else "one stream", depth, dt, float((out - ref).abs().max())), flush=True)
 
 
 def trace(steps=12):
@@ -147,3 +201,5 @@ def trace(steps=12):
 
 if __name__ == "__main__" and "--trace" in sys.argv:
     trace()
+if __name__ == "__main__" and "--alternate" in sys.argv:
+    alternate()
