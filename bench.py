@@ -548,13 +548,17 @@ def main():
         b = poses[(i + rank) % len(poses)]
         cur = ticket[0]
         ticket[0] = None
-        if overlap[0]:
-            # step i + 1's encoder is enqueued on a second HIP stream before this step's march (Renderer.prefetch): every step
-            # still encodes one frame and marches one view, the encoder's ~90 small launches run in the march's shadow
-            ticket[0] = rend.prefetch(poses[(i + 1 + rank) % len(poses)])
+        # step i + 1's encoder goes to a second HIP stream (Renderer.prefetch) behind a fence taken before this step's march:
+        # every step still encodes one frame and marches one view, the encoder's ~60 small launches run in the march's shadow
+        fence = rend.fence() if overlap[0] else None
         if args.scaling == "strong":
-            return render_sharded(rend, b, dist.group.WORLD if dist is not None else None, prefetched=cur)["rgb_map"][0]
+            out = render_sharded(rend, b, dist.group.WORLD if dist is not None else None, prefetched=cur)["rgb_map"][0]
+            if overlap[0]:
+                ticket[0] = rend.prefetch(poses[(i + 1 + rank) % len(poses)], after=fence)
+            return out
         out = rend.render(b, prefetched=cur)
+        if overlap[0]:
+            ticket[0] = rend.prefetch(poses[(i + 1 + rank) % len(poses)], after=fence)
         if dist is not None:
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             g0.record()
@@ -601,7 +605,8 @@ def main():
             serial_ms = (time.perf_counter() - t1) / 6 * 1e3
             overlap[0] = True
     march_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
-    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
+    step_ms_in_order = [a.elapsed_time(b) for a, b in step_events]
+    step_ms = sorted(step_ms_in_order)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     per_rank = None
     if dist is not None:
@@ -632,7 +637,7 @@ def main():
     result = {
         "metric": "ray_samples_per_sec", "value": samples_per_s, "unit": "ray-samples/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "median_ms_per_step": median_ms, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": dtype,
+        "median_ms_per_step": median_ms, "step_ms": [round(v, 3) for v in step_ms_in_order[:32]], "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": dtype,
         "data": "synthetic",
         "rays_per_sec": total_rays / elapsed,
         "config": {"workload": "synthetic 6890-vertex SMPL scene, %dx%d full-coverage view, %d samples/ray, "

@@ -204,13 +204,14 @@ class NovelViewRenderer:
             batch = self._finish_batch(launched, cur[3])
             nxt = next(it, None)
             cur_ticket, ticket = ticket, None
+            ahead = nxt is not None and self.prefetch_encoder and not self.reuse_volumes
             if nxt is not None:
                 launched = self._launch_rays(nxt[0], nxt[1], nxt[2])
-                if self.prefetch_encoder and not self.reuse_volumes:
-                    with torch.no_grad():
-                        ticket = self.renderer.prefetch(nxt[3])  # view k + 1's encoder on a second stream, beside view k's march
+            fence = self.renderer.fence(self.device) if ahead else None
             with torch.no_grad():  # the render runs without autograd; the consumer's loop body keeps ITS grad mode (yielding from
                 out = self._render_batch(batch, bgr, scale, None, cur_ticket)  # inside the block would leak no_grad into it)
+                if ahead:  # view k + 1's encoder on a second stream, beside view k's march (enqueued behind it, ordered before it)
+                    ticket = self.renderer.prefetch(nxt[3], after=fence)
             yield out
             cur = nxt
 

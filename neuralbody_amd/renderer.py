@@ -187,11 +187,21 @@ class Renderer:
     # synchronous pass: if_clight_renderer.py:94-122)
     _FRAME_KEYS = ("coord", "out_sh", "bounds", "R", "Th", "latent_index")
 
-    def prefetch(self, batch):
+    def fence(self, device=None):
+        """An event on the current stream, for `prefetch(batch, after=fence)`: everything enqueued so far (the previous march,
+        the copies that produced the next frame's tensors), and nothing enqueued later."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        return ev
+
+    def prefetch(self, batch, after=None):
         """Enqueue the encoder of `batch`'s frame (prepare_sp_input, encode_sparse_voxels and, for the folded arithmetic, the
-        fold planes) on a SECOND HIP stream and return a ticket for `render(batch, prefetched=ticket)`.  Call it BEFORE the
-        render() of the frame in front of it: the second stream first waits for everything enqueued so far (the previous march:
-        the volumes it read are recycled by this pass), then its ~90 small launches (1.2 ms on an empty chip, a quarter of the
+        fold planes) on a SECOND HIP stream and return a ticket for `render(batch, prefetched=ticket)`.  The second stream first
+        waits for `after` (an event of `fence()` taken BEFORE the render() of the frame in front was enqueued) or, without one,
+        for everything enqueued on the current stream so far — so either call prefetch before that render(), or take the fence
+        before it and call prefetch behind it (the launch thread then hands the march to the device first, its ~60 encoder
+        launches afterwards: what a loop that starts on an idle device wants).  What it waits for must include the previous
+        march: the volumes that march read are recycled by this pass.  Its ~60 small launches (1.2 ms on an empty chip, a quarter of the
         CUs busy) run beside the march that render() enqueues next — mostly in the slots the march's last workgroups leave free
         (tools/experiments/overlap_check.py: 13.26 -> 12.72 ms per 512 x 512 view).  render() marches the ticket's volumes when its
         batch carries the SAME frame tensors (identity and version counters of coord, out_sh, bounds, R, Th, latent_index; the
@@ -205,7 +215,13 @@ class Renderer:
         side = getattr(self, "_side_stream", None)
         if side is None or side.device != dev:
             side = self._side_stream = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
+        if after is None:
+            side.wait_stream(torch.cuda.current_stream(dev))
+        else:
+            side.wait_event(after)
+        pre = getattr(self, "_pre_march", None)
+        if pre is not None:
+            side.wait_event(pre)  # whatever `after` is: never in front of the march before the one being enqueued / just enqueued
         self._frame_token = batch.get("frame_token")
         with torch.cuda.stream(side):
             sp_input = self.prepare_sp_input(batch)
@@ -225,7 +241,13 @@ class Renderer:
         key = self._frame_key(batch)
         if any(a[0] is not b[0] or a[1] != b[1] for a, b in zip(ticket[0][:-1], key[:-1])) or ticket[0][-1] != key[-1]:
             return None  # another frame, or this frame's tensors rewritten in place since: the volumes are not this batch's
-        torch.cuda.current_stream(batch["coord"].device).wait_event(ticket[3])
+        main = torch.cuda.current_stream(batch["coord"].device)
+        # The volumes live in the second stream's memory pool.  They stay referenced here until the NEXT ticket is taken, and an
+        # event in front of this march is what every later prefetch waits for at least: the pass that recycles them is then
+        # ordered behind the march that reads them, whenever the caller drops its ticket
+        self._held, self._pre_march = ticket, torch.cuda.Event()
+        self._pre_march.record(main)
+        main.wait_event(ticket[3])
         return ticket[1], ticket[2]
 
     def make_cull(self, batch):

@@ -129,13 +129,23 @@ def test_prefetched_encoder_renders_the_same_frames(precision):
                 piped.append(rend.render(cur, prefetched=cur_ticket)["rgb_map"].clone())
                 del cur, cur_ticket
             assert calls["n"] == 5, calls  # frame 0 inside its render(), 1..4 ahead
+            # the other calling order: a fence in front of render(), the prefetch behind it (the march reaches the device first),
+            # every ticket dropped as early as a caller can
+            nxt, ticket, fenced = H.device_batch(frames[0], DEV), None, []
+            for f in range(5):
+                cur, nxt = nxt, (H.device_batch(frames[f + 1], DEV) if f + 1 < 5 else None)
+                fence = rend.fence()
+                fenced.append(rend.render(cur, prefetched=ticket)["rgb_map"].clone())
+                del cur, ticket
+                ticket = rend.prefetch(nxt, after=fence) if nxt is not None else None
+            assert calls["n"] == 10, calls
             # a ticket of another frame: ignored, the rendered frame is encoded in place
             a, b = H.device_batch(frames[1], DEV), H.device_batch(frames[2], DEV)
             ta = rend.prefetch(a)
             other = rend.render(b, prefetched=ta)["rgb_map"].clone()
-            assert calls["n"] == 7
+            assert calls["n"] == 12
             late = rend.render(a, prefetched=ta)["rgb_map"].clone()  # its own frame, two renders later
-            assert calls["n"] == 7
+            assert calls["n"] == 12
             # in-place change of a frame tensor after the prefetch: the volumes are stale, render() encodes again
             c = H.device_batch(frames[3], DEV)
             tc = rend.prefetch(c)
@@ -146,7 +156,7 @@ def test_prefetched_encoder_renders_the_same_frames(precision):
             for k in ("ray_o", "ray_d", "near", "far", "mask_at_box"):
                 c[k] = H.device_batch(frames[4], DEV)[k]
             changed = rend.render(c, prefetched=tc)["rgb_map"].clone()
-            assert calls["n"] == 9
+            assert calls["n"] == 14
         finally:
             net.encode_sparse_voxels = enc
     torch.cuda.synchronize()
@@ -154,7 +164,7 @@ def test_prefetched_encoder_renders_the_same_frames(precision):
         return x.shape == y.shape and float((x - y).abs().max()) <= 2e-6
 
     for f in range(5):
-        assert same(piped[f], serial[f]), f
+        assert same(piped[f], serial[f]) and same(fenced[f], serial[f]), f
         assert f == 0 or not same(serial[f], serial[f - 1]), "frames must differ for the test to see a mix-up"
     assert same(other, serial[2]) and same(late, serial[1]) and same(changed, serial[4])
     with pytest.raises(RuntimeError):
