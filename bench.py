@@ -495,6 +495,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: one view per GPU per step (views shard with no collective but the tile all-gather); "
                          "strong: one view per step, its rays split over the GPUs")
+    ap.add_argument("--prefetch-depth", type=int, default=1, help="how many views ahead the encoder runs on the second stream")
     ap.add_argument("--no-overlap", action="store_true", help="encode and march strictly one after the other on one stream")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational turntable / train-step legs of the JSON line")
     ap.add_argument("--reuse-volumes", action="store_true", help="turntable mode: encode the frame once for all views")
@@ -542,23 +543,23 @@ def main():
     gather_events = []
 
     overlap = [not args.no_overlap]
-    ticket = [None]
+    tickets = {}  # view index -> ticket of its encoder pass, args.prefetch_depth views ahead
 
     def step(i):
         b = poses[(i + rank) % len(poses)]
-        cur = ticket[0]
-        ticket[0] = None
+        cur = tickets.pop(i, None)
+        ahead = i + args.prefetch_depth
         # step i + 1's encoder goes to a second HIP stream (Renderer.prefetch) behind a fence taken before this step's march:
         # every step still encodes one frame and marches one view, the encoder's ~60 small launches run in the march's shadow
         fence = rend.fence() if overlap[0] else None
         if args.scaling == "strong":
             out = render_sharded(rend, b, dist.group.WORLD if dist is not None else None, prefetched=cur)["rgb_map"][0]
             if overlap[0]:
-                ticket[0] = rend.prefetch(poses[(i + 1 + rank) % len(poses)], after=fence)
+                tickets[ahead] = rend.prefetch(poses[(ahead + rank) % len(poses)], after=fence)
             return out
         out = rend.render(b, prefetched=cur)
         if overlap[0]:
-            ticket[0] = rend.prefetch(poses[(i + 1 + rank) % len(poses)], after=fence)
+            tickets[ahead] = rend.prefetch(poses[(ahead + rank) % len(poses)], after=fence)
         if dist is not None:
             g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             g0.record()
@@ -595,12 +596,14 @@ def main():
         serial_ms = None
         if overlap[0] and dist is None:
             overlap[0] = False
-            step(0)  # takes the last prefetched frame
-            step(1)
+            base = args.warmup + args.steps
+            for i in range(args.prefetch_depth + 1):
+                step(base + i)  # take the frames still in flight
+            base += args.prefetch_depth + 1
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(6):
-                step(2 + i)
+                step(base + i)
             torch.cuda.synchronize()
             serial_ms = (time.perf_counter() - t1) / 6 * 1e3
             overlap[0] = True

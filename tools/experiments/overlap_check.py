@@ -78,7 +78,7 @@ def main():
             print("... of high priority        %.3f ms per view" % timed(piped, a.steps, s1), flush=True)
 
 
-if __name__ == "__main__" and "--trace" not in sys.argv and "--alternate" not in sys.argv:
+if __name__ == "__main__" and "--trace" not in sys.argv and "--alternate" not in sys.argv and "--two-sides" not in sys.argv:
     main()
 
 
@@ -136,70 +136,95 @@ def alternate(steps=32):
                     "two alternating streams" if depth > 1 else "one stream", depth, dt, float((out - ref).abs().max())), flush=True)
 
 
-def trace(steps=12):
-    """Where the encoder of step i + 1 actually runs: HIP events on both streams (Renderer.prefetch / render with tickets),
-    times in ms after the start of the first traced march."""
+def two_side_streams(steps=32):
+    """Encoders two views ahead on TWO alternating side streams (the chains of consecutive views overlap each other across two
+    march tails) against one side stream one view ahead.  (The BatchNorm running statistics of concurrent passes race here:
+    timing experiment only.)"""
+    dev = torch.device("cuda", 0)
+    sd, body, net, rend, bd, n_rays = bench.build_scene(dev, 512, 512, 64, None)
+    poses = bench.build_poses(dev, body, bd, 512, 512)
+    sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def run(n, depth, n_streams):
+        tickets = {}
+        for i in range(n):
+            cur = tickets.pop(i, None)
+            fence = rend.fence()
+            out = rend.render(poses[i % len(poses)], prefetched=cur)["rgb_map"]
+            rend._side_stream = sides[(i + depth) % n_streams]
+            tickets[i + depth] = rend.prefetch(poses[(i + depth) % len(poses)], after=fence)
+        torch.cuda.synchronize()
+        return out
+
+    with torch.no_grad():
+        ref = rend.render(poses[(steps - 1) % len(poses)])["rgb_map"].clone()
+        for rep in range(2):
+            for depth, ns in ((1, 1), (2, 2), (2, 1), (3, 2)):
+                run(6, depth, ns)
+                t0 = time.perf_counter()
+                out = run(steps, depth, ns)
+                dt = (time.perf_counter() - t0) / steps * 1e3
+                print("encoders %d ahead on %d side stream(s): %.3f ms per view (max |rgb - serial| %.1e)" % (
+                    depth, ns, dt, float((out - ref).abs().max())), flush=True)
+
+
+def trace(steps=14, depth=1):
+    """Where the encoder of a later step actually runs: HIP events on both streams (fence / render with ticket / prefetch `depth`
+    views ahead, the calling order of bench.py), times in ms after the start of the first traced march."""
     from neuralbody_amd import ops
 
     dev = torch.device("cuda", 0)
     sd, body, net, rend, bd, n_rays = bench.build_scene(dev, 512, 512, 64, None)
     poses = bench.build_poses(dev, body, bd, 512, 512)
-    rows = []
-    marks = []  # (step, layer, event) recorded on the encoder's stream behind every BatchNorm launch
-    cur_step = [0]
+    rows, enc = [], {}
+    marks = []  # (view, event) recorded on the encoder's stream behind every BatchNorm launch
+    cur_view = [0]
     for fname in ("enc_bn_relu", "enc_bn_relu_split"):
         def wrap(f):
             def g(*a, **k):
                 r = f(*a, **k)
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
-                marks.append((cur_step[0], e))
+                marks.append((cur_view[0], e))
                 return r
             return g
         setattr(ops, fname, wrap(getattr(ops, fname)))
+    tickets = {}
     with torch.no_grad():
         for i in range(3):
             rend.render(poses[i])
         torch.cuda.synchronize()
-        ticket = None
-        orig = rend.prefetch
-
-        def traced_prefetch(batch):
-            t = orig(batch)
-            return t
-
         for i in range(steps):
-            cur, ticket_next = ticket, None
-            side = getattr(rend, "_side_stream", None)
-            e_enc0 = torch.cuda.Event(enable_timing=True)
-            e_enc1 = torch.cuda.Event(enable_timing=True)
-            cur_step[0] = i
-            ticket_next = rend.prefetch(poses[(i + 1) % len(poses)])
-            side = rend._side_stream
-            # the ticket's ready event marks the end; a start marker cannot be inserted behind the wait inside prefetch, so the
-            # encoder's own duration is taken from a second event pair around an identical pass below
+            cur = tickets.pop(i, None)
+            fence = rend.fence()
             ops.MARCH_EVENTS = []
             rend.render(poses[i % len(poses)], prefetched=cur)
             (m0, m1), = ops.MARCH_EVENTS
             ops.MARCH_EVENTS = None
-            e_enc1.record(side)
-            rows.append((m0, m1, e_enc1))
-            ticket = ticket_next
+            cur_view[0] = i + depth
+            tickets[i + depth] = rend.prefetch(poses[(i + depth) % len(poses)], after=fence)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(rend._side_stream)
+            enc[i + depth] = e1
+            rows.append((m0, m1))
         torch.cuda.synchronize()
-    base = rows[2][0]
-    for k in (4, 5):
-        m0, m1, _ = rows[k]
-        print("step %d: march %.3f .. %.3f; the 17 layers of the encoder enqueued with it finish at (ms after the march's start):" % (
-            k, base.elapsed_time(m0), base.elapsed_time(m1)))
-        print("   " + " ".join("%.2f" % m0.elapsed_time(e) for st, e in marks if st == k))
-    print("step | march start | march end | encoder of the next step done (side stream) | gap to the next march start")
-    for k in range(2, len(rows) - 1):
-        m0, m1, e1 = rows[k]
-        print("%4d | %10.3f | %9.3f | %9.3f | %6.3f" % (k, base.elapsed_time(m0), base.elapsed_time(m1), base.elapsed_time(e1),
-                                                          m1.elapsed_time(rows[k + 1][0])))
+    base = rows[4][0]
+    print("prefetch depth %d" % depth)
+    for k in (6, 7):
+        m0, m1 = rows[k]
+        print("view %d: march %.3f .. %.3f; the 17 layers of the encoder of view %d (enqueued behind this march) finish at (ms after the march's start):" % (
+            k, base.elapsed_time(m0), base.elapsed_time(m1), k + depth))
+        print("   " + " ".join("%.2f" % m0.elapsed_time(e) for v, e in marks if v == k + depth))
+    print("view | march start | march end | its own encoder done (side stream) | gap to the next march start")
+    for k in range(4, len(rows) - 1):
+        m0, m1 = rows[k]
+        print("%4d | %10.3f | %9.3f | %9.3f | %6.3f" % (k, base.elapsed_time(m0), base.elapsed_time(m1),
+                                                          base.elapsed_time(enc[k]) if k in enc else float("nan"), m1.elapsed_time(rows[k + 1][0])))
 
 
 if __name__ == "__main__" and "--trace" in sys.argv:
-    trace()
+    trace(depth=2 if "--depth2" in sys.argv else 1)
 if __name__ == "__main__" and "--alternate" in sys.argv:
     alternate()
+if __name__ == "__main__" and "--two-sides" in sys.argv:
+    two_side_streams()
