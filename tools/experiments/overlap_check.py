@@ -145,27 +145,31 @@ def two_side_streams(steps=32):
     poses = bench.build_poses(dev, body, bd, 512, 512)
     sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
 
-    def run(n, depth, n_streams):
+    marchers = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+
+    def run(n, depth, n_streams, n_march=1):
         tickets = {}
         for i in range(n):
             cur = tickets.pop(i, None)
-            fence = rend.fence()
-            out = rend.render(poses[i % len(poses)], prefetched=cur)["rgb_map"]
-            rend._side_stream = sides[(i + depth) % n_streams]
-            tickets[i + depth] = rend.prefetch(poses[(i + depth) % len(poses)], after=fence)
+            ms = marchers[i % 2] if n_march == 2 else torch.cuda.current_stream()
+            with torch.cuda.stream(ms):
+                fence = rend.fence()
+                out = rend.render(poses[i % len(poses)], prefetched=cur)["rgb_map"]
+                rend._side_stream = sides[(i + depth) % n_streams]
+                tickets[i + depth] = rend.prefetch(poses[(i + depth) % len(poses)], after=fence)
         torch.cuda.synchronize()
         return out
 
     with torch.no_grad():
         ref = rend.render(poses[(steps - 1) % len(poses)])["rgb_map"].clone()
         for rep in range(2):
-            for depth, ns in ((1, 1), (2, 2), (2, 1), (3, 2)):
-                run(6, depth, ns)
+            for depth, ns, nm in ((1, 1, 1), (2, 2, 1), (2, 2, 2), (3, 2, 2), (4, 2, 2)):
+                run(8, depth, ns, nm)
                 t0 = time.perf_counter()
-                out = run(steps, depth, ns)
+                out = run(steps, depth, ns, nm)
                 dt = (time.perf_counter() - t0) / steps * 1e3
-                print("encoders %d ahead on %d side stream(s): %.3f ms per view (max |rgb - serial| %.1e)" % (
-                    depth, ns, dt, float((out - ref).abs().max())), flush=True)
+                print("encoders %d ahead on %d side stream(s), marches on %d stream(s): %.3f ms per view (max |rgb - serial| %.1e)" % (
+                    depth, ns, nm, dt, float((out - ref).abs().max())), flush=True)
 
 
 def trace(steps=14, depth=1):
