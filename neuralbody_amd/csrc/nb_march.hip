@@ -407,7 +407,7 @@ __global__ void nb_pack_kernel(nb_mlp_params p, float *__restrict__ out) {
 
 // out[0..255]: bias of the merged feature_fc / latent_fc layer, MFMA fragment order [tile][hi][16];
 // out[256..383]: bias of view_fc with that whole (activation-free) layer pair folded in, i.e. view_b + view_w[:, :256] . (the
-// former), same order — for the kernels that run feature_fc, latent_fc and view_fc as ONE linear layer (nb_march_f16.hip)
+// former), same order — for the kernels that run feature_fc, latent_fc and view_fc as ONE linear layer (nb_march_fold.hip)
 __global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__ latent_row, float *__restrict__ out) {
     __shared__ double lbn[256];  // natural order
     const int rel = threadIdx.x;  // [t][hi][16]

@@ -1,4 +1,4 @@
-// nb_march_fold.hip — the fused march / point decoder with fc_0 FOLDED INTO THE VOLUME (NB_PREC_F16F6V), gfx950.
+// nb_march_fold.hip — the fused march / point decoder with fc_0 FOLDED INTO THE VOLUME (NB_PREC_F16F6), gfx950.
 //
 // Trilinear interpolation (latent_xyzc.py:62-72) and fc_0 (:99) are linear with nothing between them:
 //     fc_0 . interp(V) = interp(fc_0 . V)  =  sum over the voxels v a sample touches of  wt(v, sample) . U[v, :]
@@ -29,8 +29,9 @@
 //   Wt      owner lanes zero their samples' B-fragment slots and scatter the 8 corner weights of their level (head and
 //           remainder, ATen's corner order and zero padding: a corner outside the volume writes nothing)             [same place]
 //   MFMA    per 16-voxel chunk and wave: 2 x 2 tiles x 3 products.
-// A list longer than 128 voxels (rays far apart: small images, random rays; long runs of lattice points) is marched in sample
-// groups of 16 or, failing that, one sample at a time through the very same steps (K = 32 for a single sample).
+// A list longer than 128 voxels is marched in passes of 128 over the same boxes (up to 1024 voxels: neighbouring but not dense
+// points, wide pixel footprints); beyond that (rays far apart: small images, random rays) in sample groups of 16 or, failing
+// that, one sample at a time through the very same steps (K = 32 for a single sample).
 //
 // Per-sample work (ray set-up, positional encoding, compositing) is done by "owner" lanes: wave w, lane l owns sample
 // 16 w + (l & 15) and, of that sample, pyramid level / axis `part` = l >> 4.
