@@ -235,11 +235,20 @@ class Renderer:
     def _frame_key(self, batch):
         return tuple((batch[k], batch[k]._version) for k in self._FRAME_KEYS) + (batch.get("frame_token"),)
 
+    def _release_held(self, device):
+        """A render() without a ticket: the volumes of the last ticket are let go (their march is in front of this point of the
+        current stream, which is what later prefetches wait for)."""
+        if getattr(self, "_held", None) is not None:
+            self._held, self._pre_march = None, torch.cuda.Event()
+            self._pre_march.record(torch.cuda.current_stream(device))
+
     def _take_prefetched(self, batch, ticket):
         if ticket is None or any(k not in batch for k in self._FRAME_KEYS):
+            self._release_held(batch["ray_o"].device)
             return None
         key = self._frame_key(batch)
         if any(a[0] is not b[0] or a[1] != b[1] for a, b in zip(ticket[0][:-1], key[:-1])) or ticket[0][-1] != key[-1]:
+            self._release_held(batch["ray_o"].device)
             return None  # another frame, or this frame's tensors rewritten in place since: the volumes are not this batch's
         main = torch.cuda.current_stream(batch["coord"].device)
         # The volumes live in the second stream's memory pool.  They stay referenced here until the NEXT ticket is taken, and an
