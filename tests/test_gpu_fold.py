@@ -146,3 +146,19 @@ def test_points_on_every_marching_tier_match_the_fp32_kernel(kind):
     # raw logits reach |20| (alpha_fc x20 / rgb_fc x8 gains): the tolerance of test_decode_points_stages_against_oracle
     H.assert_close(got.cpu().numpy(), ref.cpu().numpy(), 1e-3, "raw %s" % kind)
     H.assert_close(dgot.cpu().numpy(), dref.cpu().numpy(), 1e-3, "density %s" % kind)
+
+
+def test_sparsify_beyond_the_two_kernel_scan():
+    """More than 4 Mi voxels: nb_exclusive_scan takes its three-kernel form (the block totals get their own pass); a handful of
+    non-zero voxels at known places, in linear order."""
+    from neuralbody_amd import ops
+
+    D, H, W, C = 66, 256, 256, 32  # 4.3 Mi voxels
+    vol = torch.zeros((D, H, W, C), device=DEV)
+    lin = torch.tensor([0, 1023, 1024, 1 << 20, (1 << 22) + 5, D * H * W - 1], device=DEV)
+    vol.view(-1, C)[lin, 7] = 1.0
+    grid, rows_lin, n_rows, cap = ops.sparsify(vol)
+    torch.cuda.synchronize()
+    assert int(n_rows) == lin.numel() and bool((rows_lin[:lin.numel()].long() == lin).all())
+    g = grid.reshape(-1)
+    assert bool((g[lin] == torch.arange(lin.numel(), device=DEV, dtype=torch.int32)).all()) and int((g >= 0).sum()) == lin.numel()
