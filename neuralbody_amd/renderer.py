@@ -150,6 +150,7 @@ class Renderer:
                                           "torch.no_grad(), as run.py:66,98 does)")
             if self.cfg.perturb > 0.0 and self.net.training and t_rand is None:
                 t_rand = torch.rand((n_batch, n_pixel, self.cfg.N_samples), device=ray_o.device)
+            self._queue_behind_prefetch(ray_o.device)
             return training.render_train(self, batch, t_rand)
         self._frame_token = batch.get("frame_token")
         ahead = self._take_prefetched(batch, prefetched) if feature_volume is None else None
@@ -158,6 +159,7 @@ class Renderer:
         else:
             sp_input = self.prepare_sp_input(batch)
             if feature_volume is None:
+                self._queue_behind_prefetch(ray_o.device)
                 feature_volume = self.net.encode_sparse_voxels(sp_input)
         b, e = (0, n_pixel) if ray_range is None else ray_range
         if self.cfg.perturb > 0.0 and self.net.training:
@@ -234,6 +236,13 @@ class Renderer:
 
     def _frame_key(self, batch):
         return tuple((batch[k], batch[k]._version) for k in self._FRAME_KEYS) + (batch.get("frame_token"),)
+
+    def _queue_behind_prefetch(self, device):
+        """An encoder pass on the current stream: a prefetched pass may be in flight on the second stream, and two passes at
+        once would race on the BatchNorm running statistics and counters — this one queues behind it."""
+        side = getattr(self, "_side_stream", None)
+        if side is not None and device.type == "cuda":
+            torch.cuda.current_stream(device).wait_stream(side)
 
     def _release_held(self, device):
         """A render() without a ticket: the volumes of the last ticket are let go (their march is in front of this point of the
