@@ -251,12 +251,16 @@ class Renderer:
             self._held, self._pre_march = None, torch.cuda.Event()
             self._pre_march.record(torch.cuda.current_stream(device))
 
+    def _ticket_is_for(self, ticket, batch):
+        """The ticket's frame tensors are the batch's: the same objects at the same version counters, the same frame token."""
+        key = self._frame_key(batch)
+        return all(a[0] is b[0] and a[1] == b[1] for a, b in zip(ticket[0][:-1], key[:-1])) and ticket[0][-1] == key[-1]
+
     def _take_prefetched(self, batch, ticket):
         if ticket is None or any(k not in batch for k in self._FRAME_KEYS):
             self._release_held(batch["ray_o"].device)
             return None
-        key = self._frame_key(batch)
-        if any(a[0] is not b[0] or a[1] != b[1] for a, b in zip(ticket[0][:-1], key[:-1])) or ticket[0][-1] != key[-1]:
+        if not self._ticket_is_for(ticket, batch):
             self._release_held(batch["ray_o"].device)
             return None  # another frame, or this frame's tensors rewritten in place since: the volumes are not this batch's
         main = torch.cuda.current_stream(batch["coord"].device)

@@ -162,3 +162,23 @@ def test_prefetch_is_an_inference_call_on_device_tensors():
         r.prefetch(batch)
     with torch.no_grad(), pytest.raises(RuntimeError, match="device tensors"):
         r.prefetch(batch)
+
+
+def test_a_ticket_belongs_to_the_frame_tensors_it_was_made_from():
+    """Renderer._ticket_is_for: identity AND version counters of coord, out_sh, bounds, R, Th, latent_index (+ the frame token);
+    the rays may differ."""
+    r = _renderer(16, 16)
+
+    def frame():
+        return {"coord": torch.zeros(1, 5, 3, dtype=torch.int32), "out_sh": torch.tensor([[8, 8, 8]], dtype=torch.int32),
+                "bounds": torch.zeros(1, 2, 3), "R": torch.eye(3)[None], "Th": torch.zeros(1, 1, 3),
+                "latent_index": torch.zeros(1, dtype=torch.long)}
+
+    a = frame()
+    ticket = (r._frame_key(a), None, None, None)
+    view = dict(a, ray_o=torch.zeros(1, 4, 3))  # another view of the same frame: same tensor objects
+    assert r._ticket_is_for(ticket, view)
+    assert not r._ticket_is_for(ticket, frame())  # equal values, other tensors
+    assert not r._ticket_is_for(ticket, dict(a, frame_token=3))
+    a["Th"].add_(1.0)  # rewritten in place after the ticket was made
+    assert not r._ticket_is_for(ticket, view)
