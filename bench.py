@@ -55,7 +55,7 @@ PRECISION_INFO = {
 
 def build_scene(dev, H=512, W=512, n_samples=64, precision=None):
     from neuralbody_amd import ops
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
     from neuralbody_amd.network import Network
     from neuralbody_amd.renderer import RenderConfig, Renderer
 
@@ -86,7 +86,7 @@ def build_poses(dev, body, bd, H, W, n_poses=N_POSES):
     """`n_poses` batches of the same frame seen from different full-coverage cameras (yaw steps around the body): rays
     generated on the device by nb_raygen, everything resident in HBM before the timed region."""
     from neuralbody_amd import ops
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     poses = []
     for i in range(n_poses):
@@ -109,14 +109,16 @@ ILL_SIGMA = 5e-4
 ILL_MAX_FRACTION = 0.005
 
 
-def parity_check(sd, net, rend, batch, n_samples, n_check=4096):
-    """rgb error of `n_check` rays spread over the view: HIP render of the FULL view vs the oracle marching the picked rays
-    through the same feature volumes (train-mode BatchNorm like the timed region).  Returns a dict:
-      linf_all        max over ALL checked rays (no exclusion)
-      linf            max over the well-conditioned rays (|sigma_last| >= ILL_SIGMA in the oracle)
+def parity_check(sd, net, rend, batch, n_samples, n_check=4096, chunk=16384, list_ill=16):
+    """rgb error of `n_check` rays spread over the view (None: EVERY ray): HIP render of the FULL view vs the oracle marching
+    the picked rays through the same feature volumes (train-mode BatchNorm like the timed region), `chunk` rays at a time.
+    Returns a dict:
+      linf_all        max over ALL checked rays (no exclusion) — what `ok` is decided on (budget 1e-4, north_star)
+      linf            max over the well-conditioned rays (|sigma_last| >= ILL_SIGMA in the oracle): a diagnostic
       n, n_ill        how many rays each of the two sets holds
-      ill             per ill-conditioned checked ray: oracle sigma_last, T_last (transmittance in front of the last sample: the
-                      bound of what a flipped alpha_last can move), the rgb error actually measured
+      ill             per ill-conditioned checked ray (the first `list_ill`): oracle sigma_last, T_last (transmittance in front of
+                      the last sample: the most a flipped alpha_last could move), the rgb error actually measured
+      ill_linf        the largest error among the ill-conditioned rays
       ill_full_view   the same criterion counted over EVERY ray of the view (from the HIP path's own raw output)."""
     from oracle import neuralbody_oracle as orc
 
@@ -124,23 +126,39 @@ def parity_check(sd, net, rend, batch, n_samples, n_check=4096):
         out = rend.render(batch, want_raw=True)
         vols = net.encode_sparse_voxels(rend.prepare_sp_input(batch))
     n = batch["ray_o"].shape[1]
-    sel = torch.linspace(0, n - 1, n_check).long()
+    if n_check is None or n_check >= n:
+        n_check = n
+        sel = torch.arange(n)
+    else:
+        sel = torch.linspace(0, n - 1, n_check).long()
     b = {k: v.detach().cpu() for k, v in batch.items()}
-    b.update(ray_o=b["ray_o"][:, sel], ray_d=b["ray_d"][:, sel], near=b["near"][:, sel], far=b["far"][:, sel])
+    vols_cpu = [v.detach().float().cpu().contiguous() for v in vols]
+    sdt = orc.tensor_state_dict(sd)
+    rgb_hip = out["rgb_map"][0].cpu()
     torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    with torch.no_grad():
-        ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=n_samples, training=True,
-                         feature_volume=[v.detach().float().cpu().contiguous() for v in vols])
-    err = (out["rgb_map"][0, sel.to(out["rgb_map"].device)].cpu() - ref["rgb_map"][0]).abs().max(1).values
-    sigma_last = ref["raw"][0].reshape(n_check, n_samples, 4)[:, -1, 3]
-    t_last = 1.0 - ref["weights"][0][:, :-1].sum(1)  # sum of the weights in front of sample i = 1 - T_i
+    errs, sig, tl = [], [], []
+    for i in range(0, n_check, chunk):
+        idx = sel[i:i + chunk]
+        bb = dict(b)
+        bb.update(ray_o=b["ray_o"][:, idx], ray_d=b["ray_d"][:, idx], near=b["near"][:, idx], far=b["far"][:, idx])
+        with torch.no_grad():
+            ref = orc.render(dict(sdt), bb, n_samples=n_samples, training=True, feature_volume=vols_cpu)
+        errs.append((rgb_hip[idx] - ref["rgb_map"][0]).abs().max(1).values)
+        sig.append(ref["raw"][0].reshape(len(idx), n_samples, 4)[:, -1, 3].clone())
+        tl.append(1.0 - ref["weights"][0][:, :-1].sum(1))  # sum of the weights in front of sample i = 1 - T_i
+        del ref
+    err, sigma_last, t_last = torch.cat(errs), torch.cat(sig), torch.cat(tl)
     ill = sigma_last.abs() < ILL_SIGMA
     raw_hip = out["raw"][0].reshape(n, n_samples, 4)[:, -1, 3]
+    worst = int(err.argmax())
     res = {"linf_all": float(err.max()), "linf": float(err[~ill].max()), "n": int(n_check - int(ill.sum())), "n_ill": int(ill.sum()),
-           "ill": [{"sigma_last": float(sigma_last[i]), "T_last": float(t_last[i]), "err": float(err[i])} for i in torch.nonzero(ill).reshape(-1)[:16]],
-           "ill_full_view": int((raw_hip.abs() < ILL_SIGMA).sum()), "rays_full_view": int(n), "ill_sigma": ILL_SIGMA}
-    res["ok"] = bool(res["linf"] <= 1e-4 and res["n_ill"] <= ILL_MAX_FRACTION * n_check and
-                     all(e["err"] <= e["T_last"] + 1e-4 for e in res["ill"]))
+           "n_checked": int(n_check), "worst_ray": int(sel[worst]),
+           "ill": [{"ray": int(sel[i]), "sigma_last": float(sigma_last[i]), "T_last": float(t_last[i]), "err": float(err[i])}
+                   for i in torch.nonzero(ill).reshape(-1)[:list_ill]],
+           "ill_linf": float(err[ill].max()) if bool(ill.any()) else 0.0,
+           "ill_full_view": int((raw_hip.abs() < ILL_SIGMA).sum()), "rays_full_view": int(n), "ill_sigma": ILL_SIGMA,
+           "rays_over_1e-5": int((err > 1e-5).sum()), "rays_over_5e-5": int((err > 5e-5).sum())}
+    res["ok"] = bool(res["linf_all"] <= 1e-4)
     return res
 
 
@@ -212,7 +230,7 @@ def cpu_reference_baseline(args, budget_s=15.0, max_rays=8192):
     rays and the same feature volumes.  Runs WITHOUT a GPU and only where /root/reference exists (the build container): the
     tree cannot travel to the GPU box, where `cpu_baseline.kind` stays "port".  This run pins the port's speed to the
     reference's on the same host: the JSON it prints is committed under profiles/."""
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
     from oracle import neuralbody_oracle as orc
     from oracle import ref_harness as rh
 
@@ -269,11 +287,27 @@ def cpu_reference_baseline(args, budget_s=15.0, max_rays=8192):
             "port_value": out["port"][0], "port_over_reference": out["port"][0] / v, "rgb_linf_port_vs_reference_first_chunk": diff}
 
 
+def fullview_parity(args, dev):
+    """`--mode fullview-parity`: EVERY ray (or --n-check rays) of one timed view against the oracle — the record behind the claim
+    that the ill-conditioned-ray diagnostic of parity_check is never needed.  ~2.5 min of CPU for 512 x 512
+    x 64."""
+    H = W = args.size
+    sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
+    poses = build_poses(dev, body, bd, H, W)
+    t0 = time.perf_counter()
+    par = parity_check(sd, net, rend, poses[1], args.samples, n_check=args.n_check, list_ill=1 << 20)
+    return {"metric": "fullview_parity_rgb_linf", "value": par["linf_all"], "unit": "rgb L-inf vs the CPU oracle", "higher_is_better": False,
+            "budget": 1e-4, "precision": net.march_precision(), "seconds": time.perf_counter() - t0,
+            "config": {"workload": "synthetic 6890-vertex SMPL scene, %dx%d full-coverage view (pose 1 of the timed cycle), %d samples/ray; "
+                                   "%d of %d rays checked" % (H, W, args.samples, par["n_checked"], par["rays_full_view"])},
+            "parity": par}
+
+
 def train_bench(args, dev):
     """Config 4 of BASELINE.json in synthetic form: one training step = NetworkWrapper-style forward (1024 random rays x
     64 jittered samples of the 6890-vertex scene) + MSE loss + backward through decoder and encoder + clip + Adam.
     Informational (the headline metric is the render throughput): prints its own JSON line."""
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     sd, body, net, rend, bd, n_rays = build_scene(dev, args.size, args.size, args.samples, "f32")
     rend.cfg.perturb = 1.0
@@ -323,7 +357,7 @@ def turntable_bench(args, dev):
     as nb_raygen -> Renderer.render (encoder + march) -> nb_image_assemble, i.e. finished images on the device; the 4-byte ray
     count of a view is read one view ahead (NovelViewRenderer.render_views).  Informational: prints its own JSON line."""
     from neuralbody_amd import novel_view as nv
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     H = W = args.size
     sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
@@ -335,19 +369,32 @@ def turntable_bench(args, dev):
     path = nv.gen_path(train, args.steps + args.warmup, center=body["world_verts"].mean(0).astype(np.float64))
     frame = {k: v for k, v in bd.items() if k in ("coord", "out_sh", "bounds", "R", "Th", "latent_index")}
     nvr = nv.NovelViewRenderer(rend, H, W, dev, reuse_volumes=args.reuse_volumes)
+    from neuralbody_amd import ops
+
     rays = 0
     for RT in path[:args.warmup]:
         nvr.render_view(K, RT, body["can_bounds"], frame)
     torch.cuda.synchronize()
+    ops.MARCH_EVENTS = []
     t0 = time.perf_counter()
     for view in nvr.render_views(((K, RT, body["can_bounds"], frame) for RT in path[args.warmup:]), bgr=True, scale=255.0):
         rays += view["n_rays"]
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    events, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
+    march_ms = float(np.mean([a.elapsed_time(b) for a, b in events])) if events else float("nan")
+    dtype, kernel_name, exec_flop, peak = PRECISION_INFO[net.march_precision()]
+    mean_rays = rays / args.steps
+    achieved = FLOP_PER_SAMPLE * mean_rays * args.samples / (march_ms * 1e-3) / 1e12
     return ({"metric": "turntable_views_per_sec", "value": args.steps / dt, "unit": "views/s", "higher_is_better": True,
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_view": dt / args.steps * 1e3,
                       "rays_per_sec": rays / dt, "ray_samples_per_sec": rays * args.samples / dt,
-                      "mean_rays_per_view": rays / args.steps,
+                      "mean_rays_per_view": mean_rays, "dtype": dtype, "data": "synthetic",
+                      # the march of a spiral view covers fewer rays than the full-coverage bench view (the body's box does not
+                      # fill every pixel): algorithmic flops of the rays actually marched / the average march launch (HIP events)
+                      "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                                   "frac": achieved / peak, "traffic": None, "avg_launch_ms": march_ms, "launches": len(events),
+                                   "executed_frac": exec_flop * mean_rays * args.samples / (march_ms * 1e-3) / 1e12 / peak},
                       "config": {"workload": "synthetic spiral path, %dx%d, %d samples/ray: raygen + encoder + march + image "
                                              "assembly per view, all on device%s" % (H, W, args.samples, "; frame encoded once" if args.reuse_volumes else "")}})
 
@@ -391,6 +438,9 @@ def extras(args, dev):
         ex["%s_ms_per_view" % prec] = e0.elapsed_time(e1) / 3
         ex["%s_march_ms" % prec] = march
         ex["%s_roofline_frac" % prec] = FLOP_PER_SAMPLE * n_rays * args.samples / (march * 1e-3) / 1e12 / peak
+        # the numerator above is the reference's algebra; the kernel issues fewer flops (merged colour head, latent
+        # code as a bias), so the fraction of ITS OWN work over the peak is the occupancy figure — a frac above 1 is accounting
+        ex["%s_executed_frac" % prec] = PRECISION_INFO[prec][2] * n_rays * args.samples / (march * 1e-3) / 1e12 / peak
         del net, rend
     ex.update(culled_bench(args, dev))
     ex.update(encoder_bench(args, dev))
@@ -402,7 +452,7 @@ def culled_bench(args, dev):
     training-view silhouettes) on the capsule body with synthetic silhouettes, as in the fixtures: ms per view and the share of
     samples that survive the culling."""
     from neuralbody_amd import ops
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
     from neuralbody_amd.network import Network
     from neuralbody_amd.renderer import RenderConfig, RendererMmsk, RendererMsk
 
@@ -499,7 +549,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="encode and march strictly one after the other on one stream")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational turntable / train-step legs of the JSON line")
     ap.add_argument("--reuse-volumes", action="store_true", help="turntable mode: encode the frame once for all views")
-    ap.add_argument("--mode", default="render", choices=["render", "train", "turntable", "cpu-reference"])
+    ap.add_argument("--mode", default="render", choices=["render", "train", "turntable", "cpu-reference", "fullview-parity",
+                                                         "cpu-reference-train"])
+    ap.add_argument("--n-check", type=int, default=None, help="fullview-parity: rays checked (default: every ray of the view)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -528,6 +580,9 @@ def main():
         if world != 1:
             raise SystemExit("--mode train is a single-GPU informational run")
         print(json.dumps(train_bench(args, dev)))
+        return
+    if args.mode == "fullview-parity":
+        print(json.dumps(fullview_parity(args, dev)))
         return
     if args.mode == "turntable":
         if world != 1:

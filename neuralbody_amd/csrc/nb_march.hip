@@ -29,9 +29,7 @@
 
 using namespace nbm;
 
-#ifndef NB_PF
-#define NB_PF 8
-#endif
+#define NB_PF 8  // weight fragments in flight per wave
 #define NB_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 namespace {

@@ -259,12 +259,7 @@ __device__ __forceinline__ void gather_level(const SceneDev &sc, const GridCoord
         const bool inb = (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H && (unsigned)zz < (unsigned)D;
         cw[corner] = inb ? (wx[dx] * wy[dy]) * wz[dz] : 0.f;
         const int xc = min(max(xx, 0), W - 1), yc = min(max(yy, 0), H - 1), zc = min(max(zz, 0), D - 1);
-#ifdef NB_ABL_SAMEVOX
-        cp[corner] = reinterpret_cast<const f32x4 *>(
-            vb + ((size_t)__builtin_amdgcn_readfirstlane((zc * H + yc) * W + xc)) * C);
-#else
         cp[corner] = reinterpret_cast<const f32x4 *>(vb + ((size_t)(zc * H + yc) * W + xc) * C);
-#endif
     }
 #pragma unroll
     for (int grp = 0; grp < HALF / 16; ++grp) {

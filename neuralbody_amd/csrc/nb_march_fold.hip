@@ -36,6 +36,7 @@
 // Per-sample work (ray set-up, positional encoding, compositing) is done by "owner" lanes: wave w, lane l owns sample
 // 16 w + (l & 15) and, of that sample, pyramid level / axis `part` = l >> 4.
 #include "nb_f6_ops.h"
+#include "nb_march_hooks.h"
 
 using namespace nbm;
 
@@ -697,17 +698,6 @@ __device__ __forceinline__ void fold_mma(const FoldFrags &f, f32x16 (&acc)[2][2]
 __device__ __forceinline__ void fold_mfma(const MarchArgs &a, char *actz, int lane, int wave, const UCfg &u, f32x16 (&acc)[2][2],
                                           unsigned *tbuf = nullptr) {
     if (u.nch == 0) return;  // uniform
-#ifdef FOLD_TIMING
-#define FOLD_SUB(i)                                                     \
-    do {                                                                \
-        if (tbuf) {                                                     \
-            const unsigned long long t__ = __builtin_readcyclecounter(); \
-            if (lane == 0) tbuf[(i)] = (unsigned)t__;                   \
-        }                                                               \
-    } while (0)
-#else
-#define FOLD_SUB(i) do { } while (0)
-#endif
     FOLD_SUB(17);
     const int l15 = lane & 15, g4 = lane >> 4;
     const int tro = (g4 >> 1) * 512 + (g4 & 1) * 128 + (l15 >> 2) * 32 + (l15 & 3) * 8;
@@ -718,9 +708,7 @@ __device__ __forceinline__ void fold_mfma(const MarchArgs &a, char *actz, int la
     fold_wait(issued);
     FOLD_SUB(18);
     fold_read(f0, ring, wt);
-#ifdef FOLD_TIMING
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0.ah[0]), "+v"(f0.bl[1])::"memory");
-#endif
+    NB_HOOK_FOLD_FIRST_READ(f0);
     FOLD_SUB(19);
     auto step = [&](FoldFrags &cur, FoldFrags &nxt, int c, int slot) {
         if (c + u.R < u.nch) {  // uniform: refill this chunk's slot; its reads must have returned
@@ -797,14 +785,12 @@ __device__ __forceinline__ void composite_step(char *actz, const float *pk, int 
         recf[12 + part] = fmaf(w, 1.f / (1.f + expf(-o)), col);
     }
     wstore.push(a, ray, sidx, S, part, valid, w);
-#if !defined(FOLD_TAP) && !defined(FOLD_TIMING)
-    if (a.raw && valid && part == 0) {  // uniform in a.raw
+    if (NB_HOOK_RAW_IS_OUTPUT && a.raw && valid && part == 0) {  // uniform in a.raw
         float o3[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) o3[ch] = ins ? head_sum(actz, SCR_C + (ch * 64 + sample) * 16, pk[P_RB + ch]) : 0.f;
         *reinterpret_cast<f32x4 *>(a.raw + (ray * S + sidx) * 4) = f32x4{o3[0], o3[1], o3[2], sigma_raw};
     }
-#endif
 }
 
 // view_fc column of encoding slot `slot` (0..31) of axis a: [x, (sin, cos)(x 2^k) k<10, v, (sin, cos)(v 2^k) k<4, 0, 0]; -1 = zero pad
@@ -821,33 +807,8 @@ __host__ __device__ inline int pe_slot_col(int a, int slot) {
 }
 
 // ---------------------------------------------------------------- the kernel
-// FOLD_TAP (debug builds, tools/experiments/fold_check.py tap): workgroup 0 dumps, at depth step 0, every layer's accumulators
-// as [layer][feature][sample] fp32 into a.raw instead of the raw output (fc_0, fc_1, fc_2 pre-activation: 3 x 256 x 64;
-// folded view layer: 128 x 64), to be compared with nb_decode_points' fp32 activation tap
-#ifdef FOLD_TAP
-#define FOLD_DUMP(LAYER, MT_)                                                                                             \
-    if (blockIdx.x == 0 && s == 0 && a.raw) {                                                                            \
-        for (int m = 0; m < (MT_); ++m)                                                                                   \
-            for (int n = 0; n < 2; ++n)                                                                                   \
-                for (int r = 0; r < 16; ++r)                                                                              \
-                    a.raw[((LAYER) * 256 + 32 * ((MT_) * wave + m) + tile_row(r, hi)) * 64 + n * 32 + (lane & 31)] = acc[m][n][r]; \
-    }
-#else
-#define FOLD_DUMP(LAYER, MT_)
-#endif
-// FOLD_TIMING (experiment builds, tools/experiments/fold_phase_times.py): wave 0 of the first 32 workgroups stamps the cycle
-// counter at the phase boundaries of every depth step into the `raw` output as [workgroup][step][32]
-#ifdef FOLD_TIMING
-#define FOLD_STAMP(i)                                                   \
-    do {                                                                \
-        if (tbuf) {                                                     \
-            const unsigned long long t__ = __builtin_readcyclecounter(); \
-            if (lane == 0) tbuf[(i)] = (unsigned)t__;                   \
-        }                                                               \
-    } while (0)
-#else
-#define FOLD_STAMP(i) do { } while (0)
-#endif
+// FOLD_STAMP / FOLD_SUB / FOLD_DUMP: empty in the product build (nb_march_hooks.h); experiment builds pre-include
+// tools/experiments/fold_instrument.h (cycle stamps at the phase boundaries, per-layer accumulator taps)
 // MODE 0: rays (nb_march).  MODE 1 / 2: explicit points (nb_decode_points, raw [n,4] / density [n,1]): a point with its view
 // direction is a one-sample "ray" (origin = the point, direction = the view direction taken as given, z = 0) whose decoder
 // output is stored instead of composited; MODE 2 stops behind alpha_fc.
@@ -998,9 +959,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
         const bool ins_cur = ins;
         float z_next = 0.f;
         int tier_next = 0, active_next = 1;
-#ifdef FOLD_TIMING
-        unsigned *tbuf = (blockIdx.x < 32 && wave == 0 && a.raw) ? reinterpret_cast<unsigned *>(a.raw) + ((size_t)blockIdx.x * S + s) * 32 : nullptr;
-#endif
+        NB_HOOK_STEP_BEGIN;
         FOLD_STAMP(0);
         __syncthreads();  // Wt is visible
         FOLD_STAMP(1);
@@ -1010,11 +969,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
             init_bias<2>(pk + P_B0, 2 * wave, hi, acc);
             if (tier == 0) {
                 const UCfg u = ucfg(actz, lds_base, wave);
-#ifdef FOLD_TIMING
-                fold_mfma(a, actz, lane_i, wave, u, acc, tbuf);
-#else
-                fold_mfma(a, actz, lane_i, wave, u, acc);
-#endif
+                fold_mfma(a, actz, lane_i, wave, u, acc, NB_HOOK_TBUF);
             } else if (tier == 3) {
                 // a list of up to KM_CAP voxels (points that are neighbours but not dense, wide pixel footprints): the same boxes,
                 // marched in passes of K_CAP voxels, each through table -> U -> Wt -> MFMA

@@ -405,7 +405,7 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ fused march
     def render_rays(self, ray_o, ray_d, near, far, feature_volume, sp_input, n_samples, t_rand=None,
-                    white_bkgd=False, want_raw=False, ray_order=None, cull=None):
+                    white_bkgd=False, want_raw=False, ray_order=None, cull=None, order_covers_all=False):
         """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
         prec = self.march_precision()
         scene = self.make_scene(feature_volume, sp_input, prec)
@@ -417,4 +417,4 @@ class Network(nn.Module):
             self._t_vals[key] = t_vals
         return ops.march(scene, self.packed_weights(prec), lb, ray_o, ray_d, near, far, t_vals, t_rand,
                          white_bkgd=white_bkgd, want_raw=want_raw, precision=prec, ray_order=ray_order,
-                         cull=cull)
+                         cull=cull, order_covers_all=order_covers_all)

@@ -217,8 +217,10 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
 
 
 def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=None, white_bkgd=False,
-          want_raw=False, precision="f32", ray_order=None, cull=None):
-    """nb_march: all rays of one batch element -> dict of per-ray outputs."""
+          want_raw=False, precision="f32", ray_order=None, cull=None, order_covers_all=False):
+    """nb_march: all rays of one batch element -> dict of per-ray outputs.  With a `ray_order` the kernel stores only the rays
+    its slots name: unless the caller vouches that every ray has a slot (`order_covers_all`, e.g. the slot list of a fully
+    covered image) the outputs start out as zeros, so a ray without a slot reads 0 and never uninitialised memory."""
     sc, _keep = scene
     _req(packed, torch.float32, (mlp_pack_size(),), "packed")
     _req(latent_bias, torch.float32, (int(_lib.lib().nb_mlp_latent_bias_size()),), "latent_bias")
@@ -238,12 +240,13 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
         if n_slots == 0 or n_slots % 64:
             raise ValueError("ray_order holds %d slots: a positive multiple of 64 (ops.tile_slots)" % n_slots)
     dev = ray_o.device
-    rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    disp = torch.empty((n,), dtype=torch.float32, device=dev)
-    acc = torch.empty((n,), dtype=torch.float32, device=dev)
-    weights = torch.empty((n, S), dtype=torch.float32, device=dev)
-    depth = torch.empty((n,), dtype=torch.float32, device=dev)
-    raw = torch.empty((n, S, 4), dtype=torch.float32, device=dev) if want_raw else None
+    alloc = torch.zeros if (ray_order is not None and not order_covers_all) else torch.empty
+    rgb = alloc((n, 3), dtype=torch.float32, device=dev)
+    disp = alloc((n,), dtype=torch.float32, device=dev)
+    acc = alloc((n,), dtype=torch.float32, device=dev)
+    weights = alloc((n, S), dtype=torch.float32, device=dev)
+    depth = alloc((n,), dtype=torch.float32, device=dev)
+    raw = alloc((n, S, 4), dtype=torch.float32, device=dev) if want_raw else None
     ev = None
     if MARCH_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

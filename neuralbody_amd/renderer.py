@@ -151,7 +151,9 @@ class Renderer:
             if self.cfg.perturb > 0.0 and self.net.training and t_rand is None:
                 t_rand = torch.rand((n_batch, n_pixel, self.cfg.N_samples), device=ray_o.device)
             self._queue_behind_prefetch(ray_o.device)
-            return training.render_train(self, batch, t_rand)
+            ret = training.render_train(self, batch, t_rand)
+            self._mark_inline_encode(ray_o.device)
+            return ret
         self._frame_token = batch.get("frame_token")
         ahead = self._take_prefetched(batch, prefetched) if feature_volume is None else None
         if ahead is not None:
@@ -161,6 +163,7 @@ class Renderer:
             if feature_volume is None:
                 self._queue_behind_prefetch(ray_o.device)
                 feature_volume = self.net.encode_sparse_voxels(sp_input)
+                self._mark_inline_encode(ray_o.device)
         b, e = (0, n_pixel) if ray_range is None else ray_range
         if self.cfg.perturb > 0.0 and self.net.training:
             if t_rand is None:
@@ -169,11 +172,15 @@ class Renderer:
         else:
             tr = None
         ray_order = self._tile_order(batch, n_pixel, b, e)
+        # a fully covered image's slot list names every ray of the range by construction; a mask-derived list names as many rays
+        # as the mask holds pixels, which the batch may contradict (then the surplus rays read 0: ops.march zero-fills)
+        covers = ray_order is not None and n_pixel == int(getattr(self.cfg, "H", 0) or 0) * int(getattr(self.cfg, "W", 0) or 0)
         cull = self.make_cull(batch)
         noisy = self.cfg.raw_noise_std != 0.0
         ret = self.net.render_rays(ray_o[0, b:e].contiguous(), ray_d[0, b:e].contiguous(), near[0, b:e].contiguous(),
                                    far[0, b:e].contiguous(), feature_volume, sp_input, self.cfg.N_samples, t_rand=tr,
-                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw or noisy, ray_order=ray_order, cull=cull)
+                                   white_bkgd=self.cfg.white_bkgd, want_raw=want_raw or noisy, ray_order=ray_order, cull=cull,
+                                   order_covers_all=covers)
         if noisy:
             # raw_noise_std > 0 (nerf_net_utils.py:31-35; no shipped config): the march delivers `raw`, the noise is added to the
             # densities and the rays are composited again by nb_composite with the z values of the same sampling
@@ -224,6 +231,11 @@ class Renderer:
         pre = getattr(self, "_pre_march", None)
         if pre is not None:
             side.wait_event(pre)  # whatever `after` is: never in front of the march before the one being enqueued / just enqueued
+        inl = getattr(self, "_inline_enc", None)
+        if inl is not None:
+            # ... and never beside an encoder pass that a render() ran inline on the main stream (first view of a loop, a ticket
+            # that did not match, a training step): both would update the BatchNorm running statistics in place
+            side.wait_event(inl)
         self._frame_token = batch.get("frame_token")
         with torch.cuda.stream(side):
             sp_input = self.prepare_sp_input(batch)
@@ -243,6 +255,13 @@ class Renderer:
         side = getattr(self, "_side_stream", None)
         if side is not None and device.type == "cuda":
             torch.cuda.current_stream(device).wait_stream(side)
+
+    def _mark_inline_encode(self, device):
+        """An encoder pass was just enqueued on the current stream: later prefetches queue behind it (the other direction of
+        `_queue_behind_prefetch`)."""
+        if device.type == "cuda":
+            self._inline_enc = torch.cuda.Event()
+            self._inline_enc.record(torch.cuda.current_stream(device))
 
     def _release_held(self, device):
         """A render() without a ticket: the volumes of the last ticket are let go (their march is in front of this point of the

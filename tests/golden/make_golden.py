@@ -97,7 +97,7 @@ def run_raygen():
     """get_rays / get_near_far (if_nerf_data_utils.py:8-21,54-69) and image_rays
     (render_utils.py:120-137) on a non-square camera."""
     ns = rh.load()
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     g = {}
     for tag, body_kw, H, W, ff in (("a", dict(seed=3, box=(0.9, 1.7, 0.35), rh=(0.2, 0.4, 0.0), th=(0.3, 0.1, 0.2)), 40, 56, 1.1),

@@ -2,7 +2,7 @@
 and by the tests (which regenerate the identical inputs from the seeds)."""
 import numpy as np
 
-from neuralbody_amd import synthetic as syn
+from tests import synthetic as syn
 
 _SMALL_BODY = dict(seed=0, box=(0.3, 0.5, 0.2), rh=(0.1, 0.2, -0.1), th=(0.05, -0.1, 0.2))
 _SMALL_CAM = dict(H=32, W=32, focal_factor=2.5, distance=1.5)

@@ -123,7 +123,7 @@ def load_plugin(fname, cfg=None):
 
 def training_batch(seed=0, n_rand=1024, size=64, latent_index=2, dev="cuda:0"):
     """(state_dict_np, device batch) of one synthetic training iteration: n_rand random rays of one frame + rgb targets."""
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     sd = syn.make_weights(seed, num_train_frame=5)
     body = syn.make_body(seed=seed, box=(0.3, 0.5, 0.2))

@@ -86,7 +86,7 @@ def test_missing_library_is_an_error(monkeypatch, tmp_path):
 
 def test_network_state_dict_matches_reference_keys():
     """120 entries with the reference's names/shapes (SURVEY.md §5 checkpoint row)."""
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
     from neuralbody_amd.network import Network
 
     sd_ref = syn.make_weights(0, num_train_frame=5)

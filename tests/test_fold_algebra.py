@@ -11,7 +11,7 @@ march interpolates the 256-channel result (as a matrix product with the sparse t
 import numpy as np
 import torch
 
-from neuralbody_amd import synthetic as syn
+from tests import synthetic as syn
 from oracle import neuralbody_oracle as orc
 
 

@@ -346,7 +346,7 @@ def test_network_wrapper_training_steps_reduce_loss():
     import sys
     import types
 
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     # the plugin imports the reference's `lib.config.cfg`; stand in for it (the GPU box has no reference tree)
     cfgmod = types.ModuleType("lib.config")

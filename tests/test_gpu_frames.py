@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from neuralbody_amd import synthetic as syn
+from tests import synthetic as syn
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu

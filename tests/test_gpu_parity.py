@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from tests import helpers as H
-from neuralbody_amd import synthetic as syn
+from tests import synthetic as syn
 from tests.golden import scenes
 
 pytestmark = pytest.mark.gpu
@@ -586,7 +586,7 @@ def test_density_cube_matches_reference(precision, monkeypatch):
 # ------------------------------------------------------------------------------------------- ray generation
 def test_raygen_matches_reference_golden():
     from neuralbody_amd import ops
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     g = np.load(H.GOLDEN + "/raygen.npz")
     for tag, body_kw, Hh, Ww, ff in (("a", dict(seed=3, box=(0.9, 1.7, 0.35), rh=(0.2, 0.4, 0.0), th=(0.3, 0.1, 0.2)), 40, 56, 1.1),
@@ -613,7 +613,7 @@ def test_full_size_properties_512(precision):
     """BASELINE.json headline shape (512x512, 64 samples, 6890 vertices): size-independent properties —
     sharding invariance (any contiguous ray range reproduces the full render bit for bit), permutation
     equivariance, sum(weights) == acc, finite outputs, and spot parity with the oracle on a ray sample."""
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
     from neuralbody_amd.renderer import RenderConfig, Renderer
     from oracle import neuralbody_oracle as orc
 

@@ -86,7 +86,7 @@ def test_oracle_render_matches_reference_golden(name, golden_dir):
 
 
 def test_oracle_raygen_matches_reference_golden(golden_dir):
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
 
     g = np.load(os.path.join(golden_dir, "raygen.npz"))
     for tag, body_kw, H, W, ff in (("a", dict(seed=3, box=(0.9, 1.7, 0.35), rh=(0.2, 0.4, 0.0), th=(0.3, 0.1, 0.2)), 40, 56, 1.1),

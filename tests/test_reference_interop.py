@@ -17,7 +17,7 @@ PLUGINS = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 
 
 def test_reference_checkpoint_round_trip(tmp_path):
-    from neuralbody_amd import synthetic as syn
+    from tests import synthetic as syn
     from neuralbody_amd.network import Network
 
     ns = rh.load()

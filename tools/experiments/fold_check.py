@@ -1,7 +1,7 @@
 """First-light checks of the fc_0-folded march (precision 'f16f6', nb_fold.hip + nb_march_fold.hip) on the GPU:
 
     python tools/experiments/fold_check.py [rows] [points] [small] [full] [time]
-    NB_LIB_PATH=neuralbody_amd/lib/libnb_hip_tap.so python tools/experiments/fold_check.py tap     (build with -DFOLD_TAP)
+    NB_LIB_PATH=neuralbody_amd/lib/libnb_hip_tap.so python tools/experiments/fold_check.py tap     (build with NB_EXTRA_FLAGS="-DFOLD_TAP -include tools/experiments/fold_instrument.h")
 
 rows    U rows of nb_fold_build against fp32 torch (V_rows @ fc_0[:, level]^T), index grids, the zero row, nb_sparsify
 points  nb_decode_points f16f6 against f32: coherent lattice points (one pass), scattered points (sample groups), outside points
@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from neuralbody_amd import ops  # noqa: E402
-from neuralbody_amd import synthetic as syn  # noqa: E402
+from tests import synthetic as syn  # noqa: E402
 from tests import helpers as H  # noqa: E402
 from tests.golden import scenes  # noqa: E402
 

@@ -1,6 +1,6 @@
 """Cycle budget of one depth step of the fc_0-folded march (experiment build -DFOLD_TIMING: wave 0 of the first 32 workgroups
 stamps the cycle counter at its phase boundaries into the `raw` output).
-    NB_EXTRA_FLAGS=-DFOLD_TIMING NB_LIB_SUFFIX=_timing python -m neuralbody_amd.build
+    NB_EXTRA_FLAGS="-DFOLD_TIMING -include tools/experiments/fold_instrument.h" NB_LIB_SUFFIX=_timing python -m neuralbody_amd.build
     NB_LIB_PATH=neuralbody_amd/lib/libnb_hip_timing.so python tools/experiments/fold_phase_times.py"""
 import os
 import sys

@@ -112,6 +112,14 @@ def _fp6_weights(W):
     return _unblocks(_minifloat(blk / scale, 3, 0, 7.5) * scale, 1, sh, shp)
 
 
+def _fp4_weights(W):
+    """fp4 e2m1 (0, 0.5, 1, 1.5, 2, 3, 4, 6), pack-time scale per (row, 32 K): the smallest power of two with max|block| / scale <= 6"""
+    blk, sh, shp = _blocks(W, 1)
+    amax = blk.abs().amax(-1, keepdim=True).clamp_min(1e-38)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 6.0)))
+    return _unblocks(_minifloat(blk / scale, 1, 0, 6.0) * scale, 1, sh, shp)
+
+
 def _bf6_acts(Xh, Xl):
     """bf6 e3m2 (max 28) of the head and the remainder; run-time scale per (sample, 32 K) = 2^(exponent of the head
     block's maximum - 3) (block max lands in [8, 16)); the remainder block uses that scale * 2^-11"""
@@ -139,7 +147,7 @@ def mm(W, X, scheme):
         return _bf16(W) @ _bf16(X)
     if scheme == "f16x1":
         return _f16(W) @ _f16(X)
-    if scheme in ("bf16x3", "f16x3", "f16x2w", "f16x2x", "f16c8", "f16c8s", "f16c8b", "f16c6", "f16c6w", "f16c6x", "f16c6-wl", "f16c6-xl"):
+    if scheme in ("bf16x3", "f16x3", "f16x2w", "f16x2x", "f16c8", "f16c8s", "f16c8b", "f16c6", "f16c6w", "f16c6x", "f16c6-wl", "f16c6-xl", "f16c4", "f16c4h", "f16c4l"):
         r = _bf16 if scheme == "bf16x3" else _f16
         Wh, Xh = r(W), r(X)
         Wl, Xl = r(W - Wh), r(X - Xh)
@@ -154,6 +162,11 @@ def mm(W, X, scheme):
         if scheme == "f16c6":
             q_xh, q_xl = _bf6_acts(Xh, Xl)
             return Wh @ Xh + _fp6_weights(Wh) @ q_xl + _fp6_weights(Wl) @ q_xh
+        if scheme in ("f16c4", "f16c4h", "f16c4l"):  # round 5: the cross terms' WEIGHT operands in fp4 e2m1 (both / W_h only / W_l only)
+            q_xh, q_xl = _bf6_acts(Xh, Xl)
+            qh = _fp4_weights(Wh) if scheme != "f16c4l" else _fp6_weights(Wh)
+            ql = _fp4_weights(Wl) if scheme != "f16c4h" else _fp6_weights(Wl)
+            return Wh @ Xh + qh @ q_xl + ql @ q_xh
         if scheme == "f16c6-wl":  # the W_l cross term dropped (weights rounded to fp16)
             return Wh @ Xh + _fp6_weights(Wh) @ _bf6_acts(Xh, Xl)[1]
         if scheme == "f16c6-xl":  # the X_l cross term dropped (activations rounded to fp16)
@@ -271,6 +284,7 @@ def main():
     ap.add_argument("--quick", action="store_true", help="only the candidate shipping mixes")
     ap.add_argument("--levels", action="store_true", help="fc_0 sensitivity per pyramid level (one or both cross terms dropped)")
     ap.add_argument("--drop", action="store_true", help="round 4: one cross term of one layer dropped")
+    ap.add_argument("--fp4", action="store_true", help="round 5: fp4 e2m1 weight operands in the cross terms (a third less weight stream)")
     ap.add_argument("--fold", action="store_true", help="round 4: fc_0 folded into the volume (fp16 head + remainder planes; heads only)")
     a = ap.parse_args()
     torch.set_num_threads(8)
@@ -304,6 +318,27 @@ def main():
         report("fc_0 folded (pairs), everything else exact fp32", mix)
         mix["fc_0"] = "fold_h"
         report("fc_0 folded (heads only), everything else exact fp32", mix)
+        if a.out:
+            with open(a.out, "w") as f:
+                f.write("\n".join(lines) + "\n")
+        return
+    if a.fp4:
+        base = {k: "f16c6" for k in LAYERS}
+        base.update(fold=True, fc_0="fold", view_pe="f16c6")
+        report("shipped round 4 (fp6 e2m3 weights in both cross terms)", base)
+        for sc, tag in (("f16c4", "fp4 e2m1 weights in both cross terms"), ("f16c4h", "fp4 for W_h (x X_l) only"), ("f16c4l", "fp4 for W_l (x X_h) only")):
+            mix = dict(base)
+            for l in ("fc_1", "fc_2", "view_fc", "view_pe"):
+                mix[l] = sc
+            report("%s, every layer behind fc_0" % tag, mix)
+        for layer in ("fc_1", "fc_2", "view_fc", "view_pe"):
+            mix = dict(base)
+            mix[layer] = "f16c4"
+            report("fp4 weights in both cross terms of %s only" % layer, mix)
+        mix = dict(base)
+        for l in ("fc_1", "fc_2", "view_fc"):
+            mix[l] = "f16c4"
+        report("fp4 in fc_1, fc_2, colour head over fc_2; encodings fp6", mix)
         if a.out:
             with open(a.out, "w") as f:
                 f.write("\n".join(lines) + "\n")

@@ -2,7 +2,8 @@ import os, sys, time, types
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
-from neuralbody_amd import novel_view as nv, synthetic as syn, ops
+from neuralbody_amd import novel_view as nv, ops
+from tests import synthetic as syn
 dev = torch.device("cuda:0")
 torch.set_grad_enabled(False)
 H = W = 512
