@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 17
+#define NB_ABI_VERSION 18
 
 /* arithmetic of the decoder (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0   /* exact fp32 on v_mfma_f32_32x32x2_f32, trilinear gather of the dense volumes on the VALU: the reference's
@@ -141,9 +141,15 @@ int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *o
  * Network.calculate_density_color (lib/networks/latent_xyzc.py:99, `self.fc_0(features)`) together with the four
  * F.grid_sample calls feeding it (:62-72), by pre-multiplying every ACTIVE voxel of the four volumes with fc_0.
  *   vol[l] dev channels-last [D_l,H_l,W_l,C_l] fp32 (nb_scene.vol); rows_lin[l] dev [n_rows_max[l]] int32: linear voxel index
- *   of each active row; n_rows[l] dev [1] int32 (device-side count, <= n_rows_max[l]); fc0_w dev [256,352] fp32 row-major;
+ *   of each active row — or rows_lin[l] NULL: vol[l] then holds the level's ACTIVE ROWS themselves, compact [n_rows_max[l], C_l]
+ *   (what the encoder produces before `.dense()`, latent_xyzc.py:188-201: no dense volume need exist for this arithmetic);
+ *   n_rows[l] dev [1] int32 (device-side count, <= n_rows_max[l]); fc0_w dev [256,352] fp32 row-major;
  *   urows dev [(sum of n_rows_max) + 1][512] uint16: level l's rows start at row sum_{k<l} n_rows_max[k]; the last row is
- *   zero-filled by the call.  Exact fp32 products (v_mfma_f32_32x32x2_f32), then head = fp16(u), remainder = fp16(u - head).
+ *   zero-filled by the call (sum of n_rows_max < 2^21).  Exact fp32 products (v_mfma_f32_32x32x2_f32), then head = fp16(u),
+ *   remainder = fp16(u - head).  n_saturated dev [1] int32 or NULL, ZEROED BY THE CALLER (the call adds to it; the
+ *   encoder's one zero fill covers it): how many products were beyond the fp16 range (+-65504: clamped) or not finite (a NaN
+ *   product stays NaN in the planes) — the planes then do not carry fc_0 . V, use
+ *   NB_PREC_F32 for such weights / volumes.
  * nb_sparsify — active set of a DENSE volume that did not come with one (volumes handed to Network.calculate_density_color by a
  * caller other than encode_sparse_voxels): a voxel is active iff any channel is non-zero.  grid dev [D*H*W] int32 out (row id
  * or -1), rows_lin dev [n_rows_max] out (linear-voxel order), n_rows dev [1] out (clamped to n_rows_max; rows beyond it are
@@ -151,7 +157,7 @@ int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *o
  * ------------------------------------------------------------------------------- */
 int nb_fold_build(const float *const vol[NB_N_LEVELS], const int32_t *const rows_lin[NB_N_LEVELS],
                   const int32_t *const n_rows[NB_N_LEVELS], const int32_t n_rows_max[NB_N_LEVELS], const float *fc0_w,
-                  uint16_t *urows, void *stream);
+                  uint16_t *urows, int32_t *n_saturated, void *stream);
 int nb_sparsify(const float *vol, const int32_t dhw[3], int32_t c, int32_t *grid, int32_t *rows_lin, int32_t *n_rows,
                 int32_t n_rows_max, void *scratch, void *stream);
 
@@ -340,6 +346,11 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
  *     forward keeps them for nb_enc_bn_relu_bwd / nb_enc_conv_bwd_weight while the next convolution reads the planes)
  *   nb_enc_conv16: in_split = such a pair of planes with in_rows_cap rows each; everything else as nb_enc_conv */
 int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, int32_t mode, void *stream);
+/* up to NB_PACK_BATCH_MAX nb_enc_conv_pack16 jobs in ONE launch (host arrays of device pointers and sizes): a training step re-packs
+ * every >= 32-channel convolution after each optimiser step, forward (mode 0) and backward-input (mode 1) forms */
+#define NB_PACK_BATCH_MAX 32
+int nb_enc_conv_pack16_batch(int32_t n_jobs, const float *const weight[], const int32_t cin[], const int32_t cout[],
+                             uint16_t *const packed[], const int32_t mode[], void *stream);
 int nb_enc_bn_relu_split(const float *rows, const int32_t *n_rows, int32_t n_rows_max, int32_t c,
                          const double *stats, const float *gamma, const float *beta,
                          float *running_mean, float *running_var, int training, float eps, float momentum,
@@ -356,9 +367,11 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
  * [n_rows, c]; batch_stats dev [2c+1] as written by nb_enc_bn_relu; sums dev [2c] fp64 scratch.
  * Outputs: dx dev [n_rows, c] (may alias dy), dgamma / dbeta dev [c]; dx_split (dev or NULL): dx once more as two bf16
  * planes [2, n_rows_max, c] (heads | remainders) for the backward-input convolution on the matrix pipe. */
+#define NB_BWD_ZEROED 1 /* flags of nb_enc_bn_relu_bwd / nb_enc_conv_bwd_weight: the caller cleared `sums` / `dweight` (one zero fill
+                           for the accumulators of a whole backward pass instead of one memset per layer) */
 int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const int32_t *n_rows,
                        int32_t n_rows_max, int32_t c, const float *batch_stats, float eps, const float *gamma,
-                       double *sums, float *dx, float *dgamma, float *dbeta, uint16_t *dx_split, void *stream);
+                       double *sums, float *dx, float *dgamma, float *dbeta, uint16_t *dx_split, int32_t flags, void *stream);
 
 /* Gradient of the conv INPUT rows: din[q] = sum_o dx[r(q,o)] @ W[o]^T, where r(q,o) is the output row that
  * read input voxel q under kernel offset o.  out_grid = index grid of the OUTPUT tensor, in_lin = linear voxel
@@ -367,7 +380,7 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
                           const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3], int32_t stride,
                           const float *weight, int32_t cin, int32_t cout, float *din, void *stream);
 
-/* Gradient of the conv weight [3,3,3,Cin,Cout] (zeroed by the call): dW[o] = sum_r in[nbr(r,o)]^T (x) dx[r].
+/* Gradient of the conv weight [3,3,3,Cin,Cout] (zeroed by the call unless flags has NB_BWD_ZEROED): dW[o] = sum_r in[nbr(r,o)]^T (x) dx[r].
  * rulebook: dev int32 scratch [n_out_max * 27] (receives nbr(r,o), -1 = no active input voxel).
  * dx_split (dev or NULL): dx as bf16 head / remainder planes [2, n_out_max, Cout] (nb_enc_bn_relu_bwd writes them); when given
  * and Cin >= 32 the product runs on the 16-bit matrix pipe with both operands as bf16 pairs (three products, fp32 accumulate,
@@ -375,7 +388,7 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
 int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3],
                            const int32_t *out_lin, const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3],
                            int32_t stride, const float *dx, const uint16_t *dx_split, int32_t cin, int32_t cout,
-                           float *dweight, int32_t *rulebook, void *stream);
+                           float *dweight, int32_t *rulebook, int32_t flags, void *stream);
 
 /* Embedding-lookup backward: dcodes[rows_vert[r], :] = drows[r, :] (dcodes zeroed by the caller). */
 int nb_enc_scatter_codes_bwd(const float *drows, const int32_t *rows_vert, const int32_t *n_rows, int32_t n_rows_max,

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 17
+ABI_VERSION = 18
 SLOT_DEAD = -2147483648  # NB_SLOT_DEAD
 PRECISIONS = {"f32": 0, "f16f6": 1}
 PACK_SECTIONS = {"f32": 1, "f16f6": 2}
@@ -68,7 +68,7 @@ SIGNATURES = {
     "nb_mlp_pack": (C.c_int, [C.POINTER(NbMlpParams), _P, _P]),
     "nb_mlp_pack_sections": (C.c_int, [C.POINTER(NbMlpParams), _P, C.c_int, _P]),
     "nb_mlp_latent_bias": (C.c_int, [C.POINTER(NbMlpParams), _P, _P, _P]),
-    "nb_fold_build": (C.c_int, [C.c_void_p * 4, C.c_void_p * 4, C.c_void_p * 4, C.c_int32 * 4, _P, _P, _P]),
+    "nb_fold_build": (C.c_int, [C.c_void_p * 4, C.c_void_p * 4, C.c_void_p * 4, C.c_int32 * 4, _P, _P, _P, _P]),
     "nb_sparsify": (C.c_int, [_P, _I32x3, _I32, _P, _P, _P, _I32, _P, _P]),
     "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
     "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, C.POINTER(NbCull), C.c_int,
@@ -86,11 +86,12 @@ SIGNATURES = {
     "nb_enc_conv": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _I32, _P]),
     "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "nb_enc_conv_pack16": (C.c_int, [_P, _I32, _I32, _P, _I32, _P]),
+    "nb_enc_conv_pack16_batch": (C.c_int, [_I32, _P, _P, _P, _P, _P, _P]),
     "nb_enc_bn_relu_split": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P]),
     "nb_enc_conv16": (C.c_int, [_P, _I32, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _I32, _P]),
-    "nb_enc_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "nb_enc_bn_relu_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _P, C.c_float, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "nb_enc_conv_bwd_input": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P]),
-    "nb_enc_conv_bwd_weight": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _P, _I32, _I32, _P, _P, _P]),
+    "nb_enc_conv_bwd_weight": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _P, _I32, _I32, _P, _P, _I32, _P]),
     "nb_enc_scatter_codes_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_enc_gather_codes": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P]),
     "nb_raygen": (C.c_int, [_I32, _I32, C.c_double * 9, C.c_double * 9, C.c_double * 3, C.c_float * 6, _P, _P, _P,

@@ -287,6 +287,43 @@ __global__ void conv_pack16_kernel(const float *__restrict__ w, int cin, int cou
     out[idx] = v;
 }
 
+// the same for up to NB_PACK_BATCH_MAX (weight, mode) jobs in one launch: blockIdx.y = the job, blockIdx.x over its elements
+struct PackBatch {
+    const float *w[NB_PACK_BATCH_MAX];
+    bf16x8 *out[NB_PACK_BATCH_MAX];
+    int cin[NB_PACK_BATCH_MAX], cout[NB_PACK_BATCH_MAX], mode[NB_PACK_BATCH_MAX];
+};
+__global__ void conv_pack16_batch_kernel(PackBatch b) {
+    const int job = blockIdx.y;
+    const float *__restrict__ w = b.w[job];
+    bf16x8 *__restrict__ out = b.out[job];
+    const int cin = b.cin[job], cout = b.cout[job], mode = b.mode[job];
+    const int nc = cin / 16, ntt = cout / 32;
+    const long long total = (long long)27 * nc * ntt * 2 * 64;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63), part = (int)((idx >> 6) & 1);
+        const long long q = idx >> 7;
+        const int t = (int)(q % ntt), c = (int)((q / ntt) % nc), o = (int)(q / ((long long)ntt * nc));
+        const int j = lane & 31, hi = lane >> 5;
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * c + 8 * hi + e, n = 32 * t + j;
+            if (mode == 0) {
+                const float x = w[((size_t)o * cin + k) * cout + n];
+                const nb_h16 h = (nb_h16)x;
+                v[e] = part ? (nb_h16)(x - (float)h) : h;
+            } else {
+                const float x = w[((size_t)(26 - o) * cout + n) * cin + k];
+                const __bf16 h = (__bf16)x;
+                const __bf16 r = part ? (__bf16)(x - (float)h) : h;
+                v[e] = __builtin_bit_cast(nb_h16, r);
+            }
+        }
+        out[idx] = v;
+    }
+}
+
 // one wave = 32 output rows x NT tiles of 32 output channels (blockIdx.y selects the tile group)
 template <int CIN, int COUT, int NT, bool BF = false>
 __global__ __launch_bounds__(256) void conv16_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
@@ -1015,6 +1052,31 @@ int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t 
     hipLaunchKernelGGL(conv_pack16_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, weight, cin, cout,
                        reinterpret_cast<bf16x8 *>(packed), mode);
     NB_CHECK_LAUNCH("nb_enc_conv_pack16");
+    return NB_OK;
+}
+
+int nb_enc_conv_pack16_batch(int32_t n_jobs, const float *const weight[], const int32_t cin[], const int32_t cout[],
+                             uint16_t *const packed[], const int32_t mode[], void *stream) {
+    NB_REQUIRE(n_jobs >= 0 && n_jobs <= NB_PACK_BATCH_MAX, "nb_enc_conv_pack16_batch: %d jobs (at most %d)", n_jobs, NB_PACK_BATCH_MAX);
+    if (n_jobs == 0) return NB_OK;
+    NB_REQUIRE(weight && cin && cout && packed && mode, "nb_enc_conv_pack16_batch: NULL pointer");
+    PackBatch b = {};
+    long long most = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        NB_REQUIRE(weight[i] && packed[i], "nb_enc_conv_pack16_batch: job %d: NULL pointer", i);
+        NB_REQUIRE(mode[i] == 0 || mode[i] == 1, "nb_enc_conv_pack16_batch: job %d: mode %d", i, mode[i]);
+        NB_REQUIRE(cin[i] >= 16 && cin[i] % 16 == 0 && cout[i] >= 32 && cout[i] % 32 == 0, "nb_enc_conv_pack16_batch: job %d: channel pair %d -> %d",
+                   i, cin[i], cout[i]);
+        b.w[i] = weight[i];
+        b.out[i] = reinterpret_cast<bf16x8 *>(packed[i]);
+        b.cin[i] = cin[i];
+        b.cout[i] = cout[i];
+        b.mode[i] = mode[i];
+        const long long n = 27LL * (cin[i] / 16) * (cout[i] / 32) * 2 * 64;
+        most = n > most ? n : most;
+    }
+    hipLaunchKernelGGL(conv_pack16_batch_kernel, dim3((unsigned)nb_ceil_div(most, 256), n_jobs), dim3(256), 0, (hipStream_t)stream, b);
+    NB_CHECK_LAUNCH("nb_enc_conv_pack16_batch");
     return NB_OK;
 }
 

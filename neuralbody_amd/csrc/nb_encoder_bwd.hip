@@ -412,12 +412,12 @@ extern "C" {
 
 int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const int32_t *n_rows, int32_t n_rows_max,
                        int32_t c, const float *batch_stats, float eps, const float *gamma, double *sums, float *dx,
-                       float *dgamma, float *dbeta, uint16_t *dx_split, void *stream) {
+                       float *dgamma, float *dbeta, uint16_t *dx_split, int32_t flags, void *stream) {
     NB_REQUIRE(dy && y && x && n_rows && batch_stats && gamma && sums && dx && dgamma && dbeta,
                "nb_enc_bn_relu_bwd: NULL pointer");
     NB_REQUIRE(c > 0 && n_rows_max >= 0, "nb_enc_bn_relu_bwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    NB_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), st));
+    if (!(flags & NB_BWD_ZEROED)) NB_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), st));
     // 128 rows per block (32 per row lane): the deep levels have ~13 k rows x 128 channels, and a grid of a few dozen
     // blocks looping over hundreds of rows each ran at 150 us per layer, latency bound
     const int slabs = n_rows_max <= 128 ? 1 : (int)(nb_ceil_div(n_rows_max, 128) < 2048 ? nb_ceil_div(n_rows_max, 128) : 2048);
@@ -457,12 +457,12 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
 int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const int32_t in_dhw[3], const int32_t *out_lin,
                            const int32_t *n_out, int32_t n_out_max, const int32_t out_dhw[3], int32_t stride,
                            const float *dx, const uint16_t *dx_split, int32_t cin, int32_t cout, float *dweight,
-                           int32_t *rulebook, void *stream) {
+                           int32_t *rulebook, int32_t flags, void *stream) {
     NB_REQUIRE(in_rows && in_grid && in_dhw && out_lin && n_out && out_dhw && dx && dweight,
                "nb_enc_conv_bwd_weight: NULL pointer");
     NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv_bwd_weight: stride %d", stride);
     hipStream_t st = (hipStream_t)stream;
-    NB_HIP(hipMemsetAsync(dweight, 0, (size_t)27 * cin * cout * sizeof(float), st));
+    if (!(flags & NB_BWD_ZEROED)) NB_HIP(hipMemsetAsync(dweight, 0, (size_t)27 * cin * cout * sizeof(float), st));
     if (n_out_max <= 0) return NB_OK;
     NB_REQUIRE(rulebook != nullptr, "nb_enc_conv_bwd_weight: rulebook scratch is NULL");
     const Dims go = {out_dhw[0], out_dhw[1], out_dhw[2]}, gi = {in_dhw[0], in_dhw[1], in_dhw[2]};

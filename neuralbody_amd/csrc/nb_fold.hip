@@ -29,6 +29,7 @@ struct FoldArgs {
     const float *w0;   // [256, 352]
     unsigned short *urows;
     int zero_row;
+    int *n_sat;        // optional: how many products left the fp16 range (or are not finite)
 };
 
 // one workgroup = 128 rows x 256 outputs of one level; wave w = outputs [64 w, 64 w + 64)
@@ -47,7 +48,9 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
             const int r = idx / Q, q = idx % Q;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row0 + r < n) {
-                const size_t lin = (size_t)a.rows_lin[L][row0 + r];
+                // the level's rows straight from the encoder (compact [n_rows_max, C], rows_lin NULL) or gathered from the
+                // dense volume through rows_lin
+                const size_t lin = a.rows_lin[L] ? (size_t)a.rows_lin[L][row0 + r] : (size_t)(row0 + r);
                 v = *reinterpret_cast<const f32x4 *>(a.vol[L] + lin * C + q * 4);
             }
             float *d = at + r * PITCH + q * 4;
@@ -78,6 +81,8 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
     }
     // ---- rows out: through an LDS image [32 rows][256 heads | 256 remainders] so that a row leaves as 64 x 16 bytes
     unsigned short *st = reinterpret_cast<unsigned short *>(lds);
+    bool sat = false;  // a product beyond +-65504 is clamped (the head would be inf, the remainder inf - inf), a NaN stays a NaN:
+                       // either is counted, and Network's 'auto' leaves the fp16 planes for the exact kernel when the count is not 0
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
         __syncthreads();  // the A tile / the previous image is no longer read
@@ -86,7 +91,9 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = tile_row(r, kh), f = 64 * wave + 32 * t + i;
-                const float v = fminf(fmaxf(acc[rt][t][r], -65504.f), 65504.f);
+                const float u = acc[rt][t][r];
+                sat = sat || !(fabsf(u) <= 65504.f);
+                const float v = u > 65504.f ? 65504.f : (u < -65504.f ? -65504.f : u);
                 const _Float16 h = (_Float16)v;
                 const _Float16 l = (_Float16)(v - (float)h);
                 st[row * 512 + f] = __builtin_bit_cast(unsigned short, h);
@@ -101,6 +108,8 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
                     *reinterpret_cast<const f32x4 *>(st + row * 512 + piece * 8);
         }
     }
+    // (rows beyond n are zero-staged: their products are 0)
+    if (a.n_sat && __builtin_amdgcn_ballot_w64(sat) != 0ull && lane == 0) atomicAdd(a.n_sat, __builtin_popcountll(__builtin_amdgcn_ballot_w64(sat)));
 }
 
 __global__ __launch_bounds__(256) void nb_fold_rows_kernel(FoldArgs a) {
@@ -144,12 +153,12 @@ extern "C" {
 
 int nb_fold_build(const float *const vol[NB_N_LEVELS], const int32_t *const rows_lin[NB_N_LEVELS],
                   const int32_t *const n_rows[NB_N_LEVELS], const int32_t n_rows_max[NB_N_LEVELS], const float *fc0_w,
-                  uint16_t *urows, void *stream) {
+                  uint16_t *urows, int32_t *n_saturated, void *stream) {
     NB_REQUIRE(vol && rows_lin && n_rows && n_rows_max && fc0_w && urows, "nb_fold_build: NULL pointer");
     FoldArgs a = {};
     int base = 0, tiles = 0;
     for (int l = 0; l < 4; ++l) {
-        NB_REQUIRE(vol[l] && rows_lin[l] && n_rows[l] && n_rows_max[l] >= 1, "nb_fold_build: level %d: NULL pointer or empty capacity", l);
+        NB_REQUIRE(vol[l] && n_rows[l] && n_rows_max[l] >= 1, "nb_fold_build: level %d: NULL pointer or empty capacity", l);
         a.vol[l] = vol[l];
         a.rows_lin[l] = rows_lin[l];
         a.n_rows[l] = n_rows[l];
@@ -163,13 +172,16 @@ int nb_fold_build(const float *const vol[NB_N_LEVELS], const int32_t *const rows
     a.w0 = fc0_w;
     a.urows = urows;
     a.zero_row = base;
+    a.n_sat = n_saturated;
+    NB_REQUIRE(base < (1 << 21), "nb_fold_build: %d rows: the march addresses the 1-KiB rows with 32-bit byte offsets (< 2^21 rows)", base);
+    hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)ROWS_WG * 129 * 4;  // the widest A tile; the 32 KiB output image aliases it
     static bool attr_set = false;
     if (!attr_set) {
         NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nb_fold_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(nb_fold_rows_kernel, dim3(tiles), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(nb_fold_rows_kernel, dim3(tiles), dim3(256), lds, st, a);
     NB_CHECK_LAUNCH("nb_fold_rows_kernel");
     return NB_OK;
 }

@@ -447,11 +447,25 @@ __device__ __forceinline__ void gather_features(const SceneDev &sc, float px, fl
     for (int i = 0; i < 64; ++i) F[112 + i] = f3[i];
 }
 
-// XCD-aware wave-group remap: consecutive blocks land on different XCDs (block b -> XCD b % 8);
-// give every XCD a contiguous range of ray groups so neighbouring rays share one L2.
+// XCD-aware wave-group remap: consecutive blocks land on different XCDs (block b -> XCD b % 8).  Every XCD takes CHUNKS of
+// NB_XCD_CHUNK consecutive ray groups (64 groups = one row of 8 x 8 pixel tiles of a 512-wide image), dealt round robin: the groups
+// an XCD's L2 serves are strips of neighbouring tiles, and any run of >= 8 chunks — a rank's share of an image split over several
+// GPUs, whose other groups are dead slots — still spreads over all eight XCDs.  (Round 4 gave every XCD one contiguous eighth of
+// the list: a 1/8 share of whole tile rows then sat on ONE XCD and marched in 11 ms instead of 1.8, bench extras strong8_*.)
+// The groups behind the last full round of 8 chunks are split contiguously.
+#ifndef NB_XCD_CHUNK
+#define NB_XCD_CHUNK 64
+#endif
 __device__ __forceinline__ int xcd_remap(int b, int n) {
-    const int q = n / 8, r = n % 8, x = b % 8, i = b / 8;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    constexpr int C = NB_XCD_CHUNK;
+    const int full = (n / (8 * C)) * (8 * C);
+    if (b < full) {
+        const int x = b % 8, i = b / 8;
+        return ((i / C) * 8 + x) * C + i % C;
+    }
+    const int m = n - full, bb = b - full;
+    const int q = m / 8, r = m % 8, x = bb % 8, i = bb / 8;
+    return full + (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
 __device__ __forceinline__ float z_lin(float near, float far, float t) {
@@ -529,8 +543,11 @@ inline int fill_scene(const nb_scene *s, SceneDev *d) {
     for (int l = 0; l < 4; ++l) {
         NB_REQUIRE(s->vol[l] != nullptr || s->fold != nullptr, "nb_scene.vol[%d] is NULL", l);
         d->vol[l] = s->vol[l];
+        // the kernels index a level with 24-bit multiplies (v_mad_i32_i24) and 32-bit linear voxel numbers
+        NB_REQUIRE((long long)s->vol_dhw[l][0] * s->vol_dhw[l][1] * s->vol_dhw[l][2] < (1ll << 24),
+                   "nb_scene.vol_dhw[%d]: %d x %d x %d voxels (a level holds fewer than 2^24)", l, s->vol_dhw[l][0], s->vol_dhw[l][1], s->vol_dhw[l][2]);
         for (int k = 0; k < 3; ++k) {
-            NB_REQUIRE(s->vol_dhw[l][k] >= 1, "nb_scene.vol_dhw[%d][%d] = %d", l, k, s->vol_dhw[l][k]);
+            NB_REQUIRE(s->vol_dhw[l][k] >= 1 && s->vol_dhw[l][k] < (1 << 23), "nb_scene.vol_dhw[%d][%d] = %d", l, k, s->vol_dhw[l][k]);
             d->dhw[l][k] = s->vol_dhw[l][k];
             d->fm1[l][k] = (float)(s->vol_dhw[l][k] - 1);
             d->fp1[l][k] = (float)s->vol_dhw[l][k] + 1.f;
@@ -555,7 +572,9 @@ inline int fill_fold(const nb_scene *s, FoldDev *d) {
                f->zero_row);
     d->urows = reinterpret_cast<const char *>(f->urows);
     for (int l = 0; l < 4; ++l) {
-        NB_REQUIRE(f->grid[l] != nullptr && f->row_base[l] >= 0 && f->row_base[l] <= f->zero_row, "nb_fold: level %d", l);
+        NB_REQUIRE(f->grid[l] != nullptr && f->row_base[l] >= 0 && f->row_base[l] <= f->zero_row &&
+                       (l == 0 || f->row_base[l] >= f->row_base[l - 1]),
+                   "nb_fold: level %d: NULL grid or row_base %d outside [previous level, zero_row %d]", l, f->row_base[l], f->zero_row);
         d->grid[l] = f->grid[l];
         d->row_base[l] = f->row_base[l];
     }

@@ -33,20 +33,67 @@ DENSE_AFTER = ("conv1", "conv2", "conv3", "conv4")  # latent_xyzc.py:188-201
 BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
 DEFAULT_PRECISION = "auto"
 ENC_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # encoder convolutions with >= 32 input channels on the 16-bit matrix pipe
+LAZY_DENSE = os.environ.get("NB_LAZY_DENSE", "1") != "0"  # inference: dense volumes materialised on first access only
 SIX_BIT_MAX_SMALL = 0.5  # precision 'auto': largest per-layer share of weights six-bit blocks cannot hold before it takes 'f32'
 
 
 class FeatureVolumes(list):
-    """The four volumes of `Network.encode_sparse_voxels` ([1,C,D,H,W] views of channels-last storage, as the reference
-    returns them) together with the index structures they were scattered from: `sparse[l]` = (index grid [D,H,W] int32, linear
-    voxel index of every active row, device-side row count [1], row capacity).  Precision 'f16f6' builds its fc_0-folded
-    planes from them (`fold`: (fc_0 weight key, ops.fold_build result), rebuilt when the weight changes); a plain list of
-    volumes from elsewhere gets its active set from ops.sparsify."""
+    """The four volumes of `Network.encode_sparse_voxels` ([1,C,D,H,W] views of channels-last storage, as the reference's
+    `.dense()` returns them, latent_xyzc.py:188-201) together with the index structures they come from: `sparse[l]` = (index grid
+    [D,H,W] int32, linear voxel index of every active row, device-side row count [1], row capacity).
 
-    def __init__(self, volumes, sparse=None):
-        super().__init__(volumes)
+    On the inference path the DENSE tensors are made on first access only (`rows[l]`: the level's active rows, compact fp32
+    [capacity, C]; `shapes[l]` = (D, H, W)): the default arithmetic 'f16f6' marches the fc_0-folded planes, which nb_fold_build
+    forms from the compact rows, and never reads a dense volume — 137 MB per frame at out_sh (96, 352, 192) that nothing would
+    look at.  Indexing, iterating or `dense()` materialises them (zero fill + scatter on the device, no synchronisation):
+    `calculate_density(_color)` with precision 'f32', foreign consumers, the tests.  `fold`: (fc_0 weight key, storage,
+    ops.fold_build result), rebuilt when the weight changes; a plain list of volumes from elsewhere gets its active set from
+    ops.sparsify."""
+
+    def __init__(self, volumes=None, sparse=None, rows=None, shapes=None, zeroed_int=None):
+        super().__init__(volumes if volumes is not None else [])
         self.sparse = sparse
+        self.rows = rows
+        self.zeroed_int = zeroed_int  # one int32 the encoder's zero fill covered: the first fold build's saturation counter
+        if shapes is None and volumes is not None:  # [1,C,D,H,W] views or channels-last [D,H,W,C] storage
+            shapes = [tuple(int(x) for x in (v.shape[2:] if v.dim() == 5 else v.shape[:3])) for v in volumes]
+        self.shapes = shapes
         self.fold = None
+
+    # -- lazy dense tensors
+    def _ready(self):
+        return list.__len__(self) > 0 or self.rows is None
+
+    def dense(self):
+        """The four [1,C,D,H,W] tensors (materialised once)."""
+        if not self._ready():
+            vols = []
+            for (grid, rows_lin, n_rows, cap), rows, dhw in zip(self.sparse, self.rows, self.shapes):
+                c = int(rows.shape[1])
+                nvox = dhw[0] * dhw[1] * dhw[2]
+                cap = max(int(cap), 1)
+                buf = torch.zeros((nvox + 1, c), dtype=torch.float32, device=rows.device)  # + one row the padding scatters into
+                live = torch.arange(cap, device=rows.device) < n_rows
+                idx = torch.where(live, rows_lin[:cap].long(), torch.full((), nvox, dtype=torch.int64, device=rows.device))
+                buf.index_copy_(0, idx, torch.where(live[:, None], rows[:cap], torch.zeros((), device=rows.device)))
+                vols.append(buf[:nvox].view(dhw[0], dhw[1], dhw[2], c).permute(3, 0, 1, 2)[None])
+            list.extend(self, vols)
+        return self
+
+    def is_dense(self):
+        return self._ready()
+
+    def __len__(self):
+        return 4 if not self._ready() else list.__len__(self)
+
+    def __iter__(self):
+        return list.__iter__(self.dense())
+
+    def __getitem__(self, i):
+        return list.__getitem__(self.dense(), i)
+
+    def __bool__(self):
+        return len(self) > 0
 
 
 class SparseConv3dParam(nn.Module):
@@ -79,28 +126,61 @@ class SparseConvNet(nn.Module):
         for name, cin, cout, n, stride in ENCODER_BLOCKS:
             setattr(self, name, _block(cin, cout, n, stride))
 
-    def _packed16(self, conv):
-        """fp16 head / remainder B fragments of one convolution's weight, rebuilt when the parameter changes (the entry
-        holds the storage it was packed from, so its address cannot be recycled under the key)."""
+    @staticmethod
+    def _wkey(conv):
         w = conv.weight.detach()
-        key = (w.untyped_storage(), w.data_ptr(), w._version)
-        old = getattr(conv, "_nb_packed16", None)
-        if old is None or old[0][0]._cdata != key[0]._cdata or old[0][1:] != key[1:]:
-            old = (key, ops.enc_conv_pack16(w))
-            conv._nb_packed16 = old
+        return w, (w.untyped_storage(), w.data_ptr(), w._version)
+
+    @staticmethod
+    def _fresh(old, key):
+        return old is not None and old[0][0]._cdata == key[0]._cdata and old[0][1:] == key[1:]
+
+    def _packed16(self, conv, backward_input=False):
+        """fp16 head / remainder B fragments of one convolution's weight (backward_input: the bf16 pairs of its backward-input
+        convolution), rebuilt when the parameter changes (the entry holds the storage it was packed from, so its address cannot
+        be recycled under the key)."""
+        w, key = self._wkey(conv)
+        attr = "_nb_packed16_bwd" if backward_input else "_nb_packed16"
+        old = getattr(conv, attr, None)
+        if not self._fresh(old, key):
+            old = (key, ops.enc_conv_pack16(w, backward_input=backward_input))
+            setattr(conv, attr, old)
         return old[1]
 
-    def forward(self, codes, coord, out_sh, training, save=None):
+    def repack_stale(self, with_backward):
+        """Every stale packed form of the >= 32-channel convolutions in ONE launch (after an optimiser step all of them are stale:
+        14 forward forms + 11 backward-input forms of the stride-1 layers = 25 launches otherwise)."""
+        jobs, slots = [], []
+        for name, cin, cout, n, stride in ENCODER_BLOCKS:
+            block = getattr(self, name)
+            for j in range(n):
+                conv = block[3 * j]
+                if int(conv.weight.shape[3]) < 32:
+                    continue
+                w, key = self._wkey(conv)
+                forms = [("_nb_packed16", False)] + ([("_nb_packed16_bwd", True)] if with_backward and stride == 1 else [])
+                for attr, bwd in forms:
+                    if not self._fresh(getattr(conv, attr, None), key):
+                        jobs.append((w, bwd))
+                        slots.append((conv, attr, key))
+        if jobs:
+            for (conv, attr, key), packed in zip(slots, ops.enc_conv_pack16_batch(jobs)):
+                setattr(conv, attr, (key, packed))
+
+    def forward(self, codes, coord, out_sh, training, save=None, dense=True):
         """codes [6890,16] fp32, coord [6890,3] int32 (d,h,w) -> 4 channels-last volumes [D,H,W,C].
         save: optional list that receives one record per conv+BN+ReLU layer (index structures, raw and activated
-        rows, batch statistics) — everything neuralbody_amd.training.encoder_backward needs."""
+        rows, batch statistics) — everything neuralbody_amd.training.encoder_backward needs.
+        dense=False (inference): the `.dense()` volumes of latent_xyzc.py:188-201 are neither zero-filled nor scattered; the
+        result carries the levels' active rows instead (FeatureVolumes.rows) and materialises the volumes on first access."""
+        lazy = not dense and save is None
         dev = codes.device
         dhw = [int(s) for s in out_sh]
         n_max = coord.shape[0]
         layers = [(name, cin, cout, n, stride, j) for name, cin, cout, n, stride in ENCODER_BLOCKS for j in range(n)]
         # ONE zero fill per element type for everything the pass needs cleared: the index buffers of the levels (rows_vert |
         # rows_lin | n_rows, then out_lin | n_out per strided layer), and the dense volumes + the layers' fp64 statistics
-        int_sizes, dense_shapes, cap, d = [2 * max(n_max, 1) + 1], [], n_max, dhw
+        int_sizes, dense_shapes, cap, d = [1, 2 * max(n_max, 1) + 1], [], n_max, dhw
         for name, cin, cout, n, stride, j in layers:
             if stride == 2:
                 int_sizes.append(ops.down_capacity(cap, d) + 1)
@@ -108,11 +188,13 @@ class SparseConvNet(nn.Module):
             if name in DENSE_AFTER and j == n - 1:
                 dense_shapes.append(d + [cout])
         int_bufs = list(torch.zeros(sum(int_sizes), dtype=torch.int32, device=dev).split(int_sizes))
+        zeroed_int = int_bufs.pop(0)
         n_stats = 2 * len(layers) * 256  # fp64 [layers, 256] in front (8-byte aligned), the volumes behind it (64-float aligned)
-        dense_sizes = [(math.prod(sh) + 63) // 64 * 64 for sh in dense_shapes]
+        dense_sizes = [0 if lazy else (math.prod(sh) + 63) // 64 * 64 for sh in dense_shapes]
         f32_buf = torch.zeros(n_stats + sum(dense_sizes), dtype=torch.float32, device=dev)
         stats_all = f32_buf[:n_stats].view(torch.float64).view(len(layers), 256)
-        dense_bufs = [b[:math.prod(sh)].view(sh) for b, sh in zip(f32_buf[n_stats:].split(dense_sizes), dense_shapes)]
+        dense_bufs = [None if lazy else b[:math.prod(sh)].view(sh) for b, sh in zip(f32_buf[n_stats:].split(dense_sizes), dense_shapes)]
+        level_rows, level_shapes = [], []
         grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw, buf=int_bufs.pop(0))
         rows = ops.enc_gather_codes(codes, rows_vert, n_rows, n_max)
         if save is not None:
@@ -126,6 +208,8 @@ class SparseConvNet(nn.Module):
         # next to them — the backward pass differentiates the exact-fp32 formulas on those.  NB_ENC_SPLIT=0 keeps every
         # layer on the exact-fp32 MFMA kernel.
         fast = ENC_SPLIT
+        if fast:
+            self.repack_stale(with_backward=save is not None)
         rows_are_split = False
         rows_f32 = rows  # the fp32 form of the current layer's input rows (what the backward record keeps)
         for li, (name, cin, cout, n, stride, j) in enumerate(layers):
@@ -142,13 +226,17 @@ class SparseConvNet(nn.Module):
                 new_rows, stats = ops.enc_conv(rows, grid, dhw, out_lin, n_out, n_out_max, out_dhw, stride,
                                                conv.weight.detach(), stats=stats_all[li, :2 * cout])
             dense = None
-            if name in DENSE_AFTER and j == n - 1:
+            is_level = name in DENSE_AFTER and j == n - 1
+            if is_level:
                 dense = dense_bufs.pop(0)
-                assert list(dense.shape) == out_dhw + [cout]
+                assert lazy or list(dense.shape) == out_dhw + [cout]
                 volumes.append(dense)
                 sparse.append((out_grid, out_lin, n_out, n_out_max))
+                level_shapes.append(tuple(out_dhw))
             next_split = fast and li + 1 < len(layers) and cout >= 32  # the consumer of these rows is an enc_conv16
-            act = torch.empty_like(new_rows) if save is not None else None  # keep the raw conv output when saving
+            # the activated rows in fp32 beside the raw conv output: when saving (the backward needs both), and for a level
+            # whose dense volume is not written (its consumer convolution takes the split planes, nb_fold_build these rows)
+            act = torch.empty_like(new_rows) if (save is not None or (lazy and is_level and next_split)) else None
             split = None
             if next_split:
                 split, bstats = ops.enc_bn_relu_split(new_rows, n_out, n_out_max, stats, bn.weight.detach(), bn.bias.detach(),
@@ -166,13 +254,17 @@ class SparseConvNet(nn.Module):
                              "x": new_rows, "y": act, "bstats": bstats, "level": len(volumes) - 1 if dense is not None else None})
             if training:
                 bn_updates.append(bn.num_batches_tracked)
+            if lazy and is_level:
+                level_rows.append(act if act is not None else new_rows)  # (bn_relu without rows_out activates in place)
             rows_f32 = act if save is not None else new_rows
             rows = split if next_split else rows_f32
             grid, rows_lin, n_rows, n_max, dhw = out_grid, out_lin, n_out, n_out_max, out_dhw
             rows_are_split = next_split
         if training:
             torch._foreach_add_(bn_updates, 1)  # nn.BatchNorm1d bookkeeping, one fused launch
-        return FeatureVolumes(volumes, sparse)
+        if lazy:
+            return FeatureVolumes(None, sparse, rows=level_rows, shapes=level_shapes, zeroed_int=zeroed_int)
+        return FeatureVolumes(volumes, sparse, zeroed_int=zeroed_int)
 
 
 _MLP_NAMES = {"fc0": "fc_0", "fc1": "fc_1", "fc2": "fc_2", "alpha": "alpha_fc", "feature": "feature_fc",
@@ -189,6 +281,9 @@ class Network(nn.Module):
             raise ValueError("precision must be 'auto', 'f32' or 'f16f6'")
         self._auto = None  # (weight key, chosen arithmetic, statistic) of precision 'auto'
         self._lb_cache = None  # (latent_index tensor, versions, bias) of latent_bias()
+        self._foreign_fold = None  # (volume tensors + versions, fc_0 key, storage, planes) of volumes that came as a plain list
+        self._sat_checked = None  # fc_0 weight key whose first fold build had its saturation count read (precision 'auto')
+        self._planes_overflow = None  # ... and, if that count was not zero, the key again: 'auto' = 'f32' for these weights
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -212,7 +307,8 @@ class Network(nn.Module):
     # the packed blobs and their keys (storages!) are caches of the parameters: they are neither copied nor pickled
     def __getstate__(self):
         st = dict(self.__dict__)
-        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None)
+        st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None, _foreign_fold=None,
+                  _sat_checked=None, _planes_overflow=None)
         return st
 
     def __deepcopy__(self, memo):
@@ -225,6 +321,7 @@ class Network(nn.Module):
             setattr(new, k, copy.deepcopy(v, memo))
         for m in new.modules():
             m.__dict__.pop("_nb_packed16", None)
+            m.__dict__.pop("_nb_packed16_bwd", None)
         return new
 
     # ------------------------------------------------------------------ packed decoder weights
@@ -249,6 +346,10 @@ class Network(nn.Module):
         alone — decided once per weight version (one 3-float read-back after packing), the same on every rank, no timing."""
         if self.precision != "auto":
             return self.precision
+        if self._planes_overflow is not None:
+            w = self.fc_0.weight
+            if self._planes_overflow == (w.data_ptr(), w._version):
+                return "f32"  # fc_0 . V does not fit the fp16 planes (nb_fold_build's count, _auto_checks_planes)
         packed = self.packed_weights("f16f6")
         if self._auto is None or self._auto[0] is not self._packed_key:
             worst = float(ops.six_bit_small_fraction(packed).max())
@@ -312,27 +413,71 @@ class Network(nn.Module):
         that could hand frame k+1 the pose of frame k when the allocator recycles the batch's addresses.
         precision 'f16f6' marches the fc_0-folded planes of the volumes (ops.fold_build): built once per (volumes, fc_0
         weight version) and kept on the FeatureVolumes object."""
-        vols = []
-        for v in feature_volume:
-            vols.append(v if v.dim() == 4 else ops.volume_as_channels_last(v))
+        lazy = isinstance(feature_volume, FeatureVolumes) and not feature_volume.is_dense()
+        if lazy and precision == "f16f6":
+            vols = list(feature_volume.shapes)  # the folded planes are all this arithmetic reads: no dense volume is made
+        else:
+            vols = [v if v.dim() == 4 else ops.volume_as_channels_last(v) for v in feature_volume]
         R, Th, bounds = sp_input["R"], sp_input["Th"], sp_input["bounds"]
         if R.numel() != 9 or bounds.numel() != 6:
             raise NotImplementedError("batch size 1 only (train.batch_size / test batch are 1 in every shipped config)")
         out_sh = [int(s) for s in sp_input["out_sh"]]
         fold = self._fold_planes(feature_volume, vols) if precision == "f16f6" else None
-        return ops.make_scene(vols, ops.make_pose(R, Th, bounds, device=vols[0].device), self.voxel_size, out_sh, fold=fold)
+        dev = feature_volume.rows[0].device if lazy else vols[0].device
+        return ops.make_scene(vols, ops.make_pose(R, Th, bounds, device=dev), self.voxel_size, out_sh, fold=fold)
 
     def _fold_planes(self, feature_volume, vols):
+        """(NbFold, keepalive) of the volumes: from the encoder's compact rows when the FeatureVolumes object carries them (no
+        dense volume is touched), from its dense volumes + index structures otherwise; a plain list of dense volumes gets its
+        active set from ops.sparsify, sized by ONE read-back of the four counts and kept per (volume tensors, versions, fc_0)."""
         w = self.fc_0.weight.detach()
         key = (w.data_ptr(), w._version)
         fv = feature_volume if isinstance(feature_volume, FeatureVolumes) else None
         if fv is not None and fv.fold is not None and fv.fold[0] == key and fv.fold[1] is w.untyped_storage():
             return fv.fold[2]
-        sparse = fv.sparse if fv is not None and fv.sparse is not None else [ops.sparsify(v) for v in vols]
-        fold = ops.fold_build(vols, sparse, w)
-        if fv is not None:
+        if fv is not None and fv.sparse is not None:
+            n_sat, fv.zeroed_int = fv.zeroed_int, None  # (a rebuild for a new fc_0 gets a fresh counter)
+            if fv.rows is not None:
+                fold = ops.fold_build(fv.shapes, fv.sparse, w, rows=fv.rows, n_sat=n_sat)
+            else:
+                fold = ops.fold_build(vols, fv.sparse, w, n_sat=n_sat)
             fv.fold = (key, w.untyped_storage(), fold)  # holds the storage: its address cannot be recycled under the key
+            self._auto_checks_planes(key, fold)
+            return fold
+        # volumes from elsewhere (cloned, loaded, another encoder's): nothing to hang a cache on but the tensors themselves
+        fkey = tuple((v, v._version) for v in vols)
+        old = self._foreign_fold
+        if old is not None and old[1] == key and old[2] is w.untyped_storage() and len(old[0]) == len(fkey) and \
+                all(a[0] is b[0] and a[1] == b[1] for a, b in zip(old[0], fkey)):
+            return old[3]
+        sparse = [ops.sparsify(v) for v in vols]
+        counts = torch.cat([sp[2] for sp in sparse]).tolist()  # one read-back: a capacity of every voxel would be ~1 GB of planes
+        sparse = [(g, lin, n, max(int(c), 1)) for (g, lin, n, _), c in zip(sparse, counts)]
+        fold = ops.fold_build(vols, sparse, w)
+        self._foreign_fold = (fkey, key, w.untyped_storage(), fold)
+        self._auto_checks_planes(key, fold)
         return fold
+
+    def _auto_checks_planes(self, key, fold):
+        """precision 'auto', once per fc_0 version: read the planes' saturation count (one 4-byte read-back); a non-zero count
+        means fc_0 . V left the fp16 range somewhere, and this Network takes the exact kernel from here on (with a warning)."""
+        if self.precision != "auto" or self._sat_checked == key:
+            return
+        self._sat_checked = key
+        n = int(fold[1][1])
+        if n:
+            import warnings
+
+            warnings.warn("neuralbody_amd: %d products of fc_0 with the latent volumes exceed the fp16 range of the folded planes; "
+                          "precision 'auto' takes the exact fp32 kernel for these weights" % n)
+            self._planes_overflow = key
+
+    def fold_saturated(self, feature_volume):
+        """How many fc_0 . V products of the volumes' folded planes left the fp16 range or are not finite (device -> host read;
+        0 for any sane weights: the planes then carry fc_0 . V to fp32 accuracy).  Non-zero: use precision 'f32'."""
+        fv = feature_volume if isinstance(feature_volume, FeatureVolumes) else None
+        fold = fv.fold[2] if fv is not None and fv.fold is not None else (self._foreign_fold[3] if self._foreign_fold else None)
+        return 0 if fold is None else int(fold[1][1])
 
     # ------------------------------------------------------------------ reference API
     def encode_sparse_voxels(self, sp_input, save=None):
@@ -347,9 +492,12 @@ class Network(nn.Module):
                 coord = coord[:, 1:]
             coord = coord.reshape(-1, 3).to(torch.int32).contiguous()
         codes = self.c.weight.detach()
+        if save is None and LAZY_DENSE:
+            # inference: the dense volumes are made when (and if) somebody looks at them (FeatureVolumes)
+            return self.xyzc_net(codes, coord, sp_input["out_sh"], self.training, None, dense=False)
         vols = self.xyzc_net(codes, coord, sp_input["out_sh"], self.training, save)
         # logical layout [1,C,D,H,W] like spconv's .dense(); storage stays channels-last
-        return FeatureVolumes([v.permute(3, 0, 1, 2)[None] for v in vols], vols.sparse)
+        return FeatureVolumes([v.permute(3, 0, 1, 2)[None] for v in list.__iter__(vols)], vols.sparse, zeroed_int=vols.zeroed_int)
 
     SORT_MIN_POINTS = 4096  # below this a spatial sort of the points costs more than it saves
 
@@ -372,6 +520,9 @@ class Network(nn.Module):
     def _decode(self, wpts, viewdir, feature_volume, sp_input, density_only):
         prec = self._point_precision()
         scene = self.make_scene(feature_volume, sp_input, prec)
+        if prec != self._point_precision():  # (see render_rays)
+            prec = self._point_precision()
+            scene = self.make_scene(feature_volume, sp_input, prec)
         p = wpts.reshape(-1, 3).float().contiguous()
         v = None if density_only else viewdir.reshape(-1, 3).float().contiguous()
         lb = None if density_only else self.latent_bias(sp_input["latent_index"])
@@ -409,6 +560,9 @@ class Network(nn.Module):
         """All rays of the (single) batch element through nb_march.  ray_o/ray_d [n,3], near/far [n]."""
         prec = self.march_precision()
         scene = self.make_scene(feature_volume, sp_input, prec)
+        if prec != self.march_precision():  # 'auto' just learnt that these weights overflow the folded planes
+            prec = self.march_precision()
+            scene = self.make_scene(feature_volume, sp_input, prec)
         lb = self.latent_bias(sp_input["latent_index"])
         key = (int(n_samples), str(ray_o.device))  # a constant of (S, device), not of the frame
         t_vals = self._t_vals.get(key)

@@ -2,6 +2,7 @@
 dtype, contiguity and shape, then hands raw device pointers + the current HIP stream to
 libnb_hip.so.  Nothing here computes: there is no PyTorch / CPU fallback for any operator."""
 import ctypes as C
+import math
 
 import torch
 
@@ -80,10 +81,12 @@ def sparsify(volume_cl):
     return grid, rows_lin, n_rows, nvox
 
 
-def fold_build(volumes_cl, sparse, fc0_w):
-    """nb_fold_build: the fc_0-folded planes of one frame (precision 'f16f6').  volumes_cl: the four channels-last
-    volumes; sparse: per level (grid, rows_lin, n_rows[1], n_rows_max) — the encoder's index structures, or `sparsify`'s;
-    fc0_w [256,352(,1)].  Returns (NbFold, keepalive)."""
+def fold_build(volumes_cl, sparse, fc0_w, rows=None, n_sat=None):
+    """nb_fold_build: the fc_0-folded planes of one frame (precision 'f16f6').  volumes_cl: the four channels-last volumes
+    (or, with `rows`, just their [D,H,W] shapes); sparse: per level (grid, rows_lin, n_rows[1], n_rows_max) — the encoder's index
+    structures, or `sparsify`'s; rows: per level the ACTIVE rows themselves, compact [>= n_rows_max, C] fp32 (the encoder's
+    output before `.dense()`): the dense volumes are then not read and need not exist; fc0_w [256,352(,1)].
+    Returns (NbFold, keepalive); keepalive[0] = the planes, keepalive[1] = n_saturated [1] int32 (see include/nb_hip.h)."""
     if fc0_w.dim() == 3:
         fc0_w = fc0_w[:, :, 0]
     fc0_w = fc0_w.detach()
@@ -93,45 +96,68 @@ def fold_build(volumes_cl, sparse, fc0_w):
     v4, l4, n4, caps = (C.c_void_p * 4)(), (C.c_void_p * 4)(), (C.c_void_p * 4)(), (C.c_int32 * 4)()
     f = NbFold()
     base = 0
+    keep_src = []
     for l, (v, (grid, rows_lin, n_rows, cap)) in enumerate(zip(volumes_cl, sparse)):
-        _req(v, torch.float32, (None, None, None, LEVEL_CHANNELS[l]), "volume[%d]" % l)
-        _req(grid, torch.int32, tuple(int(x) for x in v.shape[:3]), "grid[%d]" % l)
-        _req(rows_lin, torch.int32, (None,), "rows_lin[%d]" % l)
+        dhw = tuple(int(x) for x in (v.shape[:3] if isinstance(v, torch.Tensor) else v))
+        _req(grid, torch.int32, dhw, "grid[%d]" % l)
         _req(n_rows, torch.int32, (1,), "n_rows[%d]" % l)
         cap = max(int(cap), 1)
-        if rows_lin.shape[0] < cap:
-            raise ValueError("rows_lin[%d] shorter than its capacity" % l)
-        v4[l], l4[l], n4[l], caps[l] = v.data_ptr(), rows_lin.data_ptr(), n_rows.data_ptr(), cap
+        if rows is not None:
+            r = _req(rows[l], torch.float32, (None, LEVEL_CHANNELS[l]), "rows[%d]" % l)
+            if r.shape[0] < cap:
+                raise ValueError("rows[%d] shorter than its capacity" % l)
+            v4[l], l4[l] = r.data_ptr(), None
+            keep_src.append(r)
+        else:
+            _req(v, torch.float32, (None, None, None, LEVEL_CHANNELS[l]), "volume[%d]" % l)
+            _req(rows_lin, torch.int32, (None,), "rows_lin[%d]" % l)
+            if rows_lin.shape[0] < cap:
+                raise ValueError("rows_lin[%d] shorter than its capacity" % l)
+            v4[l], l4[l] = v.data_ptr(), rows_lin.data_ptr()
+            keep_src.append(v)
+        n4[l], caps[l] = n_rows.data_ptr(), cap
         f.grid[l] = grid.data_ptr()
         f.row_base[l] = base
         base += cap
     if base >= (1 << 21):
         raise ValueError("fold_build: %d rows exceed the 2 GiB plane the march addresses with 32-bit offsets" % base)
-    urows = torch.empty((base + 1, 512), dtype=torch.int16, device=volumes_cl[0].device)
+    dev = fc0_w.device
+    urows = torch.empty((base + 1, 512), dtype=torch.int16, device=dev)
+    if n_sat is None:
+        n_sat = torch.zeros(1, dtype=torch.int32, device=dev)
+    _req(n_sat, torch.int32, (1,), "n_sat")
     f.urows = urows.data_ptr()
     f.zero_row = base
-    check(_lib.lib().nb_fold_build(v4, l4, n4, caps, ptr(fc0_w), ptr(urows), _stream()), "nb_fold_build")
-    return f, [urows, fc0_w] + [t for sp in sparse for t in sp[:3]]
+    check(_lib.lib().nb_fold_build(v4, l4, n4, caps, ptr(fc0_w), ptr(urows), ptr(n_sat), _stream()), "nb_fold_build")
+    return f, [urows, n_sat, fc0_w] + keep_src + [t for sp in sparse for t in sp[:3]]
 
 
 def make_scene(volumes_cl, pose, voxel_size, out_sh, fold=None):
-    """volumes_cl: four contiguous [D,H,W,C] fp32 device tensors; pose: the 15-float DEVICE block of make_pose;
-    voxel_size (3, dhw) and out_sh (3) are HOST sequences; fold: `fold_build`'s result (precision 'f16f6').
-    Returns (NbScene, keepalive)."""
+    """volumes_cl: four contiguous [D,H,W,C] fp32 device tensors — or, with `fold` (precision 'f16f6' reads the folded planes,
+    never the volumes), just their (D, H, W) shapes; pose: the 15-float DEVICE block of make_pose; voxel_size (3, dhw) and
+    out_sh (3) are HOST sequences; fold: `fold_build`'s result.  Returns (NbScene, keepalive)."""
     sc = NbScene()
     if len(volumes_cl) != 4:
         raise ValueError("expected 4 feature volumes")
+    keep = [pose]
     for l, v in enumerate(volumes_cl):
-        _req(v, torch.float32, (None, None, None, LEVEL_CHANNELS[l]), "volume[%d]" % l)
-        sc.vol[l] = v.data_ptr()
+        if isinstance(v, torch.Tensor):
+            _req(v, torch.float32, (None, None, None, LEVEL_CHANNELS[l]), "volume[%d]" % l)
+            sc.vol[l] = v.data_ptr()
+            keep.append(v)
+            dhw = v.shape[:3]
+        else:
+            if fold is None:
+                raise ValueError("volume[%d] given as a shape: only a scene with folded planes can do without the volume" % l)
+            sc.vol[l] = None
+            dhw = v
         for k in range(3):
-            sc.vol_dhw[l][k] = int(v.shape[k])
+            sc.vol_dhw[l][k] = int(dhw[k])
     _req(pose, torch.float32, (15,), "pose")
     sc.pose = pose.data_ptr()
     for k in range(3):
         sc.voxel_size[k] = float(voxel_size[k])
         sc.out_sh[k] = int(out_sh[k])
-    keep = list(volumes_cl) + [pose]
     if fold is not None:
         sc.fold = C.pointer(fold[0])
         keep += [fold[0]] + list(fold[1])
@@ -405,6 +431,26 @@ def enc_conv_pack16(weight, backward_input=False):
     return packed
 
 
+def enc_conv_pack16_batch(jobs):
+    """nb_enc_conv_pack16_batch: jobs = [(weight [3,3,3,Cin,Cout], backward_input)] -> list of packed int16 tensors, one launch
+    (per 32 jobs)."""
+    outs = []
+    for i0 in range(0, len(jobs), 32):
+        chunk = jobs[i0:i0 + 32]
+        n = len(chunk)
+        w_p, out_p = (C.c_void_p * n)(), (C.c_void_p * n)()
+        cin_a, cout_a, mode_a = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int32 * n)()
+        for i, (weight, bwd) in enumerate(chunk):
+            _req(weight, torch.float32, (3, 3, 3, None, None), "conv weight")
+            ci, co = int(weight.shape[3]), int(weight.shape[4])
+            packed = torch.empty(27 * ci * co * 2, dtype=torch.int16, device=weight.device)
+            outs.append(packed)
+            w_p[i], out_p[i] = weight.data_ptr(), packed.data_ptr()
+            cin_a[i], cout_a[i], mode_a[i] = (co, ci, 1) if bwd else (ci, co, 0)
+        check(_lib.lib().nb_enc_conv_pack16_batch(n, w_p, cin_a, cout_a, out_p, mode_a, _stream()), "nb_enc_conv_pack16_batch")
+    return outs
+
+
 def enc_conv16(in_split, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, wpacked, cin, cout, stats=None,
                bf16=False):
     """nb_enc_conv16 on split rows (int16 [2, cap, Cin]: fp16 heads | remainders) -> (out_rows fp32, stats fp64); `stats` as
@@ -644,7 +690,29 @@ def trilinear_bwd(scene, grids, drows, wpts, d_feat, run_length=1):
     return drows
 
 
-def enc_bn_relu_bwd(dy, y, x, n_rows, n_rows_max, batch_stats, eps, gamma, want_split=False):
+class ZeroArena:
+    """One zero fill for everything a pass accumulates into (atomics, column sums, scatter targets): `take(shape, dtype)` hands
+    out views of a single torch.zeros buffer sized by a planning pass over the same requests (`ZeroArena.plan()` counts)."""
+
+    def __init__(self, n_bytes, device):
+        self.buf = torch.zeros((int(n_bytes) + 7) // 8, dtype=torch.float64, device=device).view(torch.uint8)
+        self.off = 0
+
+    @staticmethod
+    def size_of(requests):
+        return sum((math.prod(shape) * torch.empty((), dtype=dt).element_size() + 15) // 16 * 16 for shape, dt in requests)
+
+    def take(self, shape, dtype=torch.float32):
+        shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        if self.off + n > self.buf.numel():
+            raise RuntimeError("ZeroArena exhausted: planned %d bytes, asked for %d more at %d" % (self.buf.numel(), n, self.off))
+        t = self.buf[self.off:self.off + n].view(dtype).view(shape)
+        self.off += (n + 15) // 16 * 16
+        return t
+
+
+def enc_bn_relu_bwd(dy, y, x, n_rows, n_rows_max, batch_stats, eps, gamma, want_split=False, sums=None):
     """nb_enc_bn_relu_bwd -> (dx, dgamma, dbeta) or, with want_split, (dx, dgamma, dbeta, dx_split int16 [2, rows, C]: dx as bf16
     head / remainder planes for the backward-input convolution on the matrix pipe)."""
     c = int(x.shape[1])
@@ -653,47 +721,55 @@ def enc_bn_relu_bwd(dy, y, x, n_rows, n_rows_max, batch_stats, eps, gamma, want_
     _req(batch_stats, torch.float32, (2 * c + 1,), "batch_stats")
     _req(gamma, torch.float32, (c,), "gamma")
     dev = x.device
-    sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    zeroed = sums is not None  # a ZeroArena view: the call's own memset is skipped
+    if sums is None:
+        sums = torch.empty(2 * c, dtype=torch.float64, device=dev)
+    _req(sums, torch.float64, (2 * c,), "sums")
     dx = torch.empty_like(x)
     dgamma = torch.empty(c, dtype=torch.float32, device=dev)
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     split = torch.empty((2, max(int(n_rows_max), 1), c), dtype=torch.int16, device=dev) if want_split else None
     check(_lib.lib().nb_enc_bn_relu_bwd(ptr(dy), ptr(y), ptr(x), ptr(n_rows), int(n_rows_max), c, ptr(batch_stats),
                                         float(eps), ptr(gamma), ptr(sums), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(split),
-                                        _stream()), "nb_enc_bn_relu_bwd")
+                                        1 if zeroed else 0, _stream()), "nb_enc_bn_relu_bwd")
     return (dx, dgamma, dbeta, split) if want_split else (dx, dgamma, dbeta)
 
 
-def enc_conv_bwd_input(dx, out_grid, out_dhw, in_lin, n_in, n_in_max, in_dhw, stride, weight):
+def enc_conv_bwd_input(dx, out_grid, out_dhw, in_lin, n_in, n_in_max, in_dhw, stride, weight, out=None):
+    """nb_enc_conv_bwd_input -> din [n_in_max, Cin]; out: a ZEROED buffer of that shape (ZeroArena), default torch.zeros."""
     cin, cout = int(weight.shape[3]), int(weight.shape[4])
     _req(dx, torch.float32, (None, cout), "dx")
     _req(out_grid, torch.int32, tuple(int(s) for s in out_dhw), "out_grid")
     _req(in_lin, torch.int32, (None,), "in_lin")
-    din = torch.zeros((max(int(n_in_max), 1), cin), dtype=torch.float32, device=dx.device)
+    din = out if out is not None else torch.zeros((max(int(n_in_max), 1), cin), dtype=torch.float32, device=dx.device)
+    _req(din, torch.float32, (max(int(n_in_max), 1), cin), "din")
     check(_lib.lib().nb_enc_conv_bwd_input(ptr(dx), ptr(out_grid), _i3(out_dhw), ptr(in_lin), ptr(n_in), int(n_in_max),
                                            _i3(in_dhw), int(stride), ptr(weight), cin, cout, ptr(din), _stream()),
           "nb_enc_conv_bwd_input")
     return din
 
 
-def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, dx, cin, cout, dx_split=None):
+def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, dx, cin, cout, dx_split=None, out=None):
     """nb_enc_conv_bwd_weight -> dW [3,3,3,Cin,Cout].  dx_split (int16 [2, n_out_max, Cout], enc_bn_relu_bwd(want_split=True)):
     the product runs on the 16-bit matrix pipe with bf16 pairs (Cin >= 32)."""
     _req(in_rows, torch.float32, (None, cin), "in_rows")
     _req(dx, torch.float32, (None, cout), "dx")
     if dx_split is not None:
         _req(dx_split, torch.int16, (2, max(int(n_out_max), 1), cout), "dx_split")
-    dw = torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=dx.device)
+    zeroed = out is not None  # a ZeroArena view: the call's own memset is skipped
+    dw = out if zeroed else torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=dx.device)
+    _req(dw, torch.float32, (3, 3, 3, cin, cout), "dweight")
     rulebook = torch.empty(max(int(n_out_max), 1) * 27, dtype=torch.int32, device=dx.device)
     check(_lib.lib().nb_enc_conv_bwd_weight(ptr(in_rows), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out),
                                             int(n_out_max), _i3(out_dhw), int(stride), ptr(dx), ptr(dx_split), cin, cout,
-                                            ptr(dw), ptr(rulebook), _stream()), "nb_enc_conv_bwd_weight")
+                                            ptr(dw), ptr(rulebook), 1 if zeroed else 0, _stream()), "nb_enc_conv_bwd_weight")
     return dw
 
 
-def enc_scatter_codes_bwd(drows, rows_vert, n_rows, n_rows_max, n_codes):
+def enc_scatter_codes_bwd(drows, rows_vert, n_rows, n_rows_max, n_codes, out=None):
     c = int(drows.shape[1])
-    dcodes = torch.zeros((n_codes, c), dtype=torch.float32, device=drows.device)
+    dcodes = out if out is not None else torch.zeros((n_codes, c), dtype=torch.float32, device=drows.device)
+    _req(dcodes, torch.float32, (n_codes, c), "dcodes")
     check(_lib.lib().nb_enc_scatter_codes_bwd(ptr(drows), ptr(rows_vert), ptr(n_rows), int(n_rows_max), c, ptr(dcodes),
                                               _stream()), "nb_enc_scatter_codes_bwd")
     return dcodes

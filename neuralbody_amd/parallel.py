@@ -24,6 +24,35 @@ def shard_range(n, rank, world):
     return b, b + q + (1 if rank < r else 0)
 
 
+TILE = 8  # ops.TILE: the march takes the rays of an image in 8 x 8 pixel tiles (one workgroup each)
+
+
+def shard_tile_rows(H, rank, world, tile=TILE):
+    """Pixel rows [r0, r1) of `rank`: whole bands of `tile` rows, as balanced as whole bands allow (band counts differ by at most
+    one; the last band may be cut by the image border; trailing ranks are empty when there are fewer bands than ranks)."""
+    bands = (int(H) + tile - 1) // tile
+    b0, b1 = shard_range(bands, rank, world)
+    return min(b0 * tile, int(H)), min(b1 * tile, int(H))
+
+
+def shard_range_tiled(n, rank, world, H, W, mask=None, tile=TILE):
+    """[begin, end) of the compacted ray list (pixel order) for `rank` such that the range is exactly the rays of whole
+    `tile`-row bands of the H x W image: every 8 x 8 pixel tile of the march then belongs to ONE rank with all of its rays, so the
+    rank marches the same workgroups over the same voxel lists as a single GPU rendering the whole image would — its share of the
+    image is bit-identical to that render (a range that cuts tiles agrees to rounding only: DESIGN.md §3).  `mask` [H*W] (bool /
+    uint8, host or device; None = every pixel has a ray, n == H * W): which pixels carry a ray; its row sums are read back once."""
+    r0, r1 = shard_tile_rows(H, rank, world, tile)
+    if mask is None:
+        if int(n) != int(H) * int(W):
+            raise ValueError("%d rays for a %d x %d image: pass the pixel mask of a partially covered view" % (n, H, W))
+        return r0 * int(W), r1 * int(W)
+    m = torch.as_tensor(mask).reshape(int(H), int(W))
+    rows = torch.cat([torch.zeros(1, dtype=torch.int64), (m != 0).sum(1).to(torch.int64).cpu().cumsum(0)])
+    if int(rows[-1]) != int(n):
+        raise ValueError("the mask holds %d rays, the batch %d" % (int(rows[-1]), n))
+    return int(rows[r0]), int(rows[r1])
+
+
 def all_gather_tiles(tile, group=None, sizes=None):
     """All-gather per-rank tiles [n_r, ...] into one [sum n_r, ...] tensor on every rank.  Equal-size
     tiles go through a single all_gather_into_tensor; ragged ones are padded to the largest tile
@@ -51,13 +80,28 @@ def render_sharded(renderer, batch, group=None, keys=("rgb_map",), prefetched=No
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = batch["ray_o"].shape[1]
-    b, e = shard_range(n, rank, world)
+    ranges = shard_ranges(renderer, batch, world)
+    b, e = ranges[rank]
     extra = {} if prefetched is None else {"prefetched": prefetched}  # renderers with the reference's signature stay usable
     part = renderer.render(batch, ray_range=(b, e), **extra)
     if not dist.is_initialized():
         return {k: part[k] for k in keys}
-    sizes = [shard_range(n, r, world)[1] - shard_range(n, r, world)[0] for r in range(world)]
+    sizes = [r[1] - r[0] for r in ranges]
     return {k: all_gather_tiles(part[k][0], group, sizes)[None] for k in keys}
+
+
+def shard_ranges(renderer, batch, world):
+    """The ray range of every rank: whole 8-row tile bands when the renderer knows the image geometry (cfg.H, cfg.W: the march
+    then works in 8 x 8 pixel tiles and a rank's share is bit-identical to the single-GPU render), plain balanced ranges
+    otherwise (ray lists without an image, e.g. training batches)."""
+    n = batch["ray_o"].shape[1]
+    cfg = getattr(renderer, "cfg", None)
+    H, W = (getattr(cfg, "H", None), getattr(cfg, "W", None)) if cfg is not None else (None, None)
+    mask = batch.get("mask_at_box")
+    if H and W and mask is not None and mask.numel() == int(H) * int(W) and n >= 64:
+        full = n == int(H) * int(W)
+        return [shard_range_tiled(n, r, world, H, W, None if full else mask.reshape(-1)) for r in range(world)]
+    return [shard_range(n, r, world) for r in range(world)]
 
 
 def reduce_timings(elapsed_s, local, precision_code, group=None, device=None):

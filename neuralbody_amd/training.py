@@ -26,7 +26,7 @@ def _w2(conv):
     return conv.weight.detach()[:, :, 0]
 
 
-def decoder_backward(net, tap, d_raw, latent_index):
+def decoder_backward(net, tap, d_raw, latent_index, arena=None):
     """Gradients of the MLP parameters and of the gathered features.
 
     tap [N,1600] activation tap, d_raw [N,4] = d(rgb logits, sigma).  Returns (grads, dF) where grads maps the
@@ -40,12 +40,13 @@ def decoder_backward(net, tap, d_raw, latent_index):
     d_rgb, d_sig = d_raw[:, 0:3], d_raw[:, 3:4]
     W0, W1, W2 = _w2(net.fc_0), _w2(net.fc_1), _w2(net.fc_2)
     Wa, Wf, Wl, Wv, Wr = _w2(net.alpha_fc), _w2(net.feature_fc), _w2(net.latent_fc), _w2(net.view_fc), _w2(net.rgb_fc)
-    zeros = lambda n: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+    # accumulators (column sums): views of the backward pass's one zero fill when an arena is given
+    zeros = (lambda n: arena.take(n)) if arena is not None else (lambda n: torch.zeros(n, dtype=torch.float32, device=dev))  # noqa: E731
     g = {}
     # rgb_fc (latent_xyzc.py:121)
     g["rgb_fc.weight"] = ops.sgemm(d_rgb, V, trans_a=True)
-    g["rgb_fc.bias"] = ops.colsum(d_rgb)
-    g["alpha_fc.bias"] = ops.colsum(d_sig)
+    g["rgb_fc.bias"] = ops.colsum(d_rgb, out=zeros(3))
+    g["alpha_fc.bias"] = ops.colsum(d_sig, out=zeros(1))
     # dV = (d_rgb . W_rgb) * [V > 0]; its column sums are view_fc's bias gradient
     g["view_fc.bias"] = zeros(128)
     dV = ops.sgemm(d_rgb, Wr, relu_mask=V, colsum=g["view_fc.bias"])
@@ -90,10 +91,36 @@ def decoder_backward(net, tap, d_raw, latent_index):
     return g, dF
 
 
+USE_ARENA = os.environ.get("NB_BWD_ARENA", "1") != "0"  # one zero fill per backward pass instead of one per accumulator
 BWD_INPUT_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # backward-input convolutions on the 16-bit matrix pipe (bf16 pairs)
 
 
-def encoder_backward(xyzc_net, ctx, drows_dense):
+DECODER_ARENA = [((n,), torch.float32) for n in (3, 1, 128, 256, 256, 256, 256, 256)]  # decoder_backward's zeros(), in order
+
+
+def arena_requests(net, ctx):
+    """Everything one backward pass accumulates into, in the order it is taken (RenderFunction.backward): the decoder's column
+    sums, the gradients of the four levels' active rows, and per encoder layer (last to first) the BatchNorm sums, the weight
+    gradient and — where the exact-fp32 backward-input kernel scatters with atomics — the input-row gradient; the vertex-code
+    and latent-table gradients."""
+    req = list(DECODER_ARENA)
+    layers = ctx[1:]
+    for rec in layers:
+        if rec["level"] is not None:
+            req.append(((max(int(rec["n_out_max"]), 1), int(rec["y"].shape[1])), torch.float32))
+    for rec in reversed(layers):
+        w = rec["conv"].weight
+        cin, cout = int(w.shape[3]), int(w.shape[4])
+        req.append(((2 * cout,), torch.float64))
+        req.append(((3, 3, 3, cin, cout), torch.float32))
+        if not (BWD_INPUT_SPLIT and rec["stride"] == 1 and cin >= 32):
+            req.append(((max(int(rec["n_in_max"]), 1), cin), torch.float32))
+    req.append(((6890, 16), torch.float32))
+    req.append((tuple(net.latent.weight.shape), torch.float32))
+    return req
+
+
+def encoder_backward(xyzc_net, ctx, drows_dense, arena=None):
     """Backward of SparseConvNet.forward(save=ctx).  drows_dense[l] [n_rows_l, C_l]: gradient w.r.t. the active rows of
     dense level l (from nb_trilinear_bwd).  Returns (grads, dcodes): grads maps `xyzc_net.<block>.<k>.weight|bias` to
     gradient tensors, dcodes is the gradient of the 6890 x 16 vertex codes."""
@@ -122,24 +149,26 @@ def encoder_backward(xyzc_net, ctx, drows_dense):
         # and the 16-channel ones keep the exact-fp32 kernel.
         on_pipe = BWD_INPUT_SPLIT and rec["stride"] == 1 and cin >= 32
         dx_split = None
+        take = (lambda shape, dt=torch.float32: arena.take(shape, dt)) if arena is not None else (lambda shape, dt=torch.float32: None)  # noqa: E731
         if BWD_INPUT_SPLIT and cin >= 32:  # (the weight gradient of every >= 32-channel layer takes the planes too)
             dx, dgamma, dbeta, dx_split = ops.enc_bn_relu_bwd(dy, y, x, rec["n_out"], rec["n_out_max"], rec["bstats"], bn.eps,
-                                                              bn.weight.detach(), want_split=True)
+                                                              bn.weight.detach(), want_split=True, sums=take((2 * cout,), torch.float64))
         else:
             dx, dgamma, dbeta = ops.enc_bn_relu_bwd(dy, y, x, rec["n_out"], rec["n_out_max"], rec["bstats"], bn.eps,
-                                                    bn.weight.detach())
+                                                    bn.weight.detach(), sums=take((2 * cout,), torch.float64))
         g[names[id(bn)] + ".weight"] = dgamma
         g[names[id(bn)] + ".bias"] = dbeta
         g[names[id(conv)] + ".weight"] = ops.enc_conv_bwd_weight(rec["in_rows"], rec["in_grid"], rec["in_dhw"], rec["out_lin"],
                                                                rec["n_out"], rec["n_out_max"], rec["out_dhw"], rec["stride"],
-                                                               dx, cin, cout, dx_split=dx_split)
+                                                               dx, cin, cout, dx_split=dx_split, out=take((3, 3, 3, cin, cout)))
         if on_pipe:
             dy = ops.enc_conv16(dx_split, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
-                                rec["in_dhw"], 1, ops.enc_conv_pack16(w, backward_input=True), cout, cin, bf16=True)[0]
+                                rec["in_dhw"], 1, xyzc_net._packed16(conv, backward_input=True), cout, cin, bf16=True)[0]
         else:
             dy = ops.enc_conv_bwd_input(dx, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
-                                        rec["in_dhw"], rec["stride"], w)
-    dcodes = ops.enc_scatter_codes_bwd(dy, head["rows_vert"], head["n_rows"], head["n_max"], 6890)
+                                        rec["in_dhw"], rec["stride"], w, out=take((max(int(rec["n_in_max"]), 1), cin)))
+    dcodes = ops.enc_scatter_codes_bwd(dy, head["rows_vert"], head["n_rows"], head["n_max"], 6890,
+                                       out=arena.take((6890, 16)) if arena is not None else None)
     return g, dcodes
 
 
@@ -194,17 +223,22 @@ class RenderFunction(torch.autograd.Function):
         S = z.shape[1]
         d_raw = ops.composite_bwd(raw.view(-1, S, 4), z, rd, d_rgb.reshape(-1, 3).float().contiguous(), cfg.white_bkgd)
         li = ctx.sp_input["latent_index"]
-        g, dF = decoder_backward(net, tap, d_raw.view(-1, 4), li)
+        # ONE zero fill for every accumulator of the pass (column sums, atomics' targets: ~60 fills and memsets otherwise)
+        arena = ops.ZeroArena(ops.ZeroArena.size_of(arena_requests(net, ctx.enc_ctx)), w.device) if USE_ARENA else None
+        g, dF = decoder_backward(net, tap, d_raw.view(-1, 4), li, arena)
         layers = ctx.enc_ctx[1:]
         dense = [rec for rec in layers if rec["level"] is not None]
         grids = [rec["out_grid"] for rec in dense]
-        drows = [torch.zeros((rec["n_out_max"] if rec["n_out_max"] > 0 else 1, rec["y"].shape[1]), dtype=torch.float32,
-                             device=w.device) for rec in dense]
+        if arena is not None:
+            drows = [arena.take((max(int(rec["n_out_max"]), 1), rec["y"].shape[1])) for rec in dense]
+        else:
+            drows = [torch.zeros((rec["n_out_max"] if rec["n_out_max"] > 0 else 1, rec["y"].shape[1]), dtype=torch.float32,
+                                 device=w.device) for rec in dense]
         ops.trilinear_bwd(ctx.scene, grids, drows, w, dF, run_length=S)  # w: [rays x S, 3], a ray's samples consecutive
-        ge, dcodes = encoder_backward(net.xyzc_net, ctx.enc_ctx, drows)
+        ge, dcodes = encoder_backward(net.xyzc_net, ctx.enc_ctx, drows, arena)
         g.update(ge)
         g["c.weight"] = dcodes
-        glat = torch.zeros_like(net.latent.weight)
+        glat = arena.take(tuple(net.latent.weight.shape)) if arena is not None else torch.zeros_like(net.latent.weight)
         glat.index_copy_(0, li.reshape(-1)[:1].long(), g.pop("latent.row")[None])
         g["latent.weight"] = glat
         out = []

@@ -162,3 +162,78 @@ def test_sparsify_beyond_the_two_kernel_scan():
     assert int(n_rows) == lin.numel() and bool((rows_lin[:lin.numel()].long() == lin).all())
     g = grid.reshape(-1)
     assert bool((g[lin] == torch.arange(lin.numel(), device=DEV, dtype=torch.int32)).all()) and int((g >= 0).sum()) == lin.numel()
+
+
+def test_dense_volumes_are_made_on_first_access_only(monkeypatch):
+    """Inference: encode_sparse_voxels returns the levels' active rows; the march of the default arithmetic renders from them
+    without a dense volume ever existing, bit for bit what the eagerly scattered volumes render; looking at the list
+    materialises `.dense()` (the reference's [1,C,D,H,W] tensors), equal to the eager ones."""
+    from neuralbody_amd import network as nbnet
+
+    r, sd, body, net, bd, rend = _small(train=False)
+    with torch.no_grad():
+        sp = rend.prepare_sp_input(bd)
+        lazy = net.encode_sparse_voxels(sp)
+        assert isinstance(lazy, nbnet.FeatureVolumes) and not lazy.is_dense() and len(lazy) == 4
+        out_lazy = rend.render(bd, feature_volume=lazy)
+        assert not lazy.is_dense(), "the f16f6 march must not have materialised the dense volumes"
+        assert net.fold_saturated(lazy) == 0
+        monkeypatch.setattr(nbnet, "LAZY_DENSE", False)
+        eager = net.encode_sparse_voxels(sp)
+        assert eager.is_dense()
+        out_eager = rend.render(bd, feature_volume=eager)
+        for k in ("rgb_map", "acc_map", "depth_map", "weights"):
+            assert H.same_bits(out_lazy[k], out_eager[k]), k
+        for l in range(4):
+            assert tuple(lazy[l].shape) == tuple(eager[l].shape) and H.same_bits(lazy[l].contiguous(), eager[l].contiguous()), l
+        assert lazy.is_dense()
+        # the exact arithmetic reads the dense volumes: it materialises them itself
+        net32 = H.make_network(sd, DEV, False, precision="f32")
+        rend32 = H.make_renderer(net32, r)
+        monkeypatch.setattr(nbnet, "LAZY_DENSE", True)
+        lz = net32.encode_sparse_voxels(sp)
+        assert not lz.is_dense()
+        a = rend32.render(bd, feature_volume=lz)["rgb_map"]
+        assert lz.is_dense()
+        monkeypatch.setattr(nbnet, "LAZY_DENSE", False)
+        b = rend32.render(bd)["rgb_map"]
+        assert H.same_bits(a, b)
+
+
+def test_planes_that_leave_the_fp16_range_are_counted_and_auto_takes_the_exact_kernel():
+    """nb_fold_build counts the fc_0 . V products beyond +-65504: 0 for the fixture's weights; with fc_0 scaled by
+    1e6 the count is not 0, `auto` warns once and renders with the exact kernel — the same pixels as precision 'f32'."""
+    r, sd, body, net, bd, rend = _small(precision="auto", train=False)
+    with torch.no_grad():
+        rend.render(bd)
+        assert net.march_precision() == "f16f6"
+        net.fc_0.weight.mul_(1e6)
+        net.fc_0.bias.mul_(1e6)
+        with pytest.warns(UserWarning, match="exceed the fp16 range"):
+            out = rend.render(bd)
+        assert net.march_precision() == "f32"
+        net32 = H.make_network(sd, DEV, False, precision="f32")
+        net32.fc_0.weight.mul_(1e6)
+        net32.fc_0.bias.mul_(1e6)
+        ref = H.make_renderer(net32, r).render(bd)
+    assert H.same_bits(out["rgb_map"], ref["rgb_map"])
+
+
+def test_planes_of_foreign_volumes_are_sized_by_their_rows_and_kept():
+    """A plain list of dense volumes: the planes hold as many rows as the volumes have non-zero voxels (not one per
+    voxel of the grid), and a second decode of the same tensors reuses them."""
+    r, sd, body, net, bd, rend = _small(train=False)
+    with torch.no_grad():
+        sp = rend.prepare_sp_input(bd)
+        plain = [v.clone() for v in net.encode_sparse_voxels(sp)]
+        wpts, _ = rend.get_sampling_points(bd["ray_o"][:, ::9], bd["ray_d"][:, ::9], bd["near"][:, ::9], bd["far"][:, ::9])
+        w = wpts.reshape(1, -1, 3)
+        a = net.calculate_density(w, plain, sp)
+        first = net._foreign_fold
+        nz = sum(int((v[0] != 0).any(0).sum()) for v in plain)
+        assert first[3][1][0].shape[0] == first[3][0].zero_row + 1 and first[3][0].zero_row <= nz + 4
+        b = net.calculate_density(w, plain, sp)
+        assert net._foreign_fold is first and H.same_bits(a, b)
+        plain[0].mul_(2.0)  # rewritten in place: a new version, new planes
+        net.calculate_density(w, plain, sp)
+        assert net._foreign_fold is not first

@@ -169,3 +169,62 @@ def test_prefetched_encoder_renders_the_same_frames(precision):
     assert same(other, serial[2]) and same(late, serial[1]) and same(changed, serial[4])
     with pytest.raises(RuntimeError):
         rend.prefetch(H.device_batch(frames[0], DEV))  # autograd on: the training step encodes inside its graph
+
+
+def test_prefetch_queues_behind_an_inline_encoder_pass():
+    """a render() that encodes inline on the main stream (no ticket: the first view of a loop) followed by a fenced
+    prefetch — the prefetched pass must queue behind the inline one, since in train() mode both update the BatchNorm running
+    statistics in place.  The statistics and counters after the loop equal those of the serial loop."""
+    import copy
+
+    from neuralbody_amd.renderer import RenderConfig, Renderer
+
+    sd = syn.make_weights(3, num_train_frame=7)
+    net_a = H.make_network(sd, DEV, True, H.DEFAULT_PRECISION)
+    net_b = copy.deepcopy(net_a)
+    frames = [_frame(f)[1] for f in range(4)]
+    with torch.no_grad():
+        ra = Renderer(net_a, RenderConfig(N_samples=64, perturb=0.0, H=16, W=16))
+        for b in frames:
+            ra.render(H.device_batch(b, DEV))
+        rb = Renderer(net_b, RenderConfig(N_samples=64, perturb=0.0, H=16, W=16))
+        nxt, ticket = H.device_batch(frames[0], DEV), None
+        for f in range(4):
+            cur, nxt = nxt, (H.device_batch(frames[f + 1], DEV) if f + 1 < 4 else None)
+            fence = rb.fence()
+            rb.render(cur, prefetched=ticket)  # f == 0: encodes inline, then every later pass comes from a ticket
+            assert getattr(rb, "_inline_enc", None) is not None  # recorded by the inline pass of f == 0
+            ticket = rb.prefetch(nxt, after=fence) if nxt is not None else None
+    torch.cuda.synchronize()
+    sa, sb = net_a.state_dict(), net_b.state_dict()
+    for k in sa:
+        if k.endswith("num_batches_tracked"):
+            assert int(sa[k]) == int(sb[k]) == 4, k
+        elif "running_" in k:
+            assert float((sa[k] - sb[k]).abs().max()) <= 1e-6 * max(1.0, float(sa[k].abs().max())), k
+
+
+def test_rays_without_a_slot_read_zero():
+    """a mask that names fewer pixels than the batch holds rays — the slot list then covers only the first rays; the
+    others must come back as zeros, not as uninitialised memory."""
+    from neuralbody_amd.renderer import RenderConfig, Renderer
+
+    sd = syn.make_weights(3, num_train_frame=7)
+    net = H.make_network(sd, DEV, False, H.DEFAULT_PRECISION)
+    body, b, _ = _frame(0)
+    bd = H.device_batch(b, DEV)
+    n = bd["ray_o"].shape[1]
+    rend = Renderer(net, RenderConfig(N_samples=64, perturb=0.0, H=16, W=16))
+    short = bd["mask_at_box"].clone().reshape(-1)
+    assert n >= 128
+    keep = n - min(70, n // 3)
+    idx = torch.nonzero(short).reshape(-1)[keep:]
+    short[idx] = False  # the last rays have no pixel any more
+    bad = dict(bd)
+    bad["mask_at_box"] = short.reshape(bd["mask_at_box"].shape)
+    with torch.no_grad():
+        torch.empty((n, 64), device=DEV).fill_(float("nan"))  # poison the allocator's free blocks
+        out = rend.render(bad)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out["rgb_map"]).all()) and float(out["weights"][0, keep:].abs().max()) == 0.0
+    assert float(out["rgb_map"][0, :keep].abs().max()) > 0.0

@@ -77,6 +77,67 @@ def test_sharded_render_gloo_world2(tmp_path, n):
         assert os.path.exists(tmp_path / ("ok_%d.npy" % r))
 
 
+class FakeImageRenderer(FakeRenderer):
+    """... with an image geometry, as the real Renderer has: render_sharded then hands out whole 8-row tile bands."""
+
+    def __init__(self, H, W):
+        from types import SimpleNamespace
+
+        self.cfg = SimpleNamespace(H=H, W=W)
+        self.seen = None
+
+    def render(self, batch, ray_range=None):
+        self.seen = ray_range
+        return FakeRenderer.render(self, batch, ray_range)
+
+
+def _worker_tiled(rank, world, port, H, W, covered, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", init_method="env://", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(1)
+        mask = torch.ones(H * W, dtype=torch.bool) if covered else (torch.rand(H * W, generator=g) < 0.4)
+        n = int(mask.sum())
+        batch = {"ray_o": torch.randn(1, n, 3, generator=g), "ray_d": torch.randn(1, n, 3, generator=g), "mask_at_box": mask[None]}
+        ren = FakeImageRenderer(H, W)
+        got = parallel.render_sharded(ren, batch, keys=("rgb_map", "acc_map"))
+        b, e = ren.seen
+        full = FakeRenderer().render(batch)
+        assert torch.equal(got["rgb_map"], full["rgb_map"]) and torch.equal(got["acc_map"], full["acc_map"])
+        # the range is the rays of whole 8-row bands: its first / last ray sit on band borders of the pixel grid
+        pix = torch.nonzero(mask).reshape(-1)
+        r0, r1 = parallel.shard_tile_rows(H, rank, world)
+        assert (r0 % 8 == 0 or r0 == H) and (r1 % 8 == 0 or r1 == H)
+        if e > b:
+            assert int(pix[b]) // W >= r0 and int(pix[e - 1]) // W < r1
+        assert b == int((pix < r0 * W).sum()) and e == int((pix < r1 * W).sum())
+        np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([b, e]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,W,covered", [(2, 32, 24, True), (4, 40, 16, True), (4, 20, 16, False), (2, 8, 8, True)])
+def test_tile_aligned_sharding_gloo(tmp_path, world, H, W, covered):
+    """world-2 and world-4: every rank gets whole 8-row tile bands (ragged: 5 bands over 4 ranks, 3 bands over 4, 1 band over 2),
+    the gathered image equals the serial one, and the ranges tile the ray list."""
+    port = _free_port()
+    mp.spawn(_worker_tiled, args=(world, port, H, W, covered, str(tmp_path)), nprocs=world, join=True)
+    ranges = [np.load(tmp_path / ("ok_%d.npy" % r)) for r in range(world)]
+    assert ranges[0][0] == 0 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+
+
+def test_shard_tile_rows_balance():
+    for H in (8, 20, 512, 520, 1024):
+        for world in (1, 2, 3, 4, 8):
+            rows = [parallel.shard_tile_rows(H, r, world) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == H and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+            bands = [(b - a + 7) // 8 for a, b in rows]
+            assert max(bands) - min(bands) <= 1
+    assert parallel.shard_range_tiled(512 * 512, 3, 8, 512, 512) == (3 * 64 * 512, 4 * 64 * 512)
+    with pytest.raises(ValueError):
+        parallel.shard_range_tiled(100, 0, 2, 16, 16)
+
+
 def test_reduce_timings_without_a_process_group():
     assert parallel.reduce_timings(2.5, [1.0, 2.0], 1) == (2.5, [[1.0, 2.0]])
 
