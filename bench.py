@@ -687,14 +687,25 @@ def main():
     ap.add_argument("--n-check", type=int, default=None, help="fullview-parity: rays checked (default: every ray of the view)")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries print there too (RCCL writes its version banner through C stdio, which a
+    # redirected stdout delivers at process exit, behind the JSON line): from here on file descriptor 1 is stderr for everybody, and
+    # only `emit` writes to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(line):
+        real_stdout.write(line + "\n")
+        real_stdout.flush()
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.mode == "cpu-reference":  # the modes without a GPU: they time the reference itself where its tree exists
-        print(json.dumps(cpu_reference_baseline(args)))
+        emit(json.dumps(cpu_reference_baseline(args)))
         return
     if args.mode == "cpu-reference-train":
-        print(json.dumps(cpu_reference_train(args)))
+        emit(json.dumps(cpu_reference_train(args)))
         return
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
@@ -715,15 +726,15 @@ def main():
     if args.mode == "train":
         if world != 1:
             raise SystemExit("--mode train is a single-GPU informational run")
-        print(json.dumps(train_bench(args, dev)))
+        emit(json.dumps(train_bench(args, dev)))
         return
     if args.mode == "fullview-parity":
-        print(json.dumps(fullview_parity(args, dev)))
+        emit(json.dumps(fullview_parity(args, dev)))
         return
     if args.mode == "turntable":
         if world != 1:
             raise SystemExit("--mode turntable is a single-GPU informational run (views shard with render_views_sharded)")
-        print(json.dumps(turntable_bench(args, dev)))
+        emit(json.dumps(turntable_bench(args, dev)))
         return
     H = W = args.size
     sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
@@ -885,7 +896,7 @@ def main():
             vols = net.encode_sparse_voxels(rend.prepare_sp_input(poses[0]))
         result["cpu_baseline"] = cpu_baseline(sd, poses[0], vols, S)
     if rank == 0:
-        print(json.dumps(result))
+        emit(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -445,10 +445,12 @@ class Network(nn.Module):
             self._auto_checks_planes(key, fold)
             return fold
         # volumes from elsewhere (cloned, loaded, another encoder's): nothing to hang a cache on but the tensors themselves
-        fkey = tuple((v, v._version) for v in vols)
+        # (`vols` are fresh channels-last VIEWS of the caller's tensors at every call: the key is their storage, address and version;
+        # the entry keeps the views, hence the storages, alive, so an address cannot be recycled under it)
+        fkey = tuple((v, v.untyped_storage()._cdata, v.data_ptr(), v._version, tuple(v.shape)) for v in vols)
         old = self._foreign_fold
         if old is not None and old[1] == key and old[2] is w.untyped_storage() and len(old[0]) == len(fkey) and \
-                all(a[0] is b[0] and a[1] == b[1] for a, b in zip(old[0], fkey)):
+                all(a[1:] == b[1:] for a, b in zip(old[0], fkey)):
             return old[3]
         sparse = [ops.sparsify(v) for v in vols]
         counts = torch.cat([sp[2] for sp in sparse]).tolist()  # one read-back: a capacity of every voxel would be ~1 GB of planes
