@@ -828,7 +828,7 @@ def main():
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
-    tfile = {"f16f6": "r04_march_fold_traffic.json"}.get(net.march_precision())
+    tfile = {"f16f6": "r05_march_fold_traffic.json"}.get(net.march_precision())
     tpath = os.path.join(ROOT, "profiles", tfile or "none")
     if tfile and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
         with open(tpath) as f:

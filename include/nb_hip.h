@@ -284,13 +284,16 @@ int nb_trilinear_bwd(const nb_scene *scene, const int32_t *const grids[4], float
 
 /* Voxelise the SMPL vertices: dedup (last vertex index wins, spconv_standin rule),
  * build the index grid and compact row list.
- *   coord dev [n_verts,3] (d,h,w) int32; grid dev [D*H*W] int32 (overwritten);
+ *   coord dev [n_verts,3] (d,h,w) int32; grid dev [D*H*W] int32 (overwritten; filled with -1 by the call unless flags has
+ *   NB_GRID_PREFILLED);
  *   rows_vert dev [n_verts] int32 out: vertex id feeding each row; rows_lin dev [n_verts]
  *   int32 out: linear voxel index of each row; n_rows dev [1] int32 out.
  *   scratch dev: at least nb_scan_scratch_size(n_verts) bytes. */
 int64_t nb_scan_scratch_size(int64_t n);
+#define NB_GRID_PREFILLED 1 /* flags of nb_enc_voxelize / nb_enc_downsample_index: the caller filled the index grid with -1 (one fill
+                               for the grids of all five levels of an encoder pass instead of one memset each) */
 int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3], int32_t *grid,
-                    int32_t *rows_vert, int32_t *rows_lin, int32_t *n_rows, void *scratch,
+                    int32_t *rows_vert, int32_t *rows_lin, int32_t *n_rows, void *scratch, int32_t flags,
                     void *stream);
 
 /* Output active set of SparseConv3d(k=3, s=2, p=1) (latent_xyzc.py:265-274): every output
@@ -298,7 +301,7 @@ int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3],
  * order.  in_lin dev [n_in_max] with *n_in valid (device count); out grid dev [Do*Ho*Wo]. */
 int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t n_in_max,
                             const int32_t in_dhw[3], const int32_t out_dhw[3], int32_t *out_grid,
-                            int32_t *out_lin, int32_t *n_out, int32_t n_out_max, void *scratch,
+                            int32_t *out_lin, int32_t *n_out, int32_t n_out_max, void *scratch, int32_t flags,
                             void *stream);
 
 /* One sparse 3x3x3 convolution (stride 1 submanifold or stride 2) without bias:
@@ -367,6 +370,8 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
  * [n_rows, c]; batch_stats dev [2c+1] as written by nb_enc_bn_relu; sums dev [2c] fp64 scratch.
  * Outputs: dx dev [n_rows, c] (may alias dy), dgamma / dbeta dev [c]; dx_split (dev or NULL): dx once more as two bf16
  * planes [2, n_rows_max, c] (heads | remainders) for the backward-input convolution on the matrix pipe. */
+#define NB_BWD_RULEBOOK_READY 2 /* nb_enc_conv_bwd_weight: `rulebook` already holds nbr(r, o) of this (in_grid, out_lin, stride) — written by
+                                  an earlier call for a layer of the same level (its submanifold layers share one table) */
 #define NB_BWD_ZEROED 1 /* flags of nb_enc_bn_relu_bwd / nb_enc_conv_bwd_weight: the caller cleared `sums` / `dweight` (one zero fill
                            for the accumulators of a whole backward pass instead of one memset per layer) */
 int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const int32_t *n_rows,
@@ -381,7 +386,7 @@ int nb_enc_conv_bwd_input(const float *dx, const int32_t *out_grid, const int32_
                           const float *weight, int32_t cin, int32_t cout, float *din, void *stream);
 
 /* Gradient of the conv weight [3,3,3,Cin,Cout] (zeroed by the call unless flags has NB_BWD_ZEROED): dW[o] = sum_r in[nbr(r,o)]^T (x) dx[r].
- * rulebook: dev int32 scratch [n_out_max * 27] (receives nbr(r,o), -1 = no active input voxel).
+ * rulebook: dev int32 scratch [n_out_max * 27] (receives nbr(r,o), -1 = no active input voxel; only read with NB_BWD_RULEBOOK_READY).
  * dx_split (dev or NULL): dx as bf16 head / remainder planes [2, n_out_max, Cout] (nb_enc_bn_relu_bwd writes them); when given
  * and Cin >= 32 the product runs on the 16-bit matrix pipe with both operands as bf16 pairs (three products, fp32 accumulate,
  * ~2^-16 relative) instead of the exact-fp32 MFMA kernel. */

@@ -81,8 +81,8 @@ SIGNATURES = {
     "nb_colsum": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
     "nb_trilinear_bwd": (C.c_int, [C.POINTER(NbScene), C.c_void_p * 4, C.c_void_p * 4, _P, _P, _I64, _I32, _P]),
     "nb_scan_scratch_size": (_I64, [_I64]),
-    "nb_enc_voxelize": (C.c_int, [_P, _I32, _I32x3, _P, _P, _P, _P, _P, _P]),
-    "nb_enc_downsample_index": (C.c_int, [_P, _P, _I32, _I32x3, _I32x3, _P, _P, _P, _I32, _P, _P]),
+    "nb_enc_voxelize": (C.c_int, [_P, _I32, _I32x3, _P, _P, _P, _P, _P, _I32, _P]),
+    "nb_enc_downsample_index": (C.c_int, [_P, _P, _I32, _I32x3, _I32x3, _P, _P, _P, _I32, _P, _I32, _P]),
     "nb_enc_conv": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _I32, _P]),
     "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "nb_enc_conv_pack16": (C.c_int, [_P, _I32, _I32, _P, _I32, _P]),

@@ -928,7 +928,7 @@ static int conv16_dispatch(const uint16_t *in_split, int32_t in_rows_cap, const 
 extern "C" {
 
 int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3], int32_t *grid, int32_t *rows_vert,
-                    int32_t *rows_lin, int32_t *n_rows, void *scratch, void *stream) {
+                    int32_t *rows_lin, int32_t *n_rows, void *scratch, int32_t call_flags, void *stream) {
     NB_REQUIRE(dhw && grid && n_rows, "nb_enc_voxelize: NULL pointer");
     NB_REQUIRE(n_verts == 0 || (coord && rows_vert && rows_lin && scratch), "nb_enc_voxelize: NULL pointer");
     NB_REQUIRE(n_verts >= 0 && dhw[0] > 0 && dhw[1] > 0 && dhw[2] > 0, "nb_enc_voxelize: bad sizes");
@@ -936,7 +936,7 @@ int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3],
     hipStream_t st = (hipStream_t)stream;
     const Dims g = {dhw[0], dhw[1], dhw[2]};
     const long long nvox = (long long)g.d * g.h * g.w;
-    NB_HIP(hipMemsetAsync(grid, 0xFF, nvox * sizeof(int), st));
+    if (!(call_flags & NB_GRID_PREFILLED)) NB_HIP(hipMemsetAsync(grid, 0xFF, nvox * sizeof(int), st));
     if (n_verts == 0) {
         NB_HIP(hipMemsetAsync(n_rows, 0, sizeof(int), st));
         return NB_OK;
@@ -954,7 +954,7 @@ int nb_enc_voxelize(const int32_t *coord, int32_t n_verts, const int32_t dhw[3],
 
 int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3],
                             const int32_t out_dhw[3], int32_t *out_grid, int32_t *out_lin, int32_t *n_out,
-                            int32_t n_out_max, void *scratch, void *stream) {
+                            int32_t n_out_max, void *scratch, int32_t flags, void *stream) {
     NB_REQUIRE(in_lin && n_in && in_dhw && out_dhw && out_grid && out_lin && n_out && scratch,
                "nb_enc_downsample_index: NULL pointer");
     NB_REQUIRE(n_in_max >= 0 && n_out_max >= 0, "nb_enc_downsample_index: negative capacity");
@@ -964,13 +964,13 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
                    "nb_enc_downsample_index: out_dhw[%d] = %d is not floor((%d - 1) / 2) + 1", k, out_dhw[k], in_dhw[k]);
     hipStream_t st = (hipStream_t)stream;
     const long long nvox = (long long)go.d * go.h * go.w;
-    NB_HIP(hipMemsetAsync(out_grid, 0xFF, nvox * sizeof(int), st));
-    int *flags, *pos, *bs;
-    nb_scan_carve(scratch, nvox, &flags, &pos, &bs);
+    if (!(flags & NB_GRID_PREFILLED)) NB_HIP(hipMemsetAsync(out_grid, 0xFF, nvox * sizeof(int), st));
+    int *fl, *pos, *bs;
+    nb_scan_carve(scratch, nvox, &fl, &pos, &bs);
     if (n_in_max > 0)
         hipLaunchKernelGGL(down_mark_kernel, dim3(nb_ceil_div(n_in_max, 256)), dim3(256), 0, st, in_lin, n_in, gi, go,
                            out_grid);
-    (void)flags, (void)pos;
+    (void)fl, (void)pos;
     const dim3 tiles((unsigned)nb_scan_blocks(nvox)), blk(nbscan::BLOCK);
     hipLaunchKernelGGL(grid_count_kernel, tiles, blk, 0, st, out_grid, nvox, bs);
     hipLaunchKernelGGL(grid_number_kernel, tiles, blk, 0, st, out_grid, nvox, bs, n_out_max, out_lin, n_out);

@@ -466,8 +466,9 @@ int nb_enc_conv_bwd_weight(const float *in_rows, const int32_t *in_grid, const i
     if (n_out_max <= 0) return NB_OK;
     NB_REQUIRE(rulebook != nullptr, "nb_enc_conv_bwd_weight: rulebook scratch is NULL");
     const Dims go = {out_dhw[0], out_dhw[1], out_dhw[2]}, gi = {in_dhw[0], in_dhw[1], in_dhw[2]};
-    hipLaunchKernelGGL(conv_rulebook_kernel, dim3(nb_ceil_div((long long)n_out_max * 27, 256)), dim3(256), 0, st, in_grid, gi,
-                       out_lin, n_out, go, stride, rulebook);
+    if (!(flags & NB_BWD_RULEBOOK_READY))
+        hipLaunchKernelGGL(conv_rulebook_kernel, dim3(nb_ceil_div((long long)n_out_max * 27, 256)), dim3(256), 0, st, in_grid, gi,
+                           out_lin, n_out, go, stride, rulebook);
     if (dx_split && cin >= 32) {  // bf16 pairs of dx given: the matrix-pipe kernel (the 16-channel layers stay exact fp32)
         const long long plane = (long long)n_out_max * cout;
 #define X16(CI, CO)                                                                                                   \

@@ -189,13 +189,22 @@ class SparseConvNet(nn.Module):
                 dense_shapes.append(d + [cout])
         int_bufs = list(torch.zeros(sum(int_sizes), dtype=torch.int32, device=dev).split(int_sizes))
         zeroed_int = int_bufs.pop(0)
+        # ... and ONE fill with -1 for the index grids of the five levels
+        grid_shapes, d = [list(dhw)], dhw
+        for name, cin, cout, n, stride, j in layers:
+            if stride == 2:
+                d = ops.down_dhw(d)
+                grid_shapes.append(list(d))
+        grid_sizes = [(math.prod(sh) + 63) // 64 * 64 for sh in grid_shapes]
+        grid_bufs = [b[:math.prod(sh)].view(sh) for b, sh in zip(torch.full((sum(grid_sizes),), -1, dtype=torch.int32, device=dev).split(grid_sizes),
+                                                                 grid_shapes)]
         n_stats = 2 * len(layers) * 256  # fp64 [layers, 256] in front (8-byte aligned), the volumes behind it (64-float aligned)
         dense_sizes = [0 if lazy else (math.prod(sh) + 63) // 64 * 64 for sh in dense_shapes]
         f32_buf = torch.zeros(n_stats + sum(dense_sizes), dtype=torch.float32, device=dev)
         stats_all = f32_buf[:n_stats].view(torch.float64).view(len(layers), 256)
         dense_bufs = [None if lazy else b[:math.prod(sh)].view(sh) for b, sh in zip(f32_buf[n_stats:].split(dense_sizes), dense_shapes)]
         level_rows, level_shapes = [], []
-        grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw, buf=int_bufs.pop(0))
+        grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw, buf=int_bufs.pop(0), grid=grid_bufs.pop(0))
         rows = ops.enc_gather_codes(codes, rows_vert, n_rows, n_max)
         if save is not None:
             save.append({"rows_vert": rows_vert, "n_rows": n_rows, "n_max": n_max})
@@ -216,7 +225,8 @@ class SparseConvNet(nn.Module):
             block = getattr(self, name)
             conv, bn = block[3 * j], block[3 * j + 1]
             if stride == 2:
-                out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw, buf=int_bufs.pop(0))
+                out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw, buf=int_bufs.pop(0),
+                                                                                           grid=grid_bufs.pop(0))
             else:
                 out_grid, out_lin, n_out, n_out_max, out_dhw = grid, rows_lin, n_rows, n_max, dhw
             if rows_are_split:

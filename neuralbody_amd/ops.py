@@ -235,7 +235,10 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
         _req(viewdir, torch.float32, (n, 3), "viewdir")
         _req(latent_bias, torch.float32, (int(_lib.lib().nb_mlp_latent_bias_size()),), "latent_bias")
     out = torch.empty((n, 1 if density_only else 4), dtype=torch.float32, device=wpts.device)
-    dbg = torch.zeros((n, DBG_WIDTH), dtype=torch.float32, device=wpts.device) if debug else None
+    dbg = None
+    if debug:  # the kernel writes columns [0, 1594) of every point's tap; the six pad columns are cleared (a strided 1.5 MB fill,
+        dbg = torch.empty((n, DBG_WIDTH), dtype=torch.float32, device=wpts.device)  # not the 419 MB of a training batch)
+        dbg[:, TAP["PE"][1]:].zero_()
     check(_lib.lib().nb_decode_points(C.byref(sc), ptr(packed), ptr(latent_bias), ptr(wpts), ptr(viewdir), n,
                                       1 if density_only else 0, ptr(out), ptr(dbg), _lib.PRECISIONS[precision],
                                       _stream()), "nb_decode_points")
@@ -317,14 +320,17 @@ def _i3(v):
     return (C.c_int32 * 3)(int(v[0]), int(v[1]), int(v[2]))
 
 
-def enc_voxelize(coord, dhw, buf=None):
+def enc_voxelize(coord, dhw, buf=None, grid=None):
     """nb_enc_voxelize: coord [n,3] int32 (d,h,w) -> (grid [D,H,W] i32, rows_vert, rows_lin, n_rows[1]).
     buf: a ZEROED int32 [2 * max(n, 1) + 1] buffer of the caller's for the three outputs (the encoder clears the index buffers of
-    all its levels with one fill)."""
+    all its levels with one fill); grid: an int32 [D,H,W] buffer ALREADY FILLED WITH -1 (likewise one fill for all levels)."""
     _req(coord, torch.int32, (None, 3), "coord")
     n = coord.shape[0]
     dev = coord.device
-    grid = torch.empty([int(s) for s in dhw], dtype=torch.int32, device=dev)
+    prefilled = grid is not None
+    if grid is None:
+        grid = torch.empty([int(s) for s in dhw], dtype=torch.int32, device=dev)
+    _req(grid, torch.int32, tuple(int(s) for s in dhw), "grid")
     m = max(n, 1)
     if buf is None:
         buf = torch.zeros(2 * m + 1, dtype=torch.int32, device=dev)  # one fill
@@ -333,7 +339,7 @@ def enc_voxelize(coord, dhw, buf=None):
     rows_vert, rows_lin, n_rows = buf[:m], buf[m:2 * m], buf[2 * m:]
     scratch = scan_scratch(n, dev)
     check(_lib.lib().nb_enc_voxelize(ptr(coord), n, _i3(dhw), ptr(grid), ptr(rows_vert), ptr(rows_lin), ptr(n_rows),
-                                     ptr(scratch), _stream()), "nb_enc_voxelize")
+                                     ptr(scratch), 1 if prefilled else 0, _stream()), "nb_enc_voxelize")
     return grid, rows_vert, rows_lin, n_rows
 
 
@@ -347,7 +353,7 @@ def down_capacity(n_in_max, in_dhw):
     return max(min(8 * int(n_in_max), out_dhw[0] * out_dhw[1] * out_dhw[2]), 1)
 
 
-def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None, buf=None):
+def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None, buf=None, grid=None):
     """nb_enc_downsample_index -> (out_grid, out_lin, n_out[1], n_out_max, out_dhw).
     buf: a ZEROED int32 [down_capacity(n_in_max, in_dhw) + 1] buffer of the caller's for out_lin and n_out."""
     _req(in_lin, torch.int32, (None,), "in_lin")
@@ -356,7 +362,9 @@ def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None, buf=None)
     out_dhw = down_dhw(in_dhw)
     nvox = out_dhw[0] * out_dhw[1] * out_dhw[2]
     n_out_max = down_capacity(n_in_max, in_dhw)
-    out_grid = torch.empty(out_dhw, dtype=torch.int32, device=dev)
+    prefilled = grid is not None  # an int32 [Do,Ho,Wo] buffer already filled with -1
+    out_grid = grid if prefilled else torch.empty(out_dhw, dtype=torch.int32, device=dev)
+    _req(out_grid, torch.int32, tuple(out_dhw), "out_grid")
     if buf is None:
         buf = torch.zeros(n_out_max + 1, dtype=torch.int32, device=dev)  # one fill
     else:
@@ -366,7 +374,7 @@ def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None, buf=None)
         scratch = scan_scratch(nvox, dev)
     check(_lib.lib().nb_enc_downsample_index(ptr(in_lin), ptr(n_in), int(n_in_max), _i3(in_dhw), _i3(out_dhw),
                                              ptr(out_grid), ptr(out_lin), ptr(n_out), n_out_max, ptr(scratch),
-                                             _stream()), "nb_enc_downsample_index")
+                                             1 if prefilled else 0, _stream()), "nb_enc_downsample_index")
     return out_grid, out_lin, n_out, n_out_max, out_dhw
 
 
@@ -749,7 +757,8 @@ def enc_conv_bwd_input(dx, out_grid, out_dhw, in_lin, n_in, n_in_max, in_dhw, st
     return din
 
 
-def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, dx, cin, cout, dx_split=None, out=None):
+def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, dx, cin, cout, dx_split=None, out=None,
+                        rulebook=None):
     """nb_enc_conv_bwd_weight -> dW [3,3,3,Cin,Cout].  dx_split (int16 [2, n_out_max, Cout], enc_bn_relu_bwd(want_split=True)):
     the product runs on the 16-bit matrix pipe with bf16 pairs (Cin >= 32)."""
     _req(in_rows, torch.float32, (None, cin), "in_rows")
@@ -759,10 +768,17 @@ def enc_conv_bwd_weight(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out
     zeroed = out is not None  # a ZeroArena view: the call's own memset is skipped
     dw = out if zeroed else torch.empty((3, 3, 3, cin, cout), dtype=torch.float32, device=dx.device)
     _req(dw, torch.float32, (3, 3, 3, cin, cout), "dweight")
-    rulebook = torch.empty(max(int(n_out_max), 1) * 27, dtype=torch.int32, device=dx.device)
+    # rulebook: a one-element list cache shared by the layers of one (input grid, output rows, stride): the first call fills it,
+    # the others reuse the neighbour table (the three submanifold layers of a level have the same one)
+    ready = rulebook is not None and len(rulebook) == 1
+    rb = rulebook[0] if ready else torch.empty(max(int(n_out_max), 1) * 27, dtype=torch.int32, device=dx.device)
+    _req(rb, torch.int32, (max(int(n_out_max), 1) * 27,), "rulebook")
     check(_lib.lib().nb_enc_conv_bwd_weight(ptr(in_rows), ptr(in_grid), _i3(in_dhw), ptr(out_lin), ptr(n_out),
                                             int(n_out_max), _i3(out_dhw), int(stride), ptr(dx), ptr(dx_split), cin, cout,
-                                            ptr(dw), ptr(rulebook), 1 if zeroed else 0, _stream()), "nb_enc_conv_bwd_weight")
+                                            ptr(dw), ptr(rb), (1 if zeroed else 0) | (2 if ready else 0), _stream()),
+          "nb_enc_conv_bwd_weight")
+    if rulebook is not None and not ready:
+        rulebook.append(rb)
     return dw
 
 

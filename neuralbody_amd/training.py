@@ -133,6 +133,7 @@ def encoder_backward(xyzc_net, ctx, drows_dense, arena=None):
             names[id(block[3 * j + 1])] = "xyzc_net.%s.%d" % (bname, 3 * j + 1)
     g = {}
     dy = None
+    rulebooks = {}  # (input grid, output rows, stride) -> [neighbour table]: the layers of a level share it
     for rec in reversed(layers):
         y, x = rec["y"], rec["x"]
         if rec["level"] is not None:
@@ -160,7 +161,9 @@ def encoder_backward(xyzc_net, ctx, drows_dense, arena=None):
         g[names[id(bn)] + ".bias"] = dbeta
         g[names[id(conv)] + ".weight"] = ops.enc_conv_bwd_weight(rec["in_rows"], rec["in_grid"], rec["in_dhw"], rec["out_lin"],
                                                                rec["n_out"], rec["n_out_max"], rec["out_dhw"], rec["stride"],
-                                                               dx, cin, cout, dx_split=dx_split, out=take((3, 3, 3, cin, cout)))
+                                                               dx, cin, cout, dx_split=dx_split, out=take((3, 3, 3, cin, cout)),
+                                                               rulebook=rulebooks.setdefault(
+                                                                   (rec["in_grid"].data_ptr(), rec["out_lin"].data_ptr(), rec["stride"]), []))
         if on_pipe:
             dy = ops.enc_conv16(dx_split, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
                                 rec["in_dhw"], 1, xyzc_net._packed16(conv, backward_input=True), cout, cin, bf16=True)[0]

@@ -210,7 +210,7 @@ def test_rays_without_a_slot_read_zero():
     from neuralbody_amd.renderer import RenderConfig, Renderer
 
     sd = syn.make_weights(3, num_train_frame=7)
-    net = H.make_network(sd, DEV, False, H.DEFAULT_PRECISION)
+    net = H.make_network(sd, DEV, True, H.DEFAULT_PRECISION)  # (batch statistics, as the other tests of this scene: a visible body)
     body, b, _ = _frame(0)
     bd = H.device_batch(b, DEV)
     n = bd["ray_o"].shape[1]

@@ -1,0 +1,19 @@
+"""Encoder + fold planes of one view, alone on the device (bench.encoder_bench) and the training step: A/B of library variants.
+    NB_LIB_PATH=neuralbody_amd/lib/libnb_hip_<variant>.so python tools/experiments/encoder_time.py [train]"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+a = argparse.Namespace(size=512, samples=64, precision=None, steps=20, warmup=5)
+dev = torch.device("cuda:0")
+e = bench.encoder_bench(a, dev)
+print("encoder %.4f ms, %s launches" % (e["encoder_ms"], e["launches_per_view"]))
+if "train" in sys.argv[1:]:
+    t = bench.train_bench(a, dev)
+    print("train step %.3f ms" % t["value"])
