@@ -27,11 +27,14 @@ struct Dims {
 __host__ __device__ constexpr int tile_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // ------------------------------------------------------------------ BatchNorm + ReLU backward
-__global__ void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *__restrict__ y, const float *__restrict__ x,
-                                     const int *__restrict__ n_rows, int C, const float *__restrict__ batch_stats,
-                                     float eps, double *__restrict__ sums) {
-    // block = 256 threads = 4 row lanes x 64 channels; grid.x over channel groups, grid.y over row slabs
-    __shared__ double pa[4][64], pb[4][64];
+__global__ __launch_bounds__(1024) void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *__restrict__ y,
+                                                             const float *__restrict__ x, const int *__restrict__ n_rows, int C,
+                                                             const float *__restrict__ batch_stats, float eps, double *__restrict__ sums) {
+    // block = 1024 threads = 16 row lanes x 64 channels; grid.x over channel groups, grid.y over row slabs.  Few, fat blocks:
+    // every block ends in one fp64 atomic per channel and sum, and L2 serialises the atomics of an address — with round 4's
+    // 2048 slabs of 256 threads a layer spent its 20 us waiting on 2048 atomics per address (r05_train_kernel_stats.md)
+    constexpr int RL = 16;
+    __shared__ double pa[RL][64], pb[RL][64];
     const int n = *n_rows;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
     const long long per = ((long long)n + gridDim.y - 1) / gridDim.y;
@@ -40,13 +43,13 @@ __global__ void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *
     if (c < C) {
         const double mean = batch_stats[c], invstd = 1.0 / sqrt((double)batch_stats[C + c] + (double)eps);
         // four rows per trip, their 12 loads issued together and four independent fp64 chains: the one-row loop ran at the
-        // latency of a load + two dependent fp64 adds per row (29 us per layer for 15-22 MB)
+        // latency of a load + two dependent fp64 adds per row
         double a4[4] = {0.0, 0.0, 0.0, 0.0}, b4[4] = {0.0, 0.0, 0.0, 0.0};
-        for (long long r = r0 + w; r < r1; r += 16) {
+        for (long long r = r0 + w; r < r1; r += 4 * RL) {
             float yv[4], dv[4], xv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const long long rr = r + 4 * q;
+                const long long rr = r + RL * q;
                 const bool ok = rr < r1;
                 const long long e = (ok ? rr : r) * C + c;
                 yv[q] = y[e];
@@ -68,8 +71,14 @@ __global__ void bn_bwd_reduce_kernel(const float *__restrict__ dy, const float *
     __syncthreads();
     if (w == 0 && c < C) {
         const int t = threadIdx.x;
-        atomicAdd(&sums[c], pa[0][t] + pa[1][t] + pa[2][t] + pa[3][t]);
-        atomicAdd(&sums[C + c], pb[0][t] + pb[1][t] + pb[2][t] + pb[3][t]);
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int q = 0; q < RL; ++q) {  // fixed order
+            sa += pa[q][t];
+            sb += pb[q][t];
+        }
+        atomicAdd(&sums[c], sa);
+        atomicAdd(&sums[C + c], sb);
     }
 }
 
@@ -418,10 +427,9 @@ int nb_enc_bn_relu_bwd(const float *dy, const float *y, const float *x, const in
     NB_REQUIRE(c > 0 && n_rows_max >= 0, "nb_enc_bn_relu_bwd: bad sizes");
     hipStream_t st = (hipStream_t)stream;
     if (!(flags & NB_BWD_ZEROED)) NB_HIP(hipMemsetAsync(sums, 0, 2 * (size_t)c * sizeof(double), st));
-    // 128 rows per block (32 per row lane): the deep levels have ~13 k rows x 128 channels, and a grid of a few dozen
-    // blocks looping over hundreds of rows each ran at 150 us per layer, latency bound
-    const int slabs = n_rows_max <= 128 ? 1 : (int)(nb_ceil_div(n_rows_max, 128) < 2048 ? nb_ceil_div(n_rows_max, 128) : 2048);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb_ceil_div(c, 64), slabs), dim3(256), 0, st, dy, y, x, n_rows, c,
+    // one block per 256 rows of CAPACITY, at most 256 slabs (the live rows are split evenly over whatever the grid holds)
+    const int slabs = n_rows_max <= 256 ? 1 : (int)(nb_ceil_div(n_rows_max, 256) < 256 ? nb_ceil_div(n_rows_max, 256) : 256);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb_ceil_div(c, 64), slabs), dim3(1024), 0, st, dy, y, x, n_rows, c,
                        batch_stats, eps, sums);
     const long long total = (long long)n_rows_max * c;
     const long long threads = total > c ? total : c;
