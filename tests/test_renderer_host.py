@@ -182,3 +182,56 @@ def test_a_ticket_belongs_to_the_frame_tensors_it_was_made_from():
     assert not r._ticket_is_for(ticket, dict(a, frame_token=3))
     a["Th"].add_(1.0)  # rewritten in place after the ticket was made
     assert not r._ticket_is_for(ticket, view)
+
+
+def test_feature_volumes_materialise_on_first_access():
+    """FeatureVolumes built from compact rows (what the inference encoder returns): four [1,C,D,H,W] tensors appear when the list
+    is looked at — zeros at inactive voxels, rows beyond the device-side count ignored — and not before."""
+    import torch
+
+    from neuralbody_amd.network import FeatureVolumes
+
+    g = torch.Generator().manual_seed(0)
+    shapes, chans = [(4, 5, 3), (2, 3, 2), (2, 2, 2), (1, 2, 1)], (32, 64, 128, 128)
+    sparse, rows, want = [], [], []
+    for (D, H, W), c in zip(shapes, chans):
+        nvox, cap = D * H * W, 7
+        n = min(5, nvox)
+        lin = torch.randperm(nvox, generator=g)[:n].sort().values.int()
+        rows_lin = torch.zeros(cap, dtype=torch.int32)
+        rows_lin[:n] = lin
+        r = torch.randn(cap, c, generator=g)  # rows n.. are garbage the count must hide
+        grid = torch.full((D, H, W), -1, dtype=torch.int32)
+        grid.view(-1)[lin.long()] = torch.arange(n, dtype=torch.int32)
+        sparse.append((grid, rows_lin, torch.tensor([n], dtype=torch.int32), cap))
+        rows.append(r)
+        d = torch.zeros(nvox, c)
+        d[lin.long()] = r[:n]
+        want.append(d.view(D, H, W, c).permute(3, 0, 1, 2)[None])
+    fv = FeatureVolumes(None, sparse, rows=rows, shapes=shapes)
+    assert len(fv) == 4 and not fv.is_dense() and bool(fv)
+    assert list.__len__(fv) == 0
+    v2 = fv[2]
+    assert fv.is_dense() and list.__len__(fv) == 4
+    assert v2.shape == (1, 128, 2, 2, 2)
+    for got, ref in zip(fv, want):
+        assert got.shape == ref.shape and torch.equal(got, ref)
+    # eager volumes behave like the plain list they are
+    eager = FeatureVolumes([w.clone() for w in want], sparse)
+    assert eager.is_dense() and eager.shapes == [tuple(s) for s in shapes] and torch.equal(eager[0], want[0])
+
+
+def test_zero_arena_hands_out_zeroed_aligned_views():
+    import torch
+
+    from neuralbody_amd import ops
+
+    req = [((3,), torch.float32), ((2, 5), torch.float64), ((7, 16), torch.float32)]
+    arena = ops.ZeroArena(ops.ZeroArena.size_of(req), "cpu")
+    views = [arena.take(shape, dt) for shape, dt in req]
+    for v, (shape, dt) in zip(views, req):
+        assert tuple(v.shape) == tuple(shape) and v.dtype == dt and float(v.abs().sum()) == 0.0 and v.data_ptr() % 16 == 0
+    views[0].fill_(1.0)
+    assert float(views[1].abs().sum()) == 0.0 and float(views[2].abs().sum()) == 0.0  # the views do not overlap
+    with pytest.raises(RuntimeError):
+        arena.take((1,))

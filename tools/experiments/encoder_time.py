@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-a = argparse.Namespace(size=512, samples=64, precision=None, steps=20, warmup=5)
+a = argparse.Namespace(size=512, samples=64, precision=os.environ.get("NB_BENCH_PRECISION"), steps=20, warmup=5)
 dev = torch.device("cuda:0")
 e = bench.encoder_bench(a, dev)
 print("encoder %.4f ms, %s launches" % (e["encoder_ms"], e["launches_per_view"]))
