@@ -15,6 +15,7 @@ New: `render_rays(...)`, the fused march used by `Renderer.render` (one launch f
 """
 import math
 import os
+from collections.abc import Sequence
 
 import torch
 import torch.nn as nn
@@ -37,10 +38,13 @@ LAZY_DENSE = os.environ.get("NB_LAZY_DENSE", "1") != "0"  # inference: dense vol
 SIX_BIT_MAX_SMALL = 0.5  # precision 'auto': largest per-layer share of weights six-bit blocks cannot hold before it takes 'f32'
 
 
-class FeatureVolumes(list):
+class FeatureVolumes(Sequence):
     """The four volumes of `Network.encode_sparse_voxels` ([1,C,D,H,W] views of channels-last storage, as the reference's
     `.dense()` returns them, latent_xyzc.py:188-201) together with the index structures they come from: `sparse[l]` = (index grid
-    [D,H,W] int32, linear voxel index of every active row, device-side row count [1], row capacity).
+    [D,H,W] int32, linear voxel index of every active row, device-side row count [1], row capacity).  A read-only sequence of
+    four tensors: `len`, indexing, slicing and iteration work as on the reference's list.  (Deliberately NOT a `list` subclass:
+    C-level consumers of lists — `torch.cat`, `PySequence_Fast` — read a list's storage directly and would see the not yet
+    materialised volumes as an empty list; handed this object they raise instead.  `list(fv)` / `fv.dense()` give a real list.)
 
     On the inference path the DENSE tensors are made on first access only (`rows[l]`: the level's active rows, compact fp32
     [capacity, C]; `shapes[l]` = (D, H, W)): the default arithmetic 'f16f6' marches the fc_0-folded planes, which nb_fold_build
@@ -51,7 +55,7 @@ class FeatureVolumes(list):
     ops.sparsify."""
 
     def __init__(self, volumes=None, sparse=None, rows=None, shapes=None, zeroed_int=None):
-        super().__init__(volumes if volumes is not None else [])
+        self._dense = list(volumes) if volumes is not None else None
         self.sparse = sparse
         self.rows = rows
         self.zeroed_int = zeroed_int  # one int32 the encoder's zero fill covered: the first fold build's saturation counter
@@ -59,14 +63,12 @@ class FeatureVolumes(list):
             shapes = [tuple(int(x) for x in (v.shape[2:] if v.dim() == 5 else v.shape[:3])) for v in volumes]
         self.shapes = shapes
         self.fold = None
-
-    # -- lazy dense tensors
-    def _ready(self):
-        return list.__len__(self) > 0 or self.rows is None
+        if self._dense is None and rows is None:
+            raise ValueError("FeatureVolumes needs the dense volumes or the levels' compact rows")
 
     def dense(self):
-        """The four [1,C,D,H,W] tensors (materialised once)."""
-        if not self._ready():
+        """The list of the four [1,C,D,H,W] tensors (materialised once)."""
+        if self._dense is None:
             vols = []
             for (grid, rows_lin, n_rows, cap), rows, dhw in zip(self.sparse, self.rows, self.shapes):
                 c = int(rows.shape[1])
@@ -77,23 +79,20 @@ class FeatureVolumes(list):
                 idx = torch.where(live, rows_lin[:cap].long(), torch.full((), nvox, dtype=torch.int64, device=rows.device))
                 buf.index_copy_(0, idx, torch.where(live[:, None], rows[:cap], torch.zeros((), device=rows.device)))
                 vols.append(buf[:nvox].view(dhw[0], dhw[1], dhw[2], c).permute(3, 0, 1, 2)[None])
-            list.extend(self, vols)
-        return self
+            self._dense = vols
+        return self._dense
 
     def is_dense(self):
-        return self._ready()
+        return self._dense is not None
 
     def __len__(self):
-        return 4 if not self._ready() else list.__len__(self)
-
-    def __iter__(self):
-        return list.__iter__(self.dense())
+        return len(self.shapes) if self._dense is None else len(self._dense)
 
     def __getitem__(self, i):
-        return list.__getitem__(self.dense(), i)
+        return self.dense()[i]
 
-    def __bool__(self):
-        return len(self) > 0
+    def __iter__(self):
+        return iter(self.dense())
 
 
 class SparseConv3dParam(nn.Module):
@@ -509,7 +508,7 @@ class Network(nn.Module):
             return self.xyzc_net(codes, coord, sp_input["out_sh"], self.training, None, dense=False)
         vols = self.xyzc_net(codes, coord, sp_input["out_sh"], self.training, save)
         # logical layout [1,C,D,H,W] like spconv's .dense(); storage stays channels-last
-        return FeatureVolumes([v.permute(3, 0, 1, 2)[None] for v in list.__iter__(vols)], vols.sparse, zeroed_int=vols.zeroed_int)
+        return FeatureVolumes([v.permute(3, 0, 1, 2)[None] for v in vols], vols.sparse, zeroed_int=vols.zeroed_int)
 
     SORT_MIN_POINTS = 4096  # below this a spatial sort of the points costs more than it saves
 

@@ -210,9 +210,12 @@ def test_feature_volumes_materialise_on_first_access():
         want.append(d.view(D, H, W, c).permute(3, 0, 1, 2)[None])
     fv = FeatureVolumes(None, sparse, rows=rows, shapes=shapes)
     assert len(fv) == 4 and not fv.is_dense() and bool(fv)
-    assert list.__len__(fv) == 0
+    assert not isinstance(fv, list)  # a C-level list consumer must not see "no volumes": it gets a TypeError instead
+    with pytest.raises(TypeError):
+        torch.cat(fv)
+    assert not fv.is_dense()
     v2 = fv[2]
-    assert fv.is_dense() and list.__len__(fv) == 4
+    assert fv.is_dense() and len(list(fv)) == 4 and len(fv[1:]) == 3
     assert v2.shape == (1, 128, 2, 2, 2)
     for got, ref in zip(fv, want):
         assert got.shape == ref.shape and torch.equal(got, ref)

@@ -1,7 +1,7 @@
-# round 5, job h: the records of the round on the final tree — GPU tests + smoke, default bench, kernel stats, serial step timeline,
+# round 5, job m (first run as job h, before the last training-step changes): the records of the round on the final tree — GPU tests + smoke, default bench, kernel stats, serial step timeline,
 # training step stats, PMC passes, HBM traffic, power / clocks under load
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-O=gpurun_out/r5h; mkdir -p $O
+O=gpurun_out/r5m; mkdir -p $O
 timeout 1800 python -m pytest tests -x -q -m gpu > $O/pytest.txt 2>&1; grep -E "passed|failed|error" $O/pytest.txt | tail -3
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -2 $O/smoke.txt
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-300 $O/bench.json
@@ -13,8 +13,8 @@ timeout 600 rocprofv3 --kernel-trace -d $O/tr -o t -- python bench.py --mode tra
 python tools/rocpd_summary.py $(find $O/tr -name "*.db" | head -1) > $O/train_kernel_stats.md 2>&1; tail -1 $O/train_kernel_stats.md
 timeout 300 python bench.py --mode train --steps 20 --warmup 5 > $O/train.json 2> $O/train.err; cut -c1-120 $O/train.json
 find $O -name "*.db" -delete
-bash tools/pmc_march.sh f16f6 r5h/pmc > $O/pmc_out.txt 2>&1
-bash tools/pmc_traffic.sh f16f6 r5h/traffic > $O/traffic_out.txt 2>&1
+bash tools/pmc_march.sh f16f6 r5m/pmc > $O/pmc_out.txt 2>&1
+bash tools/pmc_traffic.sh f16f6 r5m/traffic > $O/traffic_out.txt 2>&1
 python bench.py --steps 1500 --warmup 3 --no-cpu-baseline --no-extras > $O/loop.log 2>&1 &
 sleep 14; for i in 1 2 3; do rocm-smi --showpower --showclocks >> $O/smi_load.txt 2>&1; sleep 2; done; wait
 grep -i "sclk\|power (W)" $O/smi_load.txt | head -8; tail -1 $O/loop.log | cut -c1-200
