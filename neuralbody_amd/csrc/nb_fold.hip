@@ -67,16 +67,24 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
     const int cb = lvl_chan_base(L);
-    const float *wb0 = a.w0 + (size_t)(64 * wave + i) * 352 + cb + kh;
+    // B[k][n] = fc_0.weight[n][cb + k]: the lane's weight row is contiguous along k — one 16-byte load serves two K = 2 steps
+    // (elements kh and 2 + kh; cb is a multiple of 32, the rows 1408 bytes apart: aligned).  As one float per lane and step the
+    // loads were 64 different lines per instruction, four bytes used of each
+    const float *wb0 = a.w0 + (size_t)(64 * wave + i) * 352 + cb;
     const float *wb1 = wb0 + 32 * 352;
-#pragma unroll 4
-    for (int kk = 0; kk < C / 2; ++kk) {
-        const float b0 = wb0[2 * kk], b1 = wb1[2 * kk];  // B[k][n] = fc_0.weight[n][cb + k]
+#pragma unroll 2
+    for (int k4 = 0; k4 < C / 4; ++k4) {
+        const f32x4 w0 = *reinterpret_cast<const f32x4 *>(wb0 + 4 * k4), w1 = *reinterpret_cast<const f32x4 *>(wb1 + 4 * k4);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const float av = at[(32 * rt + i) * PITCH + 2 * kk + kh];
-            acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[rt][0], 0, 0, 0);
-            acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[rt][1], 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {
+            const int kk = 2 * k4 + h;
+            const float b0 = kh ? (h ? w0.w : w0.y) : (h ? w0.z : w0.x), b1 = kh ? (h ? w1.w : w1.y) : (h ? w1.z : w1.x);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+                const float av = at[(32 * rt + i) * PITCH + 2 * kk + kh];
+                acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[rt][0], 0, 0, 0);
+                acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[rt][1], 0, 0, 0);
+            }
         }
     }
     // ---- rows out: through an LDS image [32 rows][256 heads | 256 remainders] so that a row leaves as 64 x 16 bytes
