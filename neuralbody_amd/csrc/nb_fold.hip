@@ -16,7 +16,10 @@ namespace {
 
 using namespace nbm;
 
-constexpr int ROWS_WG = 128;  // rows per workgroup: 4 row tiles per wave share every fc_0 fragment
+constexpr int ROWS_WG = 128;  // rows per workgroup of the 32- and 64-channel levels: 4 row tiles per wave share every fc_0 fragment
+// the 128-channel levels take 64 rows per workgroup: a workgroup's 4 C MFMAs per wave (64 cycles each on the exact-fp32 pipe) are
+// the launch's critical path — 512 of them = 16 us with a SIMD to itself, the whole launch used to take 80
+__host__ __device__ constexpr int rows_wg(int level) { return level >= 2 ? 64 : ROWS_WG; }
 constexpr int N_OUT = 256;
 
 struct FoldArgs {
@@ -33,9 +36,10 @@ struct FoldArgs {
 };
 
 // one workgroup = 128 rows x 256 outputs of one level; wave w = outputs [64 w, 64 w + 64)
-template <int C>
+template <int C, int RT>
 __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int tile, char *lds) {
     constexpr int PITCH = C + 1;  // floats: lanes i = 0..31 of an A fragment read rows i at distinct banks
+    constexpr int ROWS_WG = 32 * RT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = min(*a.n_rows[L], a.cap[L]);
     const int row0 = tile * ROWS_WG;
@@ -59,9 +63,9 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
     }
     __syncthreads();
     const int i = lane & 31, kh = lane >> 5;
-    f32x16 acc[4][2];
+    f32x16 acc[RT][2];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -80,7 +84,7 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
             const int kk = 2 * k4 + h;
             const float b0 = kh ? (h ? w0.w : w0.y) : (h ? w0.z : w0.x), b1 = kh ? (h ? w1.w : w1.y) : (h ? w1.z : w1.x);
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
+            for (int rt = 0; rt < RT; ++rt) {
                 const float av = at[(32 * rt + i) * PITCH + 2 * kk + kh];
                 acc[rt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[rt][0], 0, 0, 0);
                 acc[rt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[rt][1], 0, 0, 0);
@@ -92,7 +96,7 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
     bool sat = false;  // a product beyond +-65504 is clamped (the head would be inf, the remainder inf - inf), a NaN stays a NaN:
                        // either is counted, and Network's 'auto' leaves the fp16 planes for the exact kernel when the count is not 0
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
         __syncthreads();  // the A tile / the previous image is no longer read
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -127,9 +131,9 @@ __global__ __launch_bounds__(256) void nb_fold_rows_kernel(FoldArgs a) {
         *reinterpret_cast<f32x4 *>(a.urows + ((size_t)a.zero_row * 512 + threadIdx.x * 8)) = f32x4{0.f, 0.f, 0.f, 0.f};
     const int L = (b >= a.tile_base[1]) + (b >= a.tile_base[2]) + (b >= a.tile_base[3]);
     const int tile = b - a.tile_base[L];
-    if (L == 0) fold_rows_level<32>(a, 0, tile, lds);
-    else if (L == 1) fold_rows_level<64>(a, 1, tile, lds);
-    else fold_rows_level<128>(a, L, tile, lds);
+    if (L == 0) fold_rows_level<32, 4>(a, 0, tile, lds);
+    else if (L == 1) fold_rows_level<64, 4>(a, 1, tile, lds);
+    else fold_rows_level<128, 2>(a, L, tile, lds);
 }
 
 // ---------------------------------------------------------------- active set of a dense volume
@@ -174,7 +178,7 @@ int nb_fold_build(const float *const vol[NB_N_LEVELS], const int32_t *const rows
         a.row_base[l] = base;
         a.tile_base[l] = tiles;
         base += n_rows_max[l];
-        tiles += nb_ceil_div(n_rows_max[l], ROWS_WG);
+        tiles += nb_ceil_div(n_rows_max[l], rows_wg(l));
     }
     a.tile_base[4] = tiles;
     a.w0 = fc0_w;
@@ -183,7 +187,8 @@ int nb_fold_build(const float *const vol[NB_N_LEVELS], const int32_t *const rows
     a.n_sat = n_saturated;
     NB_REQUIRE(base < (1 << 21), "nb_fold_build: %d rows: the march addresses the 1-KiB rows with 32-bit byte offsets (< 2^21 rows)", base);
     hipStream_t st = (hipStream_t)stream;
-    const size_t lds = (size_t)ROWS_WG * 129 * 4;  // the widest A tile; the 32 KiB output image aliases it
+    // the largest A tile: 128 rows x (64 + 1) floats or 64 rows x (128 + 1); the 32 KiB output image aliases it
+    const size_t lds = (size_t)(ROWS_WG * 65 > 64 * 129 ? ROWS_WG * 65 : 64 * 129) * 4;
     static bool attr_set = false;
     if (!attr_set) {
         NB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(nb_fold_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
