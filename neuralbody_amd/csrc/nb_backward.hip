@@ -228,7 +228,7 @@ constexpr int TN16_P = 128 * 2 + 32;            // LDS row pitch in bytes
 constexpr int TN16_PLANE = 32 * TN16_P;         // one bf16 plane of one operand
 constexpr int TN16_BUF = 4 * TN16_PLANE;        // A head | A remainder | B head | B remainder
 
-__global__ __launch_bounds__(256) void gemm_tn16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
+__global__ __launch_bounds__(256, 2) void gemm_tn16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B,
                                                         int ldb, long long R, int M, int N, float alpha,
                                                         float *__restrict__ C, int ldc) {
     __shared__ __attribute__((aligned(16))) char lds[2 * TN16_BUF];
@@ -350,7 +350,7 @@ __global__ void scale_matrix_kernel(float *__restrict__ C, int m, int n, int ldc
 // weight element (k, column), C/D in the standard 32x32 layout.  Fused epilogues of the backward chain:
 //   mask_y   : C *= (Y[row, col] > 0)   — the ReLU that followed the layer whose input gradient this is
 //   colsum   : colsum[col] += sum_rows C (after the mask) — the bias gradient of that layer
-__global__ __launch_bounds__(256) void gemm_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+__global__ __launch_bounds__(256, 2) void gemm_rows_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                                                         int trans_b, long long R, int K, int N, float alpha, float beta,
                                                         float *__restrict__ C, int ldc, const float *__restrict__ mask_y, int ldy,
                                                         float *__restrict__ colsum) {
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(const float *__restrict_
 // first version loaded 8 K per step per wave with no sharing: 128 half-used cache-line requests per 16 MFMAs per wave — 5x
 // over what the vector L1 can serve; measured 320 us for the 65536 x 256 x 256 product against a 62 us matrix-pipe bound.)
 template <bool TRANS_B>
-__global__ __launch_bounds__(256) void gemm_rows_fast_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+__global__ __launch_bounds__(256, 2) void gemm_rows_fast_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                                                              long long R, int K, int N, float alpha, float beta, float *__restrict__ C,
                                                              int ldc, const float *__restrict__ mask_y, int ldy,
                                                              float *__restrict__ colsum) {
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void gemm_rows_fast_kernel(const float *__rest
 // products of the MLP backward.  A fragment: a lane's row, 8 consecutive K values = two float4 straight from global memory, split
 // in registers.  B fragment: K-major (8 consecutive K of one column) from a [32 K][128 columns] LDS tile of bf16 pairs by
 // ds_read_b64_tr_b16 (nb_trread.h), staged once per workgroup and K chunk.  Same tile, same fused epilogue as the fp32 kernel.
-__global__ __launch_bounds__(256) void gemm_rows16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
+__global__ __launch_bounds__(256, 2) void gemm_rows16_kernel(const float *__restrict__ A, int lda, const float *__restrict__ B, int ldb,
                                                           long long R, int K, int N, float alpha, float beta, float *__restrict__ C,
                                                           int ldc, const float *__restrict__ mask_y, int ldy,
                                                           float *__restrict__ colsum) {

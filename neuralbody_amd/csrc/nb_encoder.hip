@@ -153,7 +153,7 @@ __global__ __launch_bounds__(nbscan::BLOCK) void grid_number_kernel(int *__restr
 
 // ------------------------------------------------------------------ sparse 3x3x3 convolution
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_kernel(const float *__restrict__ in_rows, const int *__restrict__ in_grid,
+__global__ __launch_bounds__(256, 2) void conv_kernel(const float *__restrict__ in_rows, const int *__restrict__ in_grid,
                                                    Dims gi, const int *__restrict__ out_lin,
                                                    const int *__restrict__ n_out, Dims go, int stride,
                                                    const float *__restrict__ weight, float *__restrict__ out_rows,
@@ -337,7 +337,7 @@ __global__ void conv_pack16_batch_kernel(PackBatch b) {
 
 // one wave = 32 output rows x NT tiles of 32 output channels (blockIdx.y selects the tile group)
 template <int CIN, int COUT, int NT, bool BF = false>
-__global__ __launch_bounds__(256) void conv16_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
+__global__ __launch_bounds__(256, 2) void conv16_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
                                                      const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
                                                      const int *__restrict__ n_out, Dims go, int stride,
                                                      const bf16x8 *__restrict__ wp, float *__restrict__ out_rows,
@@ -438,7 +438,7 @@ typedef const void __attribute__((address_space(1))) *nb_gptr_t;
 typedef void __attribute__((address_space(3))) *nb_lptr_t;
 
 template <int CIN, int COUT, int NT, bool BF = false>
-__global__ __launch_bounds__(256) void conv16_lds_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
+__global__ __launch_bounds__(256, 2) void conv16_lds_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
                                                          const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
                                                          const int *__restrict__ n_out, Dims go, int stride,
                                                          const bf16x8 *__restrict__ wp, float *__restrict__ out_rows,

@@ -110,7 +110,7 @@ __global__ void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *_
 // ------------------------------------------------------------------ conv backward w.r.t. the input rows
 // one wave = 32 INPUT rows x 32 input channels (blockIdx.y); K runs over the Cout channels of dx
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_bwd_in_kernel(const float *__restrict__ dx, const int *__restrict__ out_grid,
+__global__ __launch_bounds__(256, 2) void conv_bwd_in_kernel(const float *__restrict__ dx, const int *__restrict__ out_grid,
                                                           Dims go, const int *__restrict__ in_lin,
                                                           const int *__restrict__ n_in, Dims gi, int stride,
                                                           const float *__restrict__ weight, float *__restrict__ din) {
@@ -202,7 +202,7 @@ __global__ void conv_rulebook_kernel(const int *__restrict__ in_grid, Dims gi, c
 constexpr int ROWS_PER_WAVE = 256;
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_bwd_w_kernel(const float *__restrict__ in_rows, const int *__restrict__ nbr,
+__global__ __launch_bounds__(256, 2) void conv_bwd_w_kernel(const float *__restrict__ in_rows, const int *__restrict__ nbr,
                                                          const int *__restrict__ n_out, const float *__restrict__ dx,
                                                          float *__restrict__ dw) {
     constexpr int TO = (COUT + 31) / 32;
@@ -274,7 +274,7 @@ typedef nbtr::bf8 nb_bf8;
 __device__ __forceinline__ nb_bf8 tr_frag(unsigned addr_lo4, unsigned addr_hi4) { return nbtr::frag(addr_lo4, addr_hi4); }
 
 template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void conv_bwd_w16_kernel(const float *__restrict__ in_rows, const int *__restrict__ nbr,
+__global__ __launch_bounds__(256, 2) void conv_bwd_w16_kernel(const float *__restrict__ in_rows, const int *__restrict__ nbr,
                                                            const int *__restrict__ n_out, const unsigned short *__restrict__ dx_split,
                                                            long long dx_plane, float *__restrict__ dw) {
     constexpr int CT = CIN / 32, OT = COUT / 32;               // tiles of dW[o]

@@ -124,7 +124,7 @@ __device__ __forceinline__ void fold_rows_level(const FoldArgs &a, int L, int ti
     if (a.n_sat && __builtin_amdgcn_ballot_w64(sat) != 0ull && lane == 0) atomicAdd(a.n_sat, __builtin_popcountll(__builtin_amdgcn_ballot_w64(sat)));
 }
 
-__global__ __launch_bounds__(256) void nb_fold_rows_kernel(FoldArgs a) {
+__global__ __launch_bounds__(256, 2) void nb_fold_rows_kernel(FoldArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int b = blockIdx.x;
     if (b == 0 && threadIdx.x < 64)
