@@ -151,6 +151,51 @@ __global__ __launch_bounds__(nbscan::BLOCK) void grid_number_kernel(int *__restr
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = min(before + tot, cap);
 }
 
+// ------------------------------------------------------------------ a tile's way out
+// The tile is stored; its BatchNorm sums (fp64: sum and sum of squares per channel) meet those of the workgroup's other waves in LDS
+// and leave as ONE atomic per channel and workgroup.  As one pair of atomics per WAVE the ~900 waves of a 29 k-row level queued on
+// the layer's 2 COUT addresses: 14 of the 52 us of a 64 -> 64 launch (profiles/r05_conv_stamps.log).  Every wave of the workgroup
+// calls this (a wave without rows brings zeros; `active` false: a wave beyond the NW that hold tiles, for the barrier only); `red`: NW * NT * 64
+// doubles of LDS that nobody reads or writes any more.
+template <int COUT, int NT, int NW>
+__device__ __forceinline__ void store_tile_and_sums(const f32x16 (&acc)[NT], int row0, int n, int ct, float *__restrict__ out_rows,
+                                                    double *__restrict__ stats, double *red, int wv, int lane,
+                                                    bool active = true) {
+    const int i = lane & 31, hi = lane >> 5;
+    // D fragment: lane (j = i, hi) holds channel (ct + t) * 32 + j of rows row0 + tile_row(r, hi)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (!active) break;  // (wave-uniform) a wave that only keeps the barrier company
+        const int co = (ct + t) * 32 + i;
+        const bool cok = (COUT % 32 == 0) || co < COUT;
+        double s = 0.0, ss = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int orow = row0 + tile_row(r, hi);
+            const float v = acc[t][r];
+            if (orow < n && cok) {
+                out_rows[(size_t)orow * COUT + co] = v;
+                s += (double)v;
+                ss += (double)v * (double)v;
+            }
+        }
+        s += __shfl_xor(s, 32);
+        ss += __shfl_xor(ss, 32);
+        if (hi == 0) {
+            red[((wv * NT + t) * 2) * 32 + i] = s;
+            red[((wv * NT + t) * 2 + 1) * 32 + i] = ss;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NT * 64) {  // thread = (tile, which sum, channel of the tile)
+        const int t = threadIdx.x >> 6, which = (threadIdx.x >> 5) & 1, co = (ct + t) * 32 + (threadIdx.x & 31);
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[((w * NT + t) * 2 + which) * 32 + (threadIdx.x & 31)];
+        if ((COUT % 32 == 0) || co < COUT) atomicAdd(&stats[which * COUT + co], v);
+    }
+}
+
 // ------------------------------------------------------------------ sparse 3x3x3 convolution
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256, 2) void conv_kernel(const float *__restrict__ in_rows, const int *__restrict__ in_grid,
@@ -166,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const float *__restrict__ 
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = *n_out;
     const int row0 = wave * 32;
-    if (row0 >= n) return;  // wave-uniform
+    if (blockIdx.x * 128 >= n) return;  // workgroup-uniform: the waves of a live workgroup meet at the barrier of the sums
     const int row = row0 + i;
     const bool valid = row < n;
     const int lin = valid ? out_lin[row] : 0;
@@ -221,29 +266,8 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const float *__restrict__ 
             }
         }
     }
-    // D fragment: lane (j = i, hi) holds channel t*32 + j of rows row0 + tile_row(r, hi)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = (ct + t) * 32 + i;
-        const bool cok = (COUT % 32 == 0) || co < COUT;
-        double s = 0.0, ss = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = row0 + tile_row(r, hi);
-            const float v = acc[t][r];
-            if (orow < n && cok) {
-                out_rows[(size_t)orow * COUT + co] = v;
-                s += (double)v;
-                ss += (double)v * (double)v;
-            }
-        }
-        s += __shfl_xor(s, 32);
-        ss += __shfl_xor(ss, 32);
-        if (hi == 0 && cok) {
-            atomicAdd(&stats[co], s);
-            atomicAdd(&stats[COUT + co], ss);
-        }
-    }
+    __shared__ double red[4 * NT * 64];
+    store_tile_and_sums<COUT, NT, 4>(acc, row0, n, ct, out_rows, stats, red, threadIdx.x >> 6, lane);
 }
 
 // ------------------------------------------------------------------ the same convolution on the 16-bit matrix pipe
@@ -348,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const unsigned short *__
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = *n_out;
     const int row0 = wave * 32;
-    if (row0 >= n) return;  // wave-uniform
+    if (blockIdx.x * 128 >= n) return;  // workgroup-uniform: the waves of a live workgroup meet at the barrier of the sums
     const int row = row0 + i;
     const bool valid = row < n;
     const int lin = valid ? out_lin[row] : 0;
@@ -406,37 +430,135 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const unsigned short *__
             }
         }
     }
-    // D fragment: lane (j = i, hi) holds channel (ct + t) * 32 + j of rows row0 + tile_row(r, hi)
+    __shared__ double red[4 * NT * 64];
+    store_tile_and_sums<COUT, NT, 4>(acc, row0, n, ct, out_rows, stats, red, threadIdx.x >> 6, lane);
+}
+
+typedef const void __attribute__((address_space(1))) *nb_gptr_t;
+typedef void __attribute__((address_space(3))) *nb_lptr_t;
+
+// ------------------------------------------------------------------ a wave's 32 gathered rows through LDS
+// Loaded straight into the A-fragment registers (lane (i, hi) reads 16 bytes of row i) a gather instruction has every lane on a
+// different row and the texture-address path takes it one lane per clock: 16-18 bytes per clock and CU, measured
+// (tools/experiments/probe_gather.hip, profiles/r05_probe_gather.log), whatever the rows' placement.  With FOUR ADJACENT LANES on 64
+// contiguous bytes it delivers 40-52, so the rows come in by LDS-DMA in that shape — one global_load_lds_dwordx4 = 16 lane quads =
+// 1 KiB landing lane-contiguous — and the fragments are read back with ds_read_b128.  A 128-channel row plane is 256 bytes = 4
+// pieces of 64; instruction t of a plane carries the 16 pieces of 4 rows.  Which rows, and the 16 bytes of padding between
+// instructions, are chosen so that the 16 lanes ds_read_b128 serves in one cycle ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the
+// same + 32) fall on 16 different 16-byte slots of the 256-byte bank row.  (64-channel planes were built the same way — 8 rows per
+// instruction — and measured no faster than register loads in the pipeline; the kernel below stages 128-channel rows only.)
+template <int CIN>
+struct RowStage {
+    static_assert(CIN == 128, "row stage: 256-byte row planes (128 channels)");
+    static constexpr int ROWB = 2 * CIN, NI = ROWB / 32, BLOCK = 1024 + 16, BYTES = 2 * NI * BLOCK;
+    int src_base, src_byte, frag_base;
+    __device__ __forceinline__ explicit RowStage(int lane) {
+        const int q = lane >> 2, j = lane & 3, i = lane & 31, hi = lane >> 5;
+        // instruction t carries rows (t / 4) 16 + (t % 4) 4 .. + 3, lane quad = piece * 4 + row % 4
+        src_base = q & 3;
+        src_byte = (q >> 2) * 64 + j * 16;
+        frag_base = ((i >> 4) * 4 + ((i & 15) >> 2)) * BLOCK + (i & 3) * 64 + hi * 16;
+    }
+    // rows nbr (lane i's neighbour under the offset; < 0: none, row 0 is fetched and the consumer zeroes it) -> the wave's stage, as
+    // 2 NI instructions: addresses() once per offset, then piece(k), k = 2 t + plane, wherever the caller wants each issued
+    __device__ __forceinline__ void addresses(const unsigned short *in_split, int nbr, const char *(&g)[NI]) const {
+#pragma unroll
+        for (int t = 0; t < NI; ++t) {
+            const int src = src_base + (t >> 2) * 16 + (t & 3) * 4;
+            const int row = __shfl(nbr, src);
+            g[t] = reinterpret_cast<const char *>(in_split) + (size_t)(row >= 0 ? row : 0) * ROWB + src_byte;
+        }
+    }
+    __device__ __forceinline__ void piece(int k, const char *const (&g)[NI], long long in_plane, char *mine) const {
+        const int t = k >> 1, plane = k & 1;
+        __builtin_amdgcn_global_load_lds((nb_gptr_t)(g[t] + plane * 2 * in_plane), (nb_lptr_t)(mine + (plane * NI + t) * BLOCK), 16, 0, 0);
+    }
+    __device__ __forceinline__ void fetch(const unsigned short *in_split, long long in_plane, int nbr, char *mine) const {
+        const char *g[NI];
+        addresses(in_split, nbr, g);
+#pragma unroll
+        for (int k = 0; k < 2 * NI; ++k) piece(k, g, in_plane, mine);
+    }
+    // chunk c of lane (i, hi): bytes [32 c + 16 hi, + 16) of row i = piece c / 2, slot 2 (c % 2) + hi of the quad
+    template <typename V, int NC>
+    __device__ __forceinline__ void fragments(const char *mine, V (&ah)[NC], V (&al)[NC]) const {
+        constexpr int PIECE = 4 * 64;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const char *p = mine + frag_base + (c >> 1) * PIECE + (c & 1) * 32;
+            ah[c] = *reinterpret_cast<const V *>(p);
+            al[c] = *reinterpret_cast<const V *>(p + NI * BLOCK);
+        }
+    }
+};
+
+// One kernel offset of a wave's tile from an LDS slab ([chunk][tile][head, remainder] 1-KiB fragments): acc[t] += A_hi.B_hi + A_hi.B_lo
+// + A_lo.B_hi over the NC K chunks, every accumulator in the order chunk, (hh, hl, lh).  These kernels run one wave per SIMD, so
+// nothing fills a wait but the wave itself: chunk c + 1's fragments are read while chunk c multiplies, and the products go round the
+// NT accumulators (a dependent MFMA only every NT-th issue slot).  As "read two fragments, wait, three MFMAs into one accumulator"
+// the multiply phase of a 64 -> 64 offset stamped 1 900 cycles, like this 1 750 (24 MFMAs = 768 cycles of pipe; the rest is the
+// issue of the next offset's loads against a busy texture path: profiles/r05_conv_stamps.log).
+struct NoFetch {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// VPC > 0: the caller's fetches of the NEXT offset (VPC vector-memory instructions per chunk, fetch(k), k = 0 .. NC VPC - 1) are issued
+// BETWEEN this offset's MFMAs, one per 3 NT / VPC of them, each fenced by scheduling barriers: issued in a block before the MFMAs
+// (where the scheduler puts them) the wave sits out their issue — 60-180 cycles apiece with the texture path busy — before its
+// first MFMA, and the offset costs fetch + multiply instead of the larger of the two.
+template <int NC, int NT, bool BF, int VPC = 0, typename Fetch = NoFetch>
+__device__ __forceinline__ void multiply_offset(f32x16 (&acc)[NT], const bf16x8 (&ah)[NC], const bf16x8 (&al)[NC], bool has,
+                                                const bf16x8 *sl, Fetch fetch = Fetch()) {
+    static_assert(VPC == 0 || (3 * NT) % VPC == 0, "the chunk's MFMAs split evenly round its fetches");
+    constexpr int GROUPS = VPC > 0 ? VPC : 1, PER = 3 * NT / GROUPS;
+    bf16x8 b[2][NT][2], zero;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) zero[e] = (nb_h16)0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int co = (ct + t) * 32 + i;
-        double s = 0.0, ss = 0.0;
+        b[0][t][0] = sl[(t * 2) * 64];
+        b[0][t][1] = sl[(t * 2 + 1) * 64];
+    }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = row0 + tile_row(r, hi);
-            const float v = acc[t][r];
-            if (orow < n) {
-                out_rows[(size_t)orow * COUT + co] = v;
-                s += (double)v;
-                ss += (double)v * (double)v;
+    for (int c = 0; c < NC; ++c) {
+        if (c + 1 < NC) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                b[(c + 1) & 1][t][0] = sl[(((c + 1) * NT + t) * 2) * 64];
+                b[(c + 1) & 1][t][1] = sl[(((c + 1) * NT + t) * 2 + 1) * 64];
             }
         }
-        s += __shfl_xor(s, 32);
-        ss += __shfl_xor(ss, 32);
-        if (hi == 0) {
-            atomicAdd(&stats[co], s);
-            atomicAdd(&stats[COUT + co], ss);
+        const bf16x8 a_h = has ? ah[c] : zero, a_l = has ? al[c] : zero;
+#pragma unroll
+        for (int g = 0; g < GROUPS; ++g) {
+#pragma unroll
+            for (int q = 0; q < PER; ++q) {  // MFMA m of the chunk: product m / NT (hh, hl, lh) into accumulator m % NT
+                const int m = g * PER + q, prod = m / NT, t = m % NT;
+                acc[t] = NB_MFMA16(prod < 2 ? a_h : a_l, b[c & 1][t][prod == 1 ? 1 : 0], acc[t]);
+            }
+            if constexpr (VPC > 0) {
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(c * VPC + g);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if constexpr (VPC == 0) {  // the order for the scheduler (it otherwise sinks a chunk's reads behind the previous chunk's MFMAs)
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            if (c + 1 < NC) __builtin_amdgcn_sched_group_barrier(0x100, 2 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT, 0);
         }
     }
 }
 
-// The same with the weight slab of the current kernel offset SHARED through LDS by the four waves of a workgroup (128 output
-// rows x NT channel tiles): every B fragment is fetched from L2 once per workgroup instead of once per wave, by LDS-DMA
-// (one 1-KiB fragment = one global_load_lds_dwordx4, no registers), double buffered, one barrier per offset.  Used where the
-// per-wave kernel above is L2-bandwidth-bound: the 64- and 128-channel layers (1.4 GB of operand traffic per 128 -> 128 launch).
-typedef const void __attribute__((address_space(1))) *nb_gptr_t;
-typedef void __attribute__((address_space(3))) *nb_lptr_t;
-
+// conv16_kernel with the weight slab of the current kernel offset SHARED through LDS by the four waves of a workgroup (128 output
+// rows x NT channel tiles): every B fragment is fetched from L2 once per workgroup instead of once per wave, by LDS-DMA (one 1-KiB
+// fragment = one global_load_lds_dwordx4, no registers), double buffered, one barrier per offset; at 128 input channels the gathered
+// rows come through the waves' LDS stages (RowStage; 130 KB of LDS with two channel tiles per wave).  The 64- and 128-channel
+// layers (the per-wave kernel above moves 1.4 GB of operands per 128 -> 128 launch).  Round 4 ran the mid levels as 8 waves with the
+// offsets split over two groups, rows straight into registers (its 128 KB of slabs left no room for stages): 69.6 us per
+// 128 -> 128 launch against 51.9 for this one (profiles/r05_conv_fetch_ab.log).
 template <int CIN, int COUT, int NT, bool BF = false>
 __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
                                                          const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
@@ -447,7 +569,15 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(const unsigned short
     constexpr int NFRAG = NC * NT * 2;        // 1-KiB fragments of one offset's slab: [c][t][head, remainder]
     constexpr int PER_WAVE = NFRAG / 4;       // DMAs per wave per offset
     static_assert(NFRAG % 4 == 0, "slab must split evenly over the four waves");
-    __shared__ __attribute__((aligned(16))) char slab[2][NFRAG * 1024];
+    // measured in the pipeline (profiles/r05_conv_fetch_ab.log): 128-channel rows 51.9 us staged against 66.7 straight into registers
+    // per 128 -> 128 launch; 64-channel rows 39.3 against 38.3 (64 -> 64) and 36.4 against 32.7 (64 -> 128): only the 256-byte planes
+    constexpr bool STAGE = CIN == 128 && 2 * NFRAG * 1024 + 4 * RowStage<128>::BYTES <= 160 * 1024;
+    typedef RowStage<128> RS;
+    constexpr int STAGE_BYTES = STAGE ? RS::BYTES : 0;
+    // ONE LDS object: with the row stages as a second __shared__ array hipcc puts an s_waitcnt vmcnt(0) between a DMA into one and
+    // the next read of the other (the LDS-DMA bookkeeping of its wait-count pass), which serialises every offset's fetch and multiply
+    __shared__ __attribute__((aligned(16))) char lds[2 * NFRAG * 1024 + 4 * STAGE_BYTES];
+    char (*const slab)[NFRAG * 1024] = reinterpret_cast<char (*)[NFRAG * 1024]>(lds);
     const int ct = blockIdx.y * NT;
     const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -464,14 +594,15 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(const unsigned short
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    auto issue_slab = [&](int o, int buf) {  // this wave's share of offset o's fragments -> slab[buf]
+    auto issue_slab_piece = [&](int o, int buf, int q) {  // piece q of this wave's share of offset o's fragments -> slab[buf]
+        const int f = wv * PER_WAVE + q;           // local fragment (c, t, part) = ((c * NT) + t) * 2 + part
+        const int c = f / (NT * 2), rest = f % (NT * 2);
+        const bf16x8 *src = wp + (((size_t)o * NC + c) * NTT + ct) * 2 * 64 + (size_t)rest * 64 + lane;
+        __builtin_amdgcn_global_load_lds((nb_gptr_t)src, (nb_lptr_t)(slab[buf] + f * 1024), 16, 0, 0);
+    };
+    auto issue_slab = [&](int o, int buf) {
 #pragma unroll
-        for (int q = 0; q < PER_WAVE; ++q) {
-            const int f = wv * PER_WAVE + q;           // local fragment (c, t, part) = ((c * NT) + t) * 2 + part
-            const int c = f / (NT * 2), rest = f % (NT * 2);
-            const bf16x8 *src = wp + (((size_t)o * NC + c) * NTT + ct) * 2 * 64 + (size_t)rest * 64 + lane;
-            __builtin_amdgcn_global_load_lds((nb_gptr_t)src, (nb_lptr_t)(slab[buf] + f * 1024), 16, 0, 0);
-        }
+        for (int q = 0; q < PER_WAVE; ++q) issue_slab_piece(o, buf, q);
     };
     int nbrs[27];
 #pragma unroll
@@ -493,193 +624,60 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(const unsigned short
             al[c] = pl[2 * c];
         }
     };
-    bf16x8 ah[2][NC], al[2][NC];
+    // STAGE: the wave's 32 neighbour rows reach it through its own LDS stage (RowStage), fetched while the previous offset
+    // multiplies; else (no room beside the slabs) straight into a second set of fragment registers
+    char *const mine = lds + 2 * NFRAG * 1024 + wv * STAGE_BYTES;
+    const RS rs(lane);
+    constexpr int NBUF = STAGE ? 1 : 2;
+    bf16x8 ah[NBUF][NC], al[NBUF][NC];
     issue_slab(0, 0);
-    load_rows(nbrs[0], ah[0], al[0]);
+    if constexpr (STAGE) rs.fetch(in_split, in_plane, nbrs[0], mine);
+    else load_rows(nbrs[0], ah[0], al[0]);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
     for (int o = 0; o < 27; ++o) {
-        if (o + 1 < 27) {
-            issue_slab(o + 1, (o + 1) & 1);  // the other buffer: its last readers passed the barrier that ended offset o - 1
-            load_rows(nbrs[o + 1], ah[(o + 1) & 1], al[(o + 1) & 1]);
-        }
         const int nbr = nbrs[o];
-        if (__any(nbr >= 0)) {
-            const bf16x8 *sl = reinterpret_cast<const bf16x8 *>(slab[o & 1]) + lane;
-            bf16x8 zero;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) zero[e] = (nb_h16)0.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const bf16x8 a_h = nbr >= 0 ? ah[o & 1][c] : zero, a_l = nbr >= 0 ? al[o & 1][c] : zero;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bf16x8 bh = sl[((c * NT + t) * 2) * 64], bl = sl[((c * NT + t) * 2 + 1) * 64];
-                    acc[t] = NB_MFMA16(a_h, bh, acc[t]);
-                    acc[t] = NB_MFMA16(a_h, bl, acc[t]);
-                    acc[t] = NB_MFMA16(a_l, bh, acc[t]);
+        const bool live = __any(nbr >= 0);
+        const bf16x8 *sl = reinterpret_cast<const bf16x8 *>(slab[o & 1]) + lane;
+        if constexpr (STAGE) {
+            // one block per offset: the stage's fragments, then the next offset's fetches BETWEEN this offset's MFMAs
+            constexpr int VPC = (PER_WAVE + 2 * RS::NI) / NC;
+            static_assert(!STAGE || (PER_WAVE + 2 * RS::NI) % NC == 0, "fetches per chunk");
+            if (live) {
+                rs.fragments(mine, ah[0], al[0]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // ... before the next offset's rows overwrite the stage
+                if (o + 1 < 27) {
+                    const char *g[RS::NI];
+                    rs.addresses(in_split, nbrs[o + 1], g);
+                    // piece k of the next offset: first the wave's share of the slab (the other buffer: its last readers passed the
+                    // barrier that ended offset o - 1), then the row planes
+                    auto next_piece = [&](int k) {
+                        if (k < PER_WAVE) issue_slab_piece(o + 1, (o + 1) & 1, k);
+                        else rs.piece(k - PER_WAVE, g, in_plane, mine);
+                    };
+                    multiply_offset<NC, NT, BF, VPC>(acc, ah[0], al[0], nbr >= 0, sl, next_piece);
+                } else {
+                    multiply_offset<NC, NT, BF>(acc, ah[0], al[0], nbr >= 0, sl);
                 }
+            } else if (o + 1 < 27) {
+                issue_slab(o + 1, (o + 1) & 1);
+                rs.fetch(in_split, in_plane, nbrs[o + 1], mine);
             }
+        } else {
+            if (o + 1 < 27) {
+                issue_slab(o + 1, (o + 1) & 1);
+                load_rows(nbrs[o + 1], ah[(o + 1) & 1], al[(o + 1) & 1]);
+            }
+            if (live) multiply_offset<NC, NT, BF>(acc, ah[o & (NBUF - 1)], al[o & (NBUF - 1)], nbr >= 0, sl);
         }
         if (o + 1 < 27) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of slab o + 1 (and the prefetched rows) have landed
             __syncthreads();                                  // ... everybody's have, and everybody is done reading slab o
         }
     }
-    if (row0 >= n) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = (ct + t) * 32 + i;
-        double s = 0.0, ss = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = row0 + tile_row(r, hi);
-            const float v = acc[t][r];
-            if (orow < n) {
-                out_rows[(size_t)orow * COUT + co] = v;
-                s += (double)v;
-                ss += (double)v * (double)v;
-            }
-        }
-        s += __shfl_xor(s, 32);
-        ss += __shfl_xor(ss, 32);
-        if (hi == 0) {
-            atomicAdd(&stats[co], s);
-            atomicAdd(&stats[COUT + co], ss);
-        }
-    }
-}
-
-// conv16_lds_kernel with TWO offset groups per workgroup (8 waves: waves 0-3 take the even kernel offsets of the 128 rows,
-// waves 4-7 the odd ones, each group with its own double-buffered weight slab; the partial tiles meet in LDS at the end, fixed
-// order).  The mid levels of the SMPL grid (10-29 k rows) give 150-230 workgroups of the kernel above — less than one per
-// CU, one wave per SIMD — and each walks 27 offsets at 2.5-3.7 us apiece for 0.7 us of MFMA work: halving the chain halves
-// the launch, and the second wave per SIMD fills the first one's waits.
-template <int CIN, int COUT, int NT, bool BF = false>
-__global__ __launch_bounds__(512) void conv16_lds2_kernel(const unsigned short *__restrict__ in_split, long long in_plane,
-                                                          const int *__restrict__ in_grid, Dims gi, const int *__restrict__ out_lin,
-                                                          const int *__restrict__ n_out, Dims go, int stride,
-                                                          const bf16x8 *__restrict__ wp, float *__restrict__ out_rows,
-                                                          double *__restrict__ stats) {
-    constexpr int NC = CIN / 16, NTT = COUT / 32;
-    constexpr int NFRAG = NC * NT * 2;        // 1-KiB fragments of one offset's slab: [c][t][head, remainder]
-    constexpr int PER_WAVE = NFRAG / 4;       // DMAs per wave per offset
-    constexpr int NIT = 14;                   // offsets per group (group 1: 13)
-    static_assert(NFRAG % 4 == 0, "slab must split evenly over the four waves of a group");
-    static_assert(2 * 2 * NFRAG * 1024 >= 4 * NT * 64 * 16 * 4, "the partial tiles fit in the slab memory");
-    __shared__ __attribute__((aligned(16))) char slab[2][2][NFRAG * 1024];  // [group][buffer]
-    const int ct = blockIdx.y * NT;
-    const int lane = threadIdx.x & 63, i = lane & 31, hi = lane >> 5;
-    const int wv8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wv = wv8 & 3, grp = wv8 >> 2;
-    const int n = *n_out;
-    const int row0 = (blockIdx.x * 4 + wv) * 32;
-    if (blockIdx.x * 128 >= n) return;  // workgroup-uniform: every wave of a live workgroup takes part in the barriers
-    const int row = row0 + i;
-    const bool valid = row < n;
-    const int lin = valid ? out_lin[row] : 0;
-    const int x = lin % go.w, y = (lin / go.w) % go.h, z = lin / (go.w * go.h);
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    auto issue_slab = [&](int o, int buf) {  // this wave's share of offset o's fragments -> slab[grp][buf]
-#pragma unroll
-        for (int q = 0; q < PER_WAVE; ++q) {
-            const int f = wv * PER_WAVE + q;           // local fragment (c, t, part) = ((c * NT) + t) * 2 + part
-            const int c = f / (NT * 2), rest = f % (NT * 2);
-            const bf16x8 *src = wp + (((size_t)o * NC + c) * NTT + ct) * 2 * 64 + (size_t)rest * 64 + lane;
-            __builtin_amdgcn_global_load_lds((nb_gptr_t)src, (nb_lptr_t)(slab[grp][buf] + f * 1024), 16, 0, 0);
-        }
-    };
-    int nbrs[NIT];
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int o = 2 * k + grp;
-        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
-        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
-        int nbr = -1;
-        if (o < 27 && valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
-            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
-        nbrs[k] = nbr;
-    }
-    auto load_rows = [&](int nbr, bf16x8 (&ah)[NC], bf16x8 (&al)[NC]) {
-        const size_t r = (size_t)(nbr >= 0 ? nbr : 0) * CIN + 8 * hi;
-        const bf16x8 *ph = reinterpret_cast<const bf16x8 *>(in_split + r);
-        const bf16x8 *pl = reinterpret_cast<const bf16x8 *>(in_split + in_plane + r);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            ah[c] = ph[2 * c];
-            al[c] = pl[2 * c];
-        }
-    };
-    bf16x8 ah[2][NC], al[2][NC];
-    issue_slab(grp, 0);
-    load_rows(nbrs[0], ah[0], al[0]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NIT; ++k) {
-        const int o = 2 * k + grp;
-        if (k + 1 < NIT && o + 2 < 27) {
-            issue_slab(o + 2, (k + 1) & 1);  // the other buffer: its last readers passed the barrier that ended iteration k - 1
-            load_rows(nbrs[k + 1], ah[(k + 1) & 1], al[(k + 1) & 1]);
-        }
-        const int nbr = nbrs[k];
-        if (o < 27 && __any(nbr >= 0)) {
-            const bf16x8 *sl = reinterpret_cast<const bf16x8 *>(slab[grp][k & 1]) + lane;
-            bf16x8 zero;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) zero[e] = (nb_h16)0.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const bf16x8 a_h = nbr >= 0 ? ah[k & 1][c] : zero, a_l = nbr >= 0 ? al[k & 1][c] : zero;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bf16x8 bh = sl[((c * NT + t) * 2) * 64], bl = sl[((c * NT + t) * 2 + 1) * 64];
-                    acc[t] = NB_MFMA16(a_h, bh, acc[t]);
-                    acc[t] = NB_MFMA16(a_h, bl, acc[t]);
-                    acc[t] = NB_MFMA16(a_l, bh, acc[t]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of the next slab (and the prefetched rows) have landed
-        __syncthreads();                                  // ... everybody's have, and everybody is done reading this one
-    }
-    // the odd group's partial tiles -> LDS (the slabs are dead: the loop ended on a barrier), the even group adds and stores
-    float *part = reinterpret_cast<float *>(&slab[0][0][0]) + (size_t)wv * NT * 16 * 64;
-    if (grp == 1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) part[(t * 16 + r) * 64 + lane] = acc[t][r];
-    }
-    __syncthreads();
-    if (grp == 1 || row0 >= n) return;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = (ct + t) * 32 + i;
-        double s = 0.0, ss = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int orow = row0 + tile_row(r, hi);
-            const float v = acc[t][r] + part[(t * 16 + r) * 64 + lane];
-            if (orow < n) {
-                out_rows[(size_t)orow * COUT + co] = v;
-                s += (double)v;
-                ss += (double)v * (double)v;
-            }
-        }
-        s += __shfl_xor(s, 32);
-        ss += __shfl_xor(ss, 32);
-        if (hi == 0) {
-            atomicAdd(&stats[co], s);
-            atomicAdd(&stats[COUT + co], ss);
-        }
-    }
+    __syncthreads();  // the slabs are dead: their memory takes the sums
+    store_tile_and_sums<COUT, NT, 4>(acc, row0, n, ct, out_rows, stats, reinterpret_cast<double *>(lds), wv, lane);
 }
 
 // The same product with the 27 kernel offsets SPLIT OVER THE NW WAVES of a workgroup (one 32-row x 32-channel tile per
@@ -788,9 +786,18 @@ __global__ __launch_bounds__(64 * NW) void conv16_ks_kernel(const unsigned short
     }
     s += __shfl_xor(s, 32);
     ss += __shfl_xor(ss, 32);
+    // the waves' sums meet in LDS: one atomic per channel and workgroup (store_tile_and_sums)
+    __shared__ double sred[NW][2][32];
     if (hi == 0) {
-        atomicAdd(&stats[co], s);
-        atomicAdd(&stats[COUT + co], ss);
+        sred[wv][0][i] = s;
+        sred[wv][1][i] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += sred[w][hi][i];
+        atomicAdd(&stats[hi * COUT + co], v);
     }
 }
 
@@ -912,24 +919,16 @@ static int conv16_dispatch(const uint16_t *in_split, int32_t in_rows_cap, const 
         NB_CONV16_KS_CASE(128, 128)
 #undef NB_CONV16_KS_CASE
     }
-    // channel tiles per wave: all of them when the rows alone fill the chip (4 waves per group, 1024 SIMDs), else one per wave
-    // 64- and 128-channel layers: weight slab shared through LDS (measured slower for the 32-channel ones: 35 vs 29 us); all channel tiles per wave when the rows alone give >= 512
-    // workgroups, else two per wave (128 x 64-channel workgroups)
+    // 64- and 128-channel layers: weight slab shared through LDS (measured slower for the 32-channel ones: 35 vs 29 us); all channel
+    // tiles per wave when the rows alone give >= 512 workgroups, else two per wave (128-row x 64-channel workgroups)
 #define NB_CONV16_LDS_CASE(CI, CO)                                                                                          \
     if (cin == CI && cout == CO) {                                                                                           \
         constexpr int NTT = CO / 32;                                                                                        \
-        if (row_groups < 512) {                                                                                             \
-            hipLaunchKernelGGL((conv16_lds2_kernel<CI, CO, 2, BF>), dim3(row_groups, NTT / 2), dim3(512), 0, st, in_split, plane, \
-                               in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,  \
-                               stats);                                                                                      \
-            NB_CHECK_LAUNCH("nb_enc_conv16");                                                                               \
-            return NB_OK;                                                                                                   \
-        }                                                                                                                   \
         if (row_groups >= 512 || NTT <= 2)                                                                                  \
             hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, NTT, BF>), dim3(row_groups, 1), dim3(256), 0, st, in_split, plane, in_grid, \
                                gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows, stats); \
         else                                                                                                                \
-            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, (NTT >= 2 ? 2 : 1), BF>), dim3(row_groups, NTT >= 2 ? NTT / 2 : 1), dim3(256), 0, st, in_split, plane, \
+            hipLaunchKernelGGL((conv16_lds_kernel<CI, CO, 2, BF>), dim3(row_groups, NTT / 2), dim3(256), 0, st, in_split, plane, \
                                in_grid, gi, out_lin, n_out, go, stride, reinterpret_cast<const bf16x8 *>(wpacked), out_rows,     \
                                stats);                                                                                      \
         NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
