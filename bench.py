@@ -651,19 +651,24 @@ def encoder_bench(args, dev):
             front()
         e1.record()
         torch.cuda.synchronize()
-        launches = None
+        launches = kernel_ms = None
         try:
             from torch.profiler import ProfilerActivity, profile
 
             with profile(activities=[ProfilerActivity.CUDA]) as prof:
                 front()
                 torch.cuda.synchronize()
-            launches = sum(1 for e in prof.events() if e.device_type is not None and str(e.device_type).endswith("CUDA"))
+            dev_events = [e for e in prof.events() if e.device_type is not None and str(e.device_type).endswith("CUDA")]
+            launches = len(dev_events)
+            kernel_ms = sum(e.time_range.end - e.time_range.start for e in dev_events) / 1000.0
         except Exception:  # the profiler is informational
             pass
-    return {"encoder_ms": e0.elapsed_time(e1) / 10, "launches_per_view": launches,
-            "encoder_note": "prepare_sp_input + 17 sparse conv/BN/ReLU layers + nb_fold_build + latent bias of one view, no march: "
-                            "HIP events over 10 repetitions; launches = device kernels + memsets of one repetition (torch.profiler)"}
+    return {"encoder_ms": e0.elapsed_time(e1) / 10, "encoder_kernel_ms": kernel_ms, "launches_per_view": launches,
+            "encoder_note": "prepare_sp_input + 17 sparse conv/BN/ReLU layers + nb_fold_build + latent bias of one view, no march.  "
+                            "encoder_ms: HIP events over 10 back-to-back repetitions with nothing else on the device — set by the launch "
+                            "thread (57 launches at ~18 us each), not by the kernels; encoder_kernel_ms: the durations of one repetition's "
+                            "kernels and memsets summed (torch.profiler), i.e. what the pass costs behind a march, when the launch thread "
+                            "is ahead (profiles/r05_step_timeline.md: the same from a rocprofv3 trace); launches = those events"}
 
 
 def main():
