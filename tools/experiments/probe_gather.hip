@@ -9,7 +9,9 @@
 //   C. ROWB / 16 lanes per row, contiguous (whole rows, fully coalesced);
 //   D. four lanes per 64-byte piece, consecutive quads on DIFFERENT rows (quad Q: row Q % RPI, 64-byte piece Q / RPI);
 //   E. map C by LDS-DMA (global_load_lds_dwordx4: 1 KiB per instruction lands lane-contiguous in LDS), then the A fragments
-//      read back with ds_read_b128 — the whole staged path.
+//      read back with ds_read_b128 — the whole staged path;
+//   F. the march's weight stream: every instruction one contiguous 1-KiB piece (lane l its bytes [16 l, 16 l + 16)) out of a 704-KiB
+//      L2-resident matrix, eight pieces in flight per wave — the ceiling of the vector-memory path for fully coalesced wave loads.
 // The same bytes in every map.  Rows are consecutive with gaps (a slab of a level in voxel order) or random.
 #include <hip/hip_runtime.h>
 
@@ -134,6 +136,44 @@ static void run_lds(const char *rows, long long plane, const int *idx, int offse
            what, ROWB, ms * 1e3, bytes_cu / (ms * 1e6), bytes_cu / (ms * 1e6) / 2.1, 256 * bytes_cu / (ms * 1e9));
 }
 
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void stream_kernel(const char *__restrict__ w, int pieces, int iters, int *__restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    v4i acc = {0, 0, 0, 0};
+    int p = (blockIdx.x * 37 + wv * 11) % pieces;
+    for (int it = 0; it < iters; ++it) {
+        v4i v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            v[r] = *reinterpret_cast<const v4i *>(w + (size_t)p * 1024 + lane * 16);
+            p = p + 1 == pieces ? 0 : p + 1;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) acc += v[r];
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 0x12345678) out[threadIdx.x] = 1;
+}
+
+template <int WAVES>
+static void run_stream(const char *w, int *out) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    const int pieces = 704, iters = 400;
+    for (int k = 0; k < 2; ++k) hipLaunchKernelGGL((stream_kernel<WAVES>), dim3(256), dim3(64 * WAVES), 0, 0, w, pieces, iters, out);
+    CK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL((stream_kernel<WAVES>), dim3(256), dim3(64 * WAVES), 0, 0, w, pieces, iters, out);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= reps;
+    const double bytes_cu = (double)WAVES * iters * 8 * 1024;
+    printf("  map F, %d waves per CU: %7.1f us, %6.1f bytes per ns and CU (%5.1f per clock at 2.1 GHz), %.2f TB/s over 256 CUs\n", WAVES, ms * 1e3,
+           bytes_cu / (ms * 1e6), bytes_cu / (ms * 1e6) / 2.1, 256 * bytes_cu / (ms * 1e9));
+}
+
 template <int MAP, int ROWB>
 static void run(const char *rows, long long plane, const int *idx, int offsets, int *out, const char *what) {
     hipEvent_t e0, e1;
@@ -189,5 +229,9 @@ int main() {
         run<3, 128>(rows, plane / 2, idx, offsets, out, what);
         run_lds<128>(rows, plane / 2, idx, offsets, out, what);
     }
+    printf("contiguous 1-KiB pieces of a 704-KiB matrix (the march's weight stream: 1 408 KiB per CU and depth step in ~40.6 k cycles = 35 bytes per clock):\n");
+    run_stream<4>(rows, out);
+    run_stream<8>(rows, out);
+    run_stream<16>(rows, out);
     return 0;
 }
