@@ -338,7 +338,7 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
  * Operands as fp16 head + fp16 remainder, three products per K chunk on v_mfma_f32_32x32x16_f16 with fp32 accumulation
  * (~2^-21 relative per product), 1.3-1.9x faster than nb_enc_conv.  cin in {32, 64, 128}, cout in {32, 64, 128}.
  *   nb_enc_conv_pack16: weight dev [3,3,3,Cin,Cout] fp32 -> packed dev, 27*Cin*Cout*2 uint16 (MFMA B-fragment order).
- *     mode 0: the forward convolution, fp16 pairs.  mode 1: the BACKWARD-INPUT convolution of a stride-1 layer as a
+ *     mode 0: the forward convolution, fp16 pairs.  mode 1: the BACKWARD-INPUT convolution of a layer as a
  *     convolution of its own (d in[q] = sum_o d out[q + o - 1] . W[26 - o]^T: mirrored offsets, transposed slabs), bf16 pairs
  *     (gradients span more binades than an un-scaled fp16 head holds): `cin`, `cout` are those of the packed convolution =
  *     the layer's Cout, Cin; `weight` is the layer's weight [3,3,3,cout,cin].  Run it with nb_enc_conv16(flags = NB_CONV_BF16)
@@ -347,7 +347,11 @@ int nb_enc_bn_relu(float *rows, const int32_t *n_rows, int32_t n_rows_max, int32
  *     uint16 = the bytes of an fp32 [n_rows_max, c] matrix: heads, then remainders); `rows` (the raw convolution output) is
  *     only read; dense as in nb_enc_bn_relu; rows_out (dev or NULL): the activated rows in fp32 as well (the training
  *     forward keeps them for nb_enc_bn_relu_bwd / nb_enc_conv_bwd_weight while the next convolution reads the planes)
- *   nb_enc_conv16: in_split = such a pair of planes with in_rows_cap rows each; everything else as nb_enc_conv */
+ *   nb_enc_conv16: in_split = such a pair of planes with in_rows_cap rows each; everything else as nb_enc_conv, and
+ *     stride = -2: the TRANSPOSED gather of a stride-2 layer (its backward-input product with a mode-1 pack): output row p (a row
+ *     of the layer's input level) takes, under offset k, the row of voxel (p - 1 + k) / 2 of in_grid (the layer's output grid)
+ *     where that division is exact in all three coordinates.  Channel pairs: (32,32) (32,64) (64,32) (64,64) (64,128) (128,64)
+ *     (128,128) */
 int nb_enc_conv_pack16(const float *weight, int32_t cin, int32_t cout, uint16_t *packed, int32_t mode, void *stream);
 /* up to NB_PACK_BATCH_MAX nb_enc_conv_pack16 jobs in ONE launch (host arrays of device pointers and sizes): a training step re-packs
  * every >= 32-channel convolution after each optimiser step, forward (mode 0) and backward-input (mode 1) forms */

@@ -151,6 +151,19 @@ __global__ __launch_bounds__(nbscan::BLOCK) void grid_number_kernel(int *__restr
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = min(before + tot, cap);
 }
 
+// Row of the input level under kernel offset o of output voxel (z, y, x), or -1.  stride > 0: the forward gather, input voxel
+// = stride * out - 1 + k.  stride < 0: the TRANSPOSED gather of a layer of stride -stride (its backward-input product as a convolution
+// of its own, offsets already mirrored by nb_enc_conv_pack16 mode 1): "input" voxel = (out - 1 + k) / -stride where that divides.
+__device__ __forceinline__ int neighbour_row(const int *__restrict__ in_grid, Dims gi, int z, int y, int x, int o, int stride, bool valid) {
+    const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
+    const int mul = stride > 0 ? stride : 1, low = stride > 0 ? 0 : -stride - 1, sh = stride > 0 ? 0 : (-stride) >> 1;  // -stride in {1, 2}
+    int iz = z * mul - 1 + kd, iy = y * mul - 1 + kh, ix = x * mul - 1 + kw;
+    if (!valid || ((iz | iy | ix) & low) != 0 || iz < 0 || iy < 0 || ix < 0) return -1;
+    iz >>= sh, iy >>= sh, ix >>= sh;
+    if (iz >= gi.d || iy >= gi.h || ix >= gi.w) return -1;
+    return in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
+}
+
 // ------------------------------------------------------------------ a tile's way out
 // The tile is stored; its BatchNorm sums (fp64: sum and sum of squares per channel) meet those of the workgroup's other waves in LDS
 // and leave as ONE atomic per channel and workgroup.  As one pair of atomics per WAVE the ~900 waves of a 29 k-row level queued on
@@ -227,12 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(const float *__restrict__ 
     int nbrs[27];
 #pragma unroll
     for (int o = 0; o < 27; ++o) {
-        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
-        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
-        int nbr = -1;
-        if (valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
-            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
-        nbrs[o] = nbr;
+        nbrs[o] = neighbour_row(in_grid, gi, z, y, x, o, stride, valid);
     }
     f32x4 Ar[2][HALF / 4];
     auto load_rows = [&](int nbr, f32x4 (&dst)[HALF / 4]) {
@@ -389,12 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv16_kernel(const unsigned short *__
     int nbrs[27];
 #pragma unroll
     for (int o = 0; o < 27; ++o) {
-        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
-        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
-        int nbr = -1;
-        if (valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
-            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
-        nbrs[o] = nbr;
+        nbrs[o] = neighbour_row(in_grid, gi, z, y, x, o, stride, valid);
     }
     // A fragments: lane (row i, half hi) holds channels 16 c + 8 hi .. + 7 of its neighbour row (zeros when inactive)
     auto load_rows = [&](int nbr, bf16x8 (&ah)[NC], bf16x8 (&al)[NC]) {
@@ -607,12 +610,7 @@ __global__ __launch_bounds__(256, 2) void conv16_lds_kernel(const unsigned short
     int nbrs[27];
 #pragma unroll
     for (int o = 0; o < 27; ++o) {
-        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
-        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
-        int nbr = -1;
-        if (valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
-            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
-        nbrs[o] = nbr;
+        nbrs[o] = neighbour_row(in_grid, gi, z, y, x, o, stride, valid);
     }
     auto load_rows = [&](int nbr, bf16x8 (&ah)[NC], bf16x8 (&al)[NC]) {
         const size_t r = (size_t)(nbr >= 0 ? nbr : 0) * CIN + 8 * hi;
@@ -710,12 +708,7 @@ __global__ __launch_bounds__(64 * NW) void conv16_ks_kernel(const unsigned short
 #pragma unroll
     for (int k = 0; k < MAXO; ++k) {
         const int o = wv + NW * k;
-        const int kd = o / 9, kh = (o / 3) % 3, kw = o % 3;
-        const int iz = z * stride - 1 + kd, iy = y * stride - 1 + kh, ix = x * stride - 1 + kw;
-        int nbr = -1;
-        if (o < 27 && valid && (unsigned)iz < (unsigned)gi.d && (unsigned)iy < (unsigned)gi.h && (unsigned)ix < (unsigned)gi.w)
-            nbr = in_grid[((long long)iz * gi.h + iy) * gi.w + ix];
-        nbrs[k] = nbr;
+        nbrs[k] = neighbour_row(in_grid, gi, z, y, x, o < 27 ? o : 0, stride, o < 27 && valid);
     }
     f32x16 acc;
 #pragma unroll
@@ -914,8 +907,10 @@ static int conv16_dispatch(const uint16_t *in_split, int32_t in_rows_cap, const 
     }
         NB_CONV16_KS_CASE(32, 32)
         NB_CONV16_KS_CASE(32, 64)
+        NB_CONV16_KS_CASE(64, 32)
         NB_CONV16_KS_CASE(64, 64)
         NB_CONV16_KS_CASE(64, 128)
+        NB_CONV16_KS_CASE(128, 64)
         NB_CONV16_KS_CASE(128, 128)
 #undef NB_CONV16_KS_CASE
     }
@@ -934,8 +929,10 @@ static int conv16_dispatch(const uint16_t *in_split, int32_t in_rows_cap, const 
         NB_CHECK_LAUNCH("nb_enc_conv16");                                                                                   \
         return NB_OK;                                                                                                       \
     }
+    NB_CONV16_LDS_CASE(64, 32)
     NB_CONV16_LDS_CASE(64, 64)
     NB_CONV16_LDS_CASE(64, 128)
+    NB_CONV16_LDS_CASE(128, 64)
     NB_CONV16_LDS_CASE(128, 128)
 #undef NB_CONV16_LDS_CASE
 #define NB_CONV16_CASE(CI, CO)                                                                                              \
@@ -1118,7 +1115,7 @@ int nb_enc_conv16(const uint16_t *in_split, int32_t in_rows_cap, const int32_t *
                   void *stream) {
     NB_REQUIRE(in_split && in_grid && in_dhw && out_lin && n_out && out_dhw && wpacked && out_rows && stats,
                "nb_enc_conv16: NULL pointer");
-    NB_REQUIRE(stride == 1 || stride == 2, "nb_enc_conv16: stride %d", stride);
+    NB_REQUIRE(stride == 1 || stride == 2 || stride == -2, "nb_enc_conv16: stride %d", stride);
     NB_REQUIRE(in_rows_cap > 0, "nb_enc_conv16: in_rows_cap %d", in_rows_cap);
     hipStream_t st = (hipStream_t)stream;
     const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]}, go = {out_dhw[0], out_dhw[1], out_dhw[2]};

@@ -148,7 +148,7 @@ class SparseConvNet(nn.Module):
 
     def repack_stale(self, with_backward):
         """Every stale packed form of the >= 32-channel convolutions in ONE launch (after an optimiser step all of them are stale:
-        14 forward forms + 11 backward-input forms of the stride-1 layers = 25 launches otherwise)."""
+        14 forward forms + 14 backward-input forms = 28 launches otherwise)."""
         jobs, slots = [], []
         for name, cin, cout, n, stride in ENCODER_BLOCKS:
             block = getattr(self, name)
@@ -157,7 +157,7 @@ class SparseConvNet(nn.Module):
                 if int(conv.weight.shape[3]) < 32:
                     continue
                 w, key = self._wkey(conv)
-                forms = [("_nb_packed16", False)] + ([("_nb_packed16_bwd", True)] if with_backward and stride == 1 else [])
+                forms = [("_nb_packed16", False)] + ([("_nb_packed16_bwd", True)] if with_backward else [])
                 for attr, bwd in forms:
                     if not self._fresh(getattr(conv, attr, None), key):
                         jobs.append((w, bwd))

@@ -93,6 +93,7 @@ def decoder_backward(net, tap, d_raw, latent_index, arena=None):
 
 USE_ARENA = os.environ.get("NB_BWD_ARENA", "1") != "0"  # one zero fill per backward pass instead of one per accumulator
 BWD_INPUT_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # backward-input convolutions on the 16-bit matrix pipe (bf16 pairs)
+BWD_INPUT_STRIDED = os.environ.get("NB_ENC_SPLIT_STRIDED", "1") != "0"  # ... those of the strided layers too (0: exact-fp32 kernel)
 
 
 DECODER_ARENA = [((n,), torch.float32) for n in (3, 1, 128, 256, 256, 256, 256, 256)]  # decoder_backward's zeros(), in order
@@ -144,11 +145,11 @@ def encoder_backward(xyzc_net, ctx, drows_dense, arena=None):
         conv, bn = rec["conv"], rec["bn"]
         w = conv.weight.detach()
         cin, cout = int(w.shape[3]), int(w.shape[4])
-        # a stride-1 (submanifold) layer's backward-input product is a convolution of its own — mirrored offsets, transposed
-        # slabs, same active set — and runs on the forward's matrix-pipe kernels with bf16 head / remainder operands
-        # (nb_enc_conv16 with NB_CONV_BF16; gradients span more binades than an un-scaled fp16 head holds).  The strided layers
-        # and the 16-channel ones keep the exact-fp32 kernel.
-        on_pipe = BWD_INPUT_SPLIT and rec["stride"] == 1 and cin >= 32
+        # a layer's backward-input product is a convolution of its own — mirrored offsets, transposed slabs; for a strided layer the
+        # TRANSPOSED gather (nb_enc_conv16 with stride = -2: input voxel p takes output voxel (p - 1 + k) / 2 where that divides) —
+        # and runs on the forward's matrix-pipe kernels with bf16 head / remainder operands (NB_CONV_BF16; gradients span more
+        # binades than an un-scaled fp16 head holds).  The 16-channel layers keep the exact-fp32 kernel.
+        on_pipe = BWD_INPUT_SPLIT and cin >= 32 and (rec["stride"] == 1 or BWD_INPUT_STRIDED)
         dx_split = None
         take = (lambda shape, dt=torch.float32: arena.take(shape, dt)) if arena is not None else (lambda shape, dt=torch.float32: None)  # noqa: E731
         if BWD_INPUT_SPLIT and cin >= 32:  # (the weight gradient of every >= 32-channel layer takes the planes too)
@@ -165,14 +166,28 @@ def encoder_backward(xyzc_net, ctx, drows_dense, arena=None):
                                                                rulebook=rulebooks.setdefault(
                                                                    (rec["in_grid"].data_ptr(), rec["out_lin"].data_ptr(), rec["stride"]), []))
         if on_pipe:
+            # (the kernel's BatchNorm sums of dIn are of no use: they go to a scratch nobody zeroes or reads — no memset per call)
             dy = ops.enc_conv16(dx_split, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
-                                rec["in_dhw"], 1, xyzc_net._packed16(conv, backward_input=True), cout, cin, bf16=True)[0]
+                                rec["in_dhw"], 1 if rec["stride"] == 1 else -rec["stride"],
+                                xyzc_net._packed16(conv, backward_input=True), cout, cin, bf16=True,
+                                stats=_sums_sink(dy.device, 2 * cin))[0]
         else:
             dy = ops.enc_conv_bwd_input(dx, rec["out_grid"], rec["out_dhw"], rec["in_lin"], rec["n_in"], rec["n_in_max"],
                                         rec["in_dhw"], rec["stride"], w, out=take((max(int(rec["n_in_max"]), 1), cin)))
     dcodes = ops.enc_scatter_codes_bwd(dy, head["rows_vert"], head["n_rows"], head["n_max"], 6890,
                                        out=arena.take((6890, 16)) if arena is not None else None)
     return g, dcodes
+
+
+_SINKS = {}
+
+
+def _sums_sink(device, n):
+    """fp64 [n] scratch for statistics outputs that are never read (one per device and size)."""
+    key = (str(device), n)
+    if key not in _SINKS:
+        _SINKS[key] = torch.empty(n, dtype=torch.float64, device=device)
+    return _SINKS[key]
 
 
 def _blocks():
