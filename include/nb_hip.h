@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 18
+#define NB_ABI_VERSION 19
 
 /* arithmetic of the decoder (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0   /* exact fp32 on v_mfma_f32_32x32x2_f32, trilinear gather of the dense volumes on the VALU: the reference's
@@ -303,6 +303,16 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
                             const int32_t in_dhw[3], const int32_t out_dhw[3], int32_t *out_grid,
                             int32_t *out_lin, int32_t *n_out, int32_t n_out_max, void *scratch, int32_t flags,
                             void *stream);
+/* The index sets of n_levels (<= NB_DOWN_LEVELS_MAX) SUCCESSIVE strided levels below a voxelised level in three launches instead of
+ * three per level: level l's out_dhw is the l-fold floor((d - 1) / 2) + 1 of in_dhw; out_grid[l], out_lin[l], n_out[l], n_out_max[l] (host
+ * arrays of device pointers / capacities) as in nb_enc_downsample_index.  A cell c of level l is active iff an active voxel p of the
+ * base level lies within [2^l c - (2^l - 1), 2^l c + (2^l - 1)] in every coordinate: the per-level rule composed, and the same
+ * cells, rows and order as n_levels chained nb_enc_downsample_index calls as long as no capacity clamps (the capacities of
+ * ops.down_capacity are upper bounds).  scratch: nb_scan_scratch_size(cells of level 1) bytes. */
+#define NB_DOWN_LEVELS_MAX 4
+int nb_enc_downsample_index_all(const int32_t *in_lin, const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3],
+                                int32_t n_levels, int32_t *const out_grid[], int32_t *const out_lin[], int32_t *const n_out[],
+                                const int32_t n_out_max[], void *scratch, int32_t flags, void *stream);
 
 /* One sparse 3x3x3 convolution (stride 1 submanifold or stride 2) without bias:
  *   out[r, :] = sum_o W[o] . in[nbr(r, o), :]   over ACTIVE neighbours

@@ -9,7 +9,7 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 18
+ABI_VERSION = 19
 SLOT_DEAD = -2147483648  # NB_SLOT_DEAD
 PRECISIONS = {"f32": 0, "f16f6": 1}
 PACK_SECTIONS = {"f32": 1, "f16f6": 2}
@@ -83,6 +83,7 @@ SIGNATURES = {
     "nb_scan_scratch_size": (_I64, [_I64]),
     "nb_enc_voxelize": (C.c_int, [_P, _I32, _I32x3, _P, _P, _P, _P, _P, _I32, _P]),
     "nb_enc_downsample_index": (C.c_int, [_P, _P, _I32, _I32x3, _I32x3, _P, _P, _P, _I32, _P, _I32, _P]),
+    "nb_enc_downsample_index_all": (C.c_int, [_P, _P, _I32, _I32x3, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "nb_enc_conv": (C.c_int, [_P, _P, _I32x3, _P, _P, _I32, _I32x3, _I32, _P, _I32, _I32, _P, _P, _I32, _P]),
     "nb_enc_bn_relu": (C.c_int, [_P, _P, _I32, _I32, _P, _P, _P, _P, _P, C.c_int, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "nb_enc_conv_pack16": (C.c_int, [_P, _I32, _I32, _P, _I32, _P]),

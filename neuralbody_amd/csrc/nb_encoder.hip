@@ -151,6 +151,79 @@ __global__ __launch_bounds__(nbscan::BLOCK) void grid_number_kernel(int *__restr
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *n_out = min(before + tot, cap);
 }
 
+// ------------------------------------------------------------------ the index sets of ALL strided levels in three launches
+// A cell c of the l-th level below a voxelised base level (k = 3, s = 2, p = 1 each) is active iff an active base voxel p lies within
+// [2^l c - (2^l - 1), 2^l c + (2^l - 1)] in every coordinate — the per-level rule of down_mark_kernel composed — so every base voxel
+// marks its (at most 8) cells on every level at once, and one count and one numbering launch walk the tiles of all levels' grids.
+struct DownAll {
+    int n_levels;
+    Dims dims[NB_DOWN_LEVELS_MAX];
+    int *grid[NB_DOWN_LEVELS_MAX], *out_lin[NB_DOWN_LEVELS_MAX], *n_out[NB_DOWN_LEVELS_MAX];
+    int cap[NB_DOWN_LEVELS_MAX];
+    long long nvox[NB_DOWN_LEVELS_MAX];
+    int tile0[NB_DOWN_LEVELS_MAX + 1];  // first tile (= block) of each level's grid in the count / numbering launches
+};
+
+__global__ void down_mark_all_kernel(const int *__restrict__ in_lin, const int *__restrict__ n_in, Dims gi, DownAll a) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= *n_in) return;
+    const int lin = in_lin[r];
+    const int x = lin % gi.w, y = (lin / gi.w) % gi.h, z = lin / (gi.w * gi.h);
+    for (int l = 0; l < a.n_levels; ++l) {
+        const int sh = l + 1, up = (1 << sh) - 1;  // cells floor(p / 2^sh) and floor((p + 2^sh - 1) / 2^sh)
+        const Dims go = a.dims[l];
+        const int oz[2] = {z >> sh, (z + up) >> sh}, oy[2] = {y >> sh, (y + up) >> sh}, ox[2] = {x >> sh, (x + up) >> sh};
+        for (int i = 0; i < 1 + (oz[1] != oz[0]); ++i)
+            for (int j = 0; j < 1 + (oy[1] != oy[0]); ++j)
+                for (int k = 0; k < 1 + (ox[1] != ox[0]); ++k)
+                    if (oz[i] < go.d && oy[j] < go.h && ox[k] < go.w)
+                        a.grid[l][((long long)oz[i] * go.h + oy[j]) * go.w + ox[k]] = 0;  // mark (any value >= 0)
+    }
+}
+
+__device__ __forceinline__ int down_all_level(const DownAll &a) {  // (block-uniform) the level whose grid this block's tile is in
+    int l = 0;
+    while (l + 1 < a.n_levels && (int)blockIdx.x >= a.tile0[l + 1]) ++l;
+    return l;
+}
+
+__global__ __launch_bounds__(nbscan::BLOCK) void grid_count_all_kernel(DownAll a, int *__restrict__ block_sums) {
+    const int l = down_all_level(a);
+    const int *grid = a.grid[l];
+    const long long n = a.nvox[l], i0 = (long long)((int)blockIdx.x - a.tile0[l]) * nbscan::TILE + threadIdx.x * nbscan::ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i)
+        if (i0 + i < n) s += grid[i0 + i] >= 0;
+    int tot;
+    nbscan::block_excl_scan(s, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(nbscan::BLOCK) void grid_number_all_kernel(DownAll a, const int *__restrict__ block_sums) {
+    const int l = down_all_level(a), tile = (int)blockIdx.x - a.tile0[l];
+    int *grid = a.grid[l];
+    const long long n = a.nvox[l], i0 = (long long)tile * nbscan::TILE + threadIdx.x * nbscan::ITEMS;
+    const int cap = a.cap[l];
+    const int before = nbscan::blocks_before(block_sums + a.tile0[l], tile);
+    int f[nbscan::ITEMS], s = 0;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i) {
+        f[i] = i0 + i < n ? grid[i0 + i] >= 0 : 0;
+        s += f[i];
+    }
+    int tot;
+    int r = nbscan::block_excl_scan(s, &tot) + before;
+#pragma unroll
+    for (int i = 0; i < nbscan::ITEMS; ++i) {
+        if (!f[i]) continue;
+        grid[i0 + i] = r < cap ? r : -1;
+        if (r < cap) a.out_lin[l][r] = (int)(i0 + i);
+        ++r;
+    }
+    if ((int)blockIdx.x == a.tile0[l + 1] - 1 && threadIdx.x == 0) *a.n_out[l] = min(before + tot, cap);
+}
+
 // Row of the input level under kernel offset o of output voxel (z, y, x), or -1.  stride > 0: the forward gather, input voxel
 // = stride * out - 1 + k.  stride < 0: the TRANSPOSED gather of a layer of stride -stride (its backward-input product as a convolution
 // of its own, offsets already mirrored by nb_enc_conv_pack16 mode 1): "input" voxel = (out - 1 + k) / -stride where that divides.
@@ -1004,6 +1077,44 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
     hipLaunchKernelGGL(grid_count_kernel, tiles, blk, 0, st, out_grid, nvox, bs);
     hipLaunchKernelGGL(grid_number_kernel, tiles, blk, 0, st, out_grid, nvox, bs, n_out_max, out_lin, n_out);
     NB_CHECK_LAUNCH("nb_enc_downsample_index");
+    return NB_OK;
+}
+
+int nb_enc_downsample_index_all(const int32_t *in_lin, const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3], int32_t n_levels,
+                                int32_t *const out_grid[], int32_t *const out_lin[], int32_t *const n_out[], const int32_t n_out_max[],
+                                void *scratch, int32_t flags, void *stream) {
+    NB_REQUIRE(in_lin && n_in && in_dhw && out_grid && out_lin && n_out && n_out_max && scratch, "nb_enc_downsample_index_all: NULL pointer");
+    NB_REQUIRE(n_levels >= 1 && n_levels <= NB_DOWN_LEVELS_MAX, "nb_enc_downsample_index_all: %d levels (1..%d)", n_levels, NB_DOWN_LEVELS_MAX);
+    NB_REQUIRE(n_in_max >= 0 && in_dhw[0] > 0 && in_dhw[1] > 0 && in_dhw[2] > 0, "nb_enc_downsample_index_all: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    DownAll a = {};
+    a.n_levels = n_levels;
+    Dims d = {in_dhw[0], in_dhw[1], in_dhw[2]};
+    const long long nvox1 = (long long)((d.d - 1) / 2 + 1) * ((d.h - 1) / 2 + 1) * ((d.w - 1) / 2 + 1);
+    for (int l = 0; l < n_levels; ++l) {
+        NB_REQUIRE(out_grid[l] && out_lin[l] && n_out[l] && n_out_max[l] >= 0, "nb_enc_downsample_index_all: level %d: NULL pointer or negative capacity", l);
+        d = {(d.d - 1) / 2 + 1, (d.h - 1) / 2 + 1, (d.w - 1) / 2 + 1};
+        a.dims[l] = d;
+        a.grid[l] = out_grid[l];
+        a.out_lin[l] = out_lin[l];
+        a.n_out[l] = n_out[l];
+        a.cap[l] = n_out_max[l];
+        a.nvox[l] = (long long)d.d * d.h * d.w;
+        a.tile0[l + 1] = a.tile0[l] + (int)nb_scan_blocks(a.nvox[l]);
+        if (!(flags & NB_GRID_PREFILLED)) NB_HIP(hipMemsetAsync(out_grid[l], 0xFF, a.nvox[l] * sizeof(int), st));
+    }
+    // the tiles' sums of all levels lie in the flags area of a scratch sized for the first level (nb_scan_scratch_size(cells of level 1))
+    int *fl, *pos, *bs;
+    nb_scan_carve(scratch, nvox1, &fl, &pos, &bs);
+    (void)pos, (void)bs;
+    NB_REQUIRE(a.tile0[n_levels] <= nvox1, "nb_enc_downsample_index_all: %d tiles for a scratch of %lld ints", a.tile0[n_levels], nvox1);
+    const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]};
+    if (n_in_max > 0)
+        hipLaunchKernelGGL(down_mark_all_kernel, dim3(nb_ceil_div(n_in_max, 256)), dim3(256), 0, st, in_lin, n_in, gi, a);
+    const dim3 tiles((unsigned)a.tile0[n_levels]), blk(nbscan::BLOCK);
+    hipLaunchKernelGGL(grid_count_all_kernel, tiles, blk, 0, st, a, fl);
+    hipLaunchKernelGGL(grid_number_all_kernel, tiles, blk, 0, st, a, fl);
+    NB_CHECK_LAUNCH("nb_enc_downsample_index_all");
     return NB_OK;
 }
 

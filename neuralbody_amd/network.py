@@ -35,6 +35,7 @@ BN_EPS, BN_MOMENTUM = 1e-3, 0.01  # latent_xyzc.py:215
 DEFAULT_PRECISION = "auto"
 ENC_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # encoder convolutions with >= 32 input channels on the 16-bit matrix pipe
 LAZY_DENSE = os.environ.get("NB_LAZY_DENSE", "1") != "0"  # inference: dense volumes materialised on first access only
+INDEX_ALL_LEVELS = os.environ.get("NB_INDEX_ALL", "1") != "0"  # the strided levels' index sets in three launches (0: three per level)
 SIX_BIT_MAX_SMALL = 0.5  # precision 'auto': largest per-layer share of weights six-bit blocks cannot hold before it takes 'f32'
 
 
@@ -204,6 +205,10 @@ class SparseConvNet(nn.Module):
         dense_bufs = [None if lazy else b[:math.prod(sh)].view(sh) for b, sh in zip(f32_buf[n_stats:].split(dense_sizes), dense_shapes)]
         level_rows, level_shapes = [], []
         grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw, buf=int_bufs.pop(0), grid=grid_bufs.pop(0))
+        # the index sets of all strided levels at once (three launches; a level at a time costs three each): they follow from the
+        # voxelised level alone
+        n_strided = sum(1 for layer in layers if layer[4] == 2)
+        down_sets = ops.enc_downsample_index_all(rows_lin, n_rows, n_max, dhw, int_bufs[:n_strided], grid_bufs[:n_strided]) if INDEX_ALL_LEVELS and 1 <= n_strided <= 4 else None
         rows = ops.enc_gather_codes(codes, rows_vert, n_rows, n_max)
         if save is not None:
             save.append({"rows_vert": rows_vert, "n_rows": n_rows, "n_max": n_max})
@@ -223,7 +228,9 @@ class SparseConvNet(nn.Module):
         for li, (name, cin, cout, n, stride, j) in enumerate(layers):
             block = getattr(self, name)
             conv, bn = block[3 * j], block[3 * j + 1]
-            if stride == 2:
+            if stride == 2 and down_sets is not None:
+                out_grid, out_lin, n_out, n_out_max, out_dhw = down_sets.pop(0)
+            elif stride == 2:
                 out_grid, out_lin, n_out, n_out_max, out_dhw = ops.enc_downsample_index(rows_lin, n_rows, n_max, dhw, buf=int_bufs.pop(0),
                                                                                            grid=grid_bufs.pop(0))
             else:

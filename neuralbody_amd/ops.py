@@ -378,6 +378,34 @@ def enc_downsample_index(in_lin, n_in, n_in_max, in_dhw, scratch=None, buf=None,
     return out_grid, out_lin, n_out, n_out_max, out_dhw
 
 
+def enc_downsample_index_all(in_lin, n_in, n_in_max, in_dhw, bufs, grids, scratch=None):
+    """nb_enc_downsample_index_all: the index sets of len(bufs) successive strided levels in three launches -> a list of
+    (out_grid, out_lin, n_out[1], n_out_max, out_dhw), one per level, equal to chained enc_downsample_index calls.
+    bufs[l]: a ZEROED int32 [capacity_l + 1] buffer for out_lin and n_out (capacity_l = down_capacity of the level above);
+    grids[l]: an int32 [D_l, H_l, W_l] buffer ALREADY FILLED WITH -1."""
+    _req(in_lin, torch.int32, (None,), "in_lin")
+    _req(n_in, torch.int32, (1,), "n_in")
+    n_levels = len(bufs)
+    if n_levels != len(grids) or not 1 <= n_levels <= 4:
+        raise ValueError("1..4 levels, one buffer and one grid each")
+    dev = in_lin.device
+    out, cap, d = [], int(n_in_max), [int(x) for x in in_dhw]
+    for l in range(n_levels):
+        cap, d = down_capacity(cap, d), down_dhw(d)
+        _req(grids[l], torch.int32, tuple(d), "grids[%d]" % l)
+        _req(bufs[l], torch.int32, (cap + 1,), "bufs[%d]" % l)
+        out.append((grids[l], bufs[l][:cap], bufs[l][cap:], cap, list(d)))
+    if scratch is None:
+        scratch = scan_scratch(math.prod(out[0][4]), dev)
+    pg = (C.c_void_p * n_levels)(*[o[0].data_ptr() for o in out])
+    pl = (C.c_void_p * n_levels)(*[o[1].data_ptr() for o in out])
+    pn = (C.c_void_p * n_levels)(*[o[2].data_ptr() for o in out])
+    caps = (C.c_int32 * n_levels)(*[o[3] for o in out])
+    check(_lib.lib().nb_enc_downsample_index_all(ptr(in_lin), ptr(n_in), int(n_in_max), _i3(in_dhw), n_levels, pg, pl, pn, caps,
+                                                 ptr(scratch), 1, _stream()), "nb_enc_downsample_index_all")
+    return out
+
+
 def enc_conv(in_rows, in_grid, in_dhw, out_lin, n_out, n_out_max, out_dhw, stride, weight, stats=None):
     """nb_enc_conv -> (out_rows [n_out_max, Cout], stats [2*Cout] fp64).  `stats`: a ZEROED fp64 [2*Cout] buffer of the
     caller's (the encoder clears the statistics of all its layers with one fill) — else the call allocates and clears one."""

@@ -21,7 +21,7 @@ def test_library_exports_every_header_symbol(lib):
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.nb_abi_version() == _lib.ABI_VERSION == 18
+    assert lib.nb_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_sizes_and_struct_layout(lib):

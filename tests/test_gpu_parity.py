@@ -478,6 +478,43 @@ def test_encoder_edge_cases():
     assert int(n_rows) == 0 and int((grid >= 0).sum()) == 0
 
 
+@pytest.mark.parametrize("dhw,n", [([61, 90, 47], 6890), ([32, 32, 32], 5), ([17, 9, 30], 400), ([8, 8, 8], 0)])
+def test_all_levels_index_sets_equal_the_chained_per_level_ones(dhw, n):
+    """nb_enc_downsample_index_all (three launches for the four strided levels) against four chained nb_enc_downsample_index calls:
+    the same active cells, the same row numbers, the same out_lin and counts, bit for bit — odd and even grid sizes, voxels on the
+    borders, an empty level; and the active cells against max_pool3d(k=3, s=2, p=1) of the level above."""
+    from neuralbody_amd import ops
+
+    rs = np.random.RandomState(7)
+    c = np.stack([rs.randint(0, s, size=max(n, 1)) for s in dhw], 1).astype(np.int32)
+    if n:
+        c[0] = [s - 1 for s in dhw]  # the far corner
+        c[-1] = 0
+    coord = torch.from_numpy(c[:n]).to(DEV).contiguous()
+    grid, rows_vert, rows_lin, n_rows = ops.enc_voxelize(coord, dhw)
+    chained, lin, cnt, cap, d = [], rows_lin, n_rows, n, list(dhw)
+    for _ in range(4):
+        og, ol, no, nmax, odhw = ops.enc_downsample_index(lin, cnt, cap, d)
+        chained.append((og, ol, no, nmax, odhw))
+        lin, cnt, cap, d = ol, no, nmax, odhw
+    bufs, grids, cap, d = [], [], n, list(dhw)
+    for _ in range(4):
+        cap, d = ops.down_capacity(cap, d), ops.down_dhw(d)
+        bufs.append(torch.zeros(cap + 1, dtype=torch.int32, device=DEV))
+        grids.append(torch.full(d, -1, dtype=torch.int32, device=DEV))
+    together = ops.enc_downsample_index_all(rows_lin, n_rows, n, dhw, bufs, grids)
+    torch.cuda.synchronize()
+    above = (grid >= 0).float().cpu()[None, None]
+    for level, (a, b) in enumerate(zip(chained, together)):
+        assert a[3] == b[3] and a[4] == b[4], level
+        assert int(a[2]) == int(b[2]), level
+        assert torch.equal(a[0], b[0]), level
+        k = int(a[2])
+        assert torch.equal(a[1][:k], b[1][:k]), level
+        above = (torch.nn.functional.max_pool3d(above, 3, 2, 1) > 0).float()
+        assert np.array_equal((b[0] >= 0).cpu().numpy(), above[0, 0].numpy() > 0), level
+
+
 # ------------------------------------------------------------------------------------------- end to end
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ALL)
