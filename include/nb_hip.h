@@ -308,7 +308,7 @@ int nb_enc_downsample_index(const int32_t *in_lin, const int32_t *n_in, int32_t 
  * arrays of device pointers / capacities) as in nb_enc_downsample_index.  A cell c of level l is active iff an active voxel p of the
  * base level lies within [2^l c - (2^l - 1), 2^l c + (2^l - 1)] in every coordinate: the per-level rule composed, and the same
  * cells, rows and order as n_levels chained nb_enc_downsample_index calls as long as no capacity clamps (the capacities of
- * ops.down_capacity are upper bounds).  scratch: nb_scan_scratch_size(cells of level 1) bytes. */
+ * ops.down_capacity are upper bounds).  scratch: nb_scan_scratch_size(max(cells of level 1, 64)) bytes. */
 #define NB_DOWN_LEVELS_MAX 4
 int nb_enc_downsample_index_all(const int32_t *in_lin, const int32_t *n_in, int32_t n_in_max, const int32_t in_dhw[3],
                                 int32_t n_levels, int32_t *const out_grid[], int32_t *const out_lin[], int32_t *const n_out[],

@@ -1103,11 +1103,13 @@ int nb_enc_downsample_index_all(const int32_t *in_lin, const int32_t *n_in, int3
         a.tile0[l + 1] = a.tile0[l] + (int)nb_scan_blocks(a.nvox[l]);
         if (!(flags & NB_GRID_PREFILLED)) NB_HIP(hipMemsetAsync(out_grid[l], 0xFF, a.nvox[l] * sizeof(int), st));
     }
-    // the tiles' sums of all levels lie in the flags area of a scratch sized for the first level (nb_scan_scratch_size(cells of level 1))
+    // the tiles' sums of all levels lie in the flags area of a scratch sized for the first level: nb_scan_scratch_size(max(cells of
+    // level 1, 64)) — a level of more than one tile has > 1024 cells, so n_levels <= 4 tiles or far fewer tiles than cells
+    const long long scratch_cells = nvox1 > 64 ? nvox1 : 64;
     int *fl, *pos, *bs;
-    nb_scan_carve(scratch, nvox1, &fl, &pos, &bs);
+    nb_scan_carve(scratch, scratch_cells, &fl, &pos, &bs);
     (void)pos, (void)bs;
-    NB_REQUIRE(a.tile0[n_levels] <= nvox1, "nb_enc_downsample_index_all: %d tiles for a scratch of %lld ints", a.tile0[n_levels], nvox1);
+    NB_REQUIRE(a.tile0[n_levels] <= scratch_cells, "nb_enc_downsample_index_all: %d tiles for a scratch of %lld ints", a.tile0[n_levels], scratch_cells);
     const Dims gi = {in_dhw[0], in_dhw[1], in_dhw[2]};
     if (n_in_max > 0)
         hipLaunchKernelGGL(down_mark_all_kernel, dim3(nb_ceil_div(n_in_max, 256)), dim3(256), 0, st, in_lin, n_in, gi, a);

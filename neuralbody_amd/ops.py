@@ -396,7 +396,7 @@ def enc_downsample_index_all(in_lin, n_in, n_in_max, in_dhw, bufs, grids, scratc
         _req(bufs[l], torch.int32, (cap + 1,), "bufs[%d]" % l)
         out.append((grids[l], bufs[l][:cap], bufs[l][cap:], cap, list(d)))
     if scratch is None:
-        scratch = scan_scratch(math.prod(out[0][4]), dev)
+        scratch = scan_scratch(max(math.prod(out[0][4]), 64), dev)
     pg = (C.c_void_p * n_levels)(*[o[0].data_ptr() for o in out])
     pl = (C.c_void_p * n_levels)(*[o[1].data_ptr() for o in out])
     pn = (C.c_void_p * n_levels)(*[o[2].data_ptr() for o in out])

@@ -478,7 +478,7 @@ def test_encoder_edge_cases():
     assert int(n_rows) == 0 and int((grid >= 0).sum()) == 0
 
 
-@pytest.mark.parametrize("dhw,n", [([61, 90, 47], 6890), ([32, 32, 32], 5), ([17, 9, 30], 400), ([8, 8, 8], 0)])
+@pytest.mark.parametrize("dhw,n", [([61, 90, 47], 6890), ([32, 32, 32], 5), ([17, 9, 30], 400), ([8, 8, 8], 0), ([2, 1, 2], 3)])
 def test_all_levels_index_sets_equal_the_chained_per_level_ones(dhw, n):
     """nb_enc_downsample_index_all (three launches for the four strided levels) against four chained nb_enc_downsample_index calls:
     the same active cells, the same row numbers, the same out_lin and counts, bit for bit — odd and even grid sizes, voxels on the
