@@ -106,3 +106,34 @@ def test_block_of_the_encoder_two_ways():
         rows = rb.batchnorm_relu_rows(rb.apply_rulebook(rows, ws[i], len(keys), p2), *gb[i])
     got = rb.dense(keys, rows, 1, out_shape)
     assert got.shape == want.shape and np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("shape", [(61, 90, 47), (16, 16, 16), (17, 9, 30), (2, 1, 2), (5, 4, 3)])
+def test_active_sets_of_stacked_strided_levels_follow_from_the_base_level_alone(shape):
+    """The rule nb_enc_downsample_index_all marks with: a cell c of the l-th k=3 / s=2 / p=1 level below a voxel set is active iff an
+    active base voxel p lies within [2^l c - (2^l - 1), 2^l c + (2^l - 1)] in every coordinate, i.e. c in {p >> l, (p + 2^l - 1) >> l}
+    per axis (clipped to the level's grid) — against the level-by-level rule of the reference's stack (max_pool3d(3, 2, 1) of the
+    occupancy, which is what SparseConv3d's output index set is: oracle/neuralbody_oracle.py), odd and even sizes, four levels."""
+    rs = np.random.RandomState(sum(shape))
+    n = max(3, int(0.02 * np.prod(shape)))
+    pts = np.stack([rs.randint(0, s, size=n) for s in shape], 1)
+    pts[0] = [s - 1 for s in shape]
+    pts[1] = 0
+    occ = np.zeros(shape, dtype=bool)
+    occ[tuple(pts.T)] = True
+    chained = torch.from_numpy(occ)[None, None].float()
+    dims = list(shape)
+    for level in range(1, 5):
+        chained = (torch.nn.functional.max_pool3d(chained, 3, 2, 1) > 0).float()
+        dims = [(d - 1) // 2 + 1 for d in dims]
+        assert list(chained.shape[2:]) == dims
+        direct = np.zeros(dims, dtype=bool)
+        up = (1 << level) - 1
+        for p in np.argwhere(occ):
+            cells = [sorted({int(v) >> level, (int(v) + up) >> level}) for v in p]
+            for cz in cells[0]:
+                for cy in cells[1]:
+                    for cx in cells[2]:
+                        if cz < dims[0] and cy < dims[1] and cx < dims[2]:
+                            direct[cz, cy, cx] = True
+        assert np.array_equal(direct, chained[0, 0].numpy() > 0), level
