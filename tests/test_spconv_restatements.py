@@ -137,3 +137,36 @@ def test_active_sets_of_stacked_strided_levels_follow_from_the_base_level_alone(
                         if cz < dims[0] and cy < dims[1] and cx < dims[2]:
                             direct[cz, cy, cx] = True
         assert np.array_equal(direct, chained[0, 0].numpy() > 0), level
+
+
+@pytest.mark.parametrize("shape", [(9, 7, 10), (8, 8, 8), (5, 4, 3)])
+def test_backward_input_of_a_strided_layer_is_a_convolution_with_a_transposed_gather(shape):
+    """What nb_enc_conv16(stride = -2) with a mode-1 weight pack computes — input voxel p takes, under MIRRORED offset k', the output voxel
+    (p - 1 + k') / 2 where that division is exact in all three coordinates, times W[26 - o']^T — against the transpose of the layer's
+    own rulebook (d in[src] += d out[q] . W[o]^T over the pairs of every offset), float64."""
+    idx, _ = _case(11, shape, 50, 3)
+    rs = np.random.RandomState(12)
+    w = rs.randn(3, 3, 3, 3, 5)
+    table = rb._hash_rows(idx)
+    keys, out_shape, pairs = rb.sparse_rulebook(idx, shape)
+    dout = rs.randn(len(keys), 5)
+    want = np.zeros((len(idx), 3))
+    wk = w.reshape(27, 3, 5)
+    for o, pr in enumerate(pairs):
+        if len(pr):
+            np.add.at(want, pr[:, 0], dout[pr[:, 1]] @ wk[o].T)
+    out_row = {tuple(k): r for r, k in enumerate(keys.tolist())}
+    got = np.zeros_like(want)
+    for (b, z, y, x), src in table.items():
+        for o2 in range(27):
+            k2 = (o2 // 9, (o2 // 3) % 3, o2 % 3)
+            t = (z - 1 + k2[0], y - 1 + k2[1], x - 1 + k2[2])
+            if any(v < 0 or v % 2 for v in t):
+                continue
+            u = tuple(v // 2 for v in t)
+            if any(u[a] >= out_shape[a] for a in range(3)) or (b,) + u not in out_row:
+                continue
+            got[src] += dout[out_row[(b,) + u]] @ wk[26 - o2].T
+    rows = sorted(set(table.values()))  # (duplicates: the rows that lost receive nothing in either formulation)
+    assert np.abs(got[rows] - want[rows]).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    assert np.abs(want[rows]).max() > 0
