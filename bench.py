@@ -101,10 +101,14 @@ def build_poses(dev, body, bd, H, W, n_poses=N_POSES):
 
 
 # The last sample of a ray has the interval 1e10 (raw2outputs, nerf_net_utils.py:28): alpha_last is 0 or 1 by the SIGN of its
-# density, so a ray whose last density is within the arithmetic's own density error of zero can flip: its colour then moves by
-# T_last * c_last (the transmittance that reaches the last sample times that sample's colour), whatever arithmetic marched it.
-# ILL_SIGMA is the measured density error of the default arithmetic (~3e-4, tools/experiments/last_sample_probe.py) with a
-# margin; rays inside it are reported SEPARATELY, never dropped silently: `linf_all` is the error over every checked ray.
+# density, so a ray whose last density is within an arithmetic's own density error of zero can take the other branch: its colour
+# then moves by up to T_last (the transmittance that reaches the last sample).  Since round 6 the default arithmetic recomputes
+# exactly those densities at fp32 level (nb_march's `ill_scratch`, include/nb_hip.h), so EVERY ray is held to the budget; what
+# remains undecidable is the oracle's own fp32 rounding: |sigma_last| < FP32_SIGMA, where two fp32 evaluations of the reference's
+# formula may disagree on the sign — such a ray (none in 262 144 on the bench view) is bounded by its T_last and reported.
+# ILL_SIGMA (the measured density error of the default arithmetic, ~3e-4, tools/experiments/last_sample_probe.py, with a margin)
+# is kept for reporting: `n_ill` / `ill` list the rays inside it with the error actually measured.
+FP32_SIGMA = 2e-5
 ILL_SIGMA = 5e-4
 ILL_MAX_FRACTION = 0.005
 
@@ -161,12 +165,22 @@ def parity_check(sd, net, rend, batch, n_samples, n_check=4096, chunk=16384, lis
            "rays_over_1e-5": int((err > 1e-5).sum()), "rays_over_5e-5": int((err > 5e-5).sum())}
     flipped = ill & (err > 1e-4)
     res["n_flipped"] = int(flipped.sum())  # ill-conditioned rays whose last alpha took the other branch than the oracle's
-    # Pass rule ("Known deviation: the last sample's sign"; measured on every ray of a view:
-    # profiles/r05_fullview_parity.json — 262 143 of 262 144 rays within 8.3e-6, ONE of the 6 ill-conditioned rays flipped, by 0.103 <=
-    # its T_last 0.133): every well-conditioned ray inside the budget, the ill-conditioned ones few and each inside its own flip bound
-    res["ok"] = bool(res["linf"] <= 1e-4 and res["n_ill"] <= max(1, ILL_MAX_FRACTION * n_check) and
-                     bool(((err <= t_last + 1e-4) | ~ill).all()))
+    fix = getattr(rend, "last_ill", None)
+    if fix is not None:  # the march's last-sample fix-up: rays it listed / rays whose last alpha it moved to the other branch
+        listed, changed = fix[:2].tolist()
+        res["fixup"] = {"listed": int(listed), "changed_side": int(changed), "sigma_band": _ill_consts()[0], "t_min": _ill_consts()[1]}
+    # Pass rule: EVERY ray inside the 1e-4 budget.  The only exception is a ray whose last density the oracle itself cannot sign
+    # (|sigma_last| < FP32_SIGMA: fp32 rounding of the reference's own formula); it must stay inside its flip bound T_last.
+    und = sigma_last.abs() < FP32_SIGMA
+    res["n_undecidable"] = int(und.sum())
+    res["ok"] = bool((float(err[~und].max()) if bool((~und).any()) else 0.0) <= 1e-4 and bool(((err <= t_last + 1e-4) | ~und).all()))
     return res
+
+
+def _ill_consts():
+    from neuralbody_amd import _lib
+
+    return _lib.ILL_SIGMA, _lib.ILL_T_MIN
 
 
 def parity_linf(sd, net, rend, batch, n_samples, n_check=4096):

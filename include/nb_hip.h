@@ -30,7 +30,7 @@ extern "C" {
 #define NB_ELAUNCH (-2) /* HIP launch / runtime error */
 #define NB_ENODEV (-3)  /* no gfx950 device */
 
-#define NB_ABI_VERSION 19
+#define NB_ABI_VERSION 20
 
 /* arithmetic of the decoder (nb_decode_points / nb_march `precision` argument) */
 #define NB_PREC_F32 0   /* exact fp32 on v_mfma_f32_32x32x2_f32, trilinear gather of the dense volumes on the VALU: the reference's
@@ -212,12 +212,33 @@ typedef struct nb_cull {
  *   cull    HOST pointer to an nb_cull (whose msk / cam / snap members are DEVICE pointers) or NULL (no culling)
  *   outputs dev: rgb_map [n_rays,3], disp_map/acc_map/depth_map [n_rays],
  *           weights [n_rays,n_samples]; raw (optional, may be NULL) [n_rays,n_samples,4]
+ *   ill_scratch dev, ill_scratch_bytes = NB_ILL_SCRATCH_BYTES(cap) for a list of `cap` >= 1 rays (16-byte aligned), or NULL / 0;
+ *           NB_PREC_F16F6 only (NB_PREC_F32 ignores it).  The reference
+ *           gives a ray's LAST sample the interval 1e10 (nerf_net_utils.py:28), so that sample's alpha is a step function of the SIGN
+ *           of its density; NB_PREC_F16F6's density error (~3e-4 absolute on the bench scene) can put a ray whose last density is
+ *           that close to zero on the other side of the step (~4e-6 of the rays, each off by up to its remaining transmittance).  With
+ *           the scratch the march LISTS every ray whose last density is within NB_ILL_SIGMA of zero while its transmittance in front
+ *           of that sample exceeds NB_ILL_T_MIN (state in front of the sample + the sample's colour logits, <= cap rays), and a
+ *           second small kernel on the same stream recomputes that one density per listed ray at fp32 level (fc_0 through the folded
+ *           planes' head + remainder pairs, fc_1 / fc_2 / alpha_fc from the fp32 section of `packed`, fp64 accumulation), composites
+ *           the last sample again and rewrites the ray's rgb / disp / acc / depth, weights[n_samples - 1] and raw[n_samples - 1][3].
+ *           No host read-back.  Afterwards the scratch starts with int32 {rays listed (may exceed cap: the excess keeps the
+ *           march's result), rays whose step changed side}.  The call zeroes that header itself.  NULL: the march's result as is.
+ *           The bench view lists ~50 of its 262 144 rays (~10 us); a cap of a few thousand covers any trained scene, whose empty
+ *           space has a strongly negative density — only a decoder whose density is ~0 over whole regions lists rays by the
+ *           thousand (12 533 listed rays: +0.5 ms), which is what the cap bounds.
  * ------------------------------------------------------------------------------- */
+#define NB_ILL_SIGMA 4e-3f  /* > 10 x the measured density error of NB_PREC_F16F6 on the bench scene (alpha_fc weights x 50) */
+#define NB_ILL_T_MIN 1e-6f  /* a last sample in front of which less transmittance is left cannot move the ray by more */
+#define NB_ILL_HEADER_FLOATS 16
+#define NB_ILL_RECORD_FLOATS 16
+#define NB_ILL_FIXUP_BLOCKS 1024
+#define NB_ILL_SCRATCH_BYTES(cap) (4 * ((int64_t)NB_ILL_HEADER_FLOATS + (int64_t)(cap) * NB_ILL_RECORD_FLOATS))
 int nb_march(const nb_scene *scene, const float *packed, const float *latent_bias,
              const float *ray_o, const float *ray_d, const float *near, const float *far,
              int64_t n_rays, int32_t n_samples, const float *t_vals, const float *t_rand,
              const int32_t *ray_order, int64_t n_slots, const nb_cull *cull, int white_bkgd, float *rgb_map, float *disp_map, float *acc_map, float *weights,
-             float *depth_map, float *raw, int precision, void *stream);
+             float *depth_map, float *raw, void *ill_scratch, int64_t ill_scratch_bytes, int precision, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * nb_composite — raw2outputs alone (lib/networks/renderer/nerf_net_utils.py:6-51) for

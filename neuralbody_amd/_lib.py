@@ -9,10 +9,18 @@ LIB_PATH = os.environ.get("NB_LIB_PATH") or os.path.join(HERE, "lib", "libnb_hip
 HEADER = os.path.join(os.path.dirname(HERE), "include", "nb_hip.h")
 
 NB_N_LEVELS = 4
-ABI_VERSION = 19
+ABI_VERSION = 20
 SLOT_DEAD = -2147483648  # NB_SLOT_DEAD
 PRECISIONS = {"f32": 0, "f16f6": 1}
 PACK_SECTIONS = {"f32": 1, "f16f6": 2}
+ILL_SIGMA, ILL_T_MIN = 4e-3, 1e-6  # NB_ILL_SIGMA, NB_ILL_T_MIN
+
+
+def ill_scratch_bytes(cap):
+    """NB_ILL_SCRATCH_BYTES(cap): header + `cap` records of the march's last-sample fix-up list."""
+    return 4 * (16 + int(cap) * 16)
+
+
 
 
 class NbFold(C.Structure):
@@ -72,7 +80,7 @@ SIGNATURES = {
     "nb_sparsify": (C.c_int, [_P, _I32x3, _I32, _P, _P, _P, _I32, _P, _P]),
     "nb_decode_points": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _I64, C.c_int, _P, _P, C.c_int, _P]),
     "nb_march": (C.c_int, [C.POINTER(NbScene), _P, _P, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, C.POINTER(NbCull), C.c_int,
-                           _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+                           _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int, _P]),
     "nb_composite": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P, _P]),
     "nb_composite_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.c_int, _P, _P, _P, _P, _P]),
     "nb_sgemm": (C.c_int, [C.c_int, C.c_int, _I32, _I32, _I32, C.c_float, _P, _I32, _P, _I32, C.c_float, _P, _I32, _P]),

@@ -505,7 +505,8 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
              const float *ray_d, const float *near, const float *far, int64_t n_rays, int32_t n_samples,
              const float *t_vals, const float *t_rand, const int32_t *ray_order, int64_t n_slots, const nb_cull *cull, int white_bkgd,
              float *rgb_map, float *disp_map,
-             float *acc_map, float *weights, float *depth_map, float *raw, int precision, void *stream) {
+             float *acc_map, float *weights, float *depth_map, float *raw, void *ill_scratch, int64_t ill_scratch_bytes, int precision,
+             void *stream) {
     NB_REQUIRE(scene && packed && latent_bias, "nb_march: NULL scene / weights");
     NB_REQUIRE(n_rays >= 0 && n_samples >= 1, "nb_march: n_rays = %lld, n_samples = %d", (long long)n_rays, n_samples);
     if (n_rays == 0) return NB_OK;
@@ -524,6 +525,13 @@ int nb_march(const nb_scene *scene, const float *packed, const float *latent_bia
     NB_REQUIRE(precision == NB_PREC_F32 || precision == NB_PREC_F16F6, "nb_march: precision %d", precision);
     if (precision == NB_PREC_F16F6) {
         if (int rc = fill_fold(scene, &a.fold)) return rc;
+        if (ill_scratch) {
+            const long long cap = (ill_scratch_bytes - NB_ILL_SCRATCH_BYTES(0)) / (4 * NB_ILL_RECORD_FLOATS);
+            NB_REQUIRE(((uintptr_t)ill_scratch & 15) == 0 && cap >= 1, "nb_march: ill_scratch must be 16-byte aligned and hold >= 1 record (%lld bytes given)",
+                       (long long)ill_scratch_bytes);
+            a.ill = static_cast<float *>(ill_scratch);
+            a.ill_cap = (int)(cap < (1 << 24) ? cap : (1 << 24));
+        }
         return nbm::launch_march_fold(a, fold_stream_off(), (hipStream_t)stream);
     }
     for (int l = 0; l < 4; ++l) NB_REQUIRE(scene->vol[l] != nullptr, "nb_march: NB_PREC_F32 reads nb_scene.vol[%d]", l);

@@ -160,6 +160,9 @@ struct MarchArgs {
     float *raw_out, *dbg;
     long long n_pts;
     int n_wave_groups;
+    // last-sample fix-up of NB_PREC_F16F6 (nb_hip.h, nb_march `ill_scratch`): header + records, NULL = none
+    float *ill;
+    int ill_cap;  // records the scratch holds
 };
 
 // ---------------------------------------------------------------- positional encoding

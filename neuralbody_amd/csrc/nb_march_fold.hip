@@ -763,6 +763,33 @@ __device__ __forceinline__ float head_sum(const char *actz, int off, float bias)
     const f32x4 p = *reinterpret_cast<const f32x4 *>(actz + off);
     return ((p.x + p.y) + (p.z + p.w)) + bias;
 }
+// The LAST sample's interval is 1e10 (nerf_net_utils.py:28): its alpha is a step function of the sign of its density, and this
+// arithmetic's density error (~3e-4 absolute on the bench scene) can put a ray on the other side of the step.  A ray whose last
+// density is within NB_ILL_SIGMA of zero while it still carries transmittance is therefore LISTED — its state in front of the
+// sample, the sample's colour logits — and nb_march_fixup_kernel recomputes that one density at fp32 level and composites the
+// sample again (same stream, no host involved).  ~1e-5 of the rays; a culled sample has density 0 by definition and is not listed.
+// Called in front of the last step's composite_step (the ray record still holds the state in front of the sample), once per ray.
+__device__ __noinline__ void list_ill_ray(const char *actz, const float *pk, float *ill, int cap, int sample, int part, float z_step, int ray) {
+    const float *recf = reinterpret_cast<const float *>(actz + RAY_OFF) + sample * RAY_FLOATS;
+    const f32x4 c0 = *reinterpret_cast<const f32x4 *>(recf + 12);  // T r g b
+    const float sigma_raw = head_sum(actz, SCR_A + sample * 16, pk[P_AB]);
+    const bool hit = ray >= 0 && fabsf(sigma_raw) < NB_ILL_SIGMA && c0.x > NB_ILL_T_MIN;
+    if (__builtin_amdgcn_ballot_w64(hit) == 0ull) return;
+    int slot = -1;
+    if (hit && part == 0) slot = atomicAdd(reinterpret_cast<int *>(ill), 1);
+    slot = __builtin_amdgcn_ds_bpermute((sample & 15) << 2, slot);  // from the sample's part-0 lane
+    if (!hit || slot >= cap) return;
+    float *irec = ill + NB_ILL_HEADER_FLOATS + (long long)slot * NB_ILL_RECORD_FLOATS;
+    if (part == 0) {
+        *reinterpret_cast<f32x4 *>(irec) = f32x4{__int_as_float(ray), c0.x, recf[16], recf[17]};
+        *reinterpret_cast<f32x4 *>(irec + 4) = f32x4{z_step, __fmul_rn(1e10f, recf[11]), sigma_raw, 0.f};
+    } else {
+        const int ch = part - 1;
+        irec[8 + ch] = part == 1 ? c0.y : (part == 2 ? c0.z : c0.w);
+        irec[12 + ch] = head_sum(actz, SCR_C + (ch * 64 + sample) * 16, pk[P_RB + ch]);
+    }
+}
+
 __device__ __forceinline__ void composite_step(char *actz, const float *pk, int sample, int part, float z_step, float z_after, bool last,
                                                const MarchArgs &a, long long ray, int sidx, int S, bool valid, WeightStore4 &wstore, bool ins) {
     float *recf = reinterpret_cast<float *>(actz + RAY_OFF) + sample * RAY_FLOATS;
@@ -1190,6 +1217,8 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
                     }
                 }
             } else {
+                if (s + 1 >= S && a.ill != nullptr)  // uniform
+                    list_ill_ray(actz, pk, a.ill, a.ill_cap, sample, part, z_cur, (valid && (!CULL || ins_cur)) ? (int)ray : -1);
                 composite_step(actz, pk, sample, part, z_cur, z_next, s + 1 >= S, a, ray, s, S, valid, wstore, !CULL || ins_cur);
             }
         }
@@ -1202,6 +1231,110 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
         RayAccum ra;
         ra.T = c0.x; ra.cr = c0.y; ra.cg = c0.z; ra.cb = c0.w; ra.depth = c1.x; ra.accw = c1.y;
         ra.store(a, ray);
+    }
+}
+
+// ---------------------------------------------------------------- last-sample fix-up
+// The rays composite_step listed (their last density within NB_ILL_SIGMA of zero): one workgroup per record recomputes that ONE
+// density at fp32 level — fc_0 through the same folded planes (head + remainder = 22 bits of fc_0 . V, trilinear weights in fp32,
+// fp64 accumulation), fc_1 / fc_2 / alpha_fc from the fp32 fragments of the packed blob (fp64 accumulation, activations rounded to
+// fp32 between the layers like the reference's) — and composites the last sample again from the listed state, exactly as
+// RayAccum::add / store do.  Thread f owns natural feature f.
+__device__ __forceinline__ int frag_bias_index(int f) {  // natural feature f inside a [tile][hi][16] block (b_pack, nb_march.hip)
+    const int t = f >> 5, i = f & 31;
+    return (t * 2 + ((i >> 2) & 1)) * 16 + (i & 3) + 4 * (i >> 3);
+}
+// row `row` of a 256 x 256 layer stored as fp32 A fragments (a_pack kind 1): the 16 bytes at ((tile * 32 + g) * 64 + hi * 32 + row % 32)
+// hold the weights of input columns 8 g + 4 hi .. + 3 (col_hidden(4 g + i, hi) = 8 g + 4 hi + i)
+__device__ __forceinline__ double frag_row_dot(const float *wfrag, const float *h, int row) {
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(wfrag) + (size_t)(row >> 5) * 32 * 64 + (row & 31);
+    double s = 0.0;
+    for (int g = 0; g < 32; ++g)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const f32x4 w = w4[g * 64 + hi * 32];
+            const float *hh = h + 8 * g + 4 * hi;
+            s = fma((double)w.x, (double)hh[0], s);
+            s = fma((double)w.y, (double)hh[1], s);
+            s = fma((double)w.z, (double)hh[2], s);
+            s = fma((double)w.w, (double)hh[3], s);
+        }
+    return s;
+}
+__global__ __launch_bounds__(256) void nb_march_fixup_kernel(MarchArgs a) {
+    __shared__ float rec[NB_ILL_RECORD_FLOATS];
+    __shared__ float cw[32];
+    __shared__ int crow[32];
+    __shared__ float h[2][256];
+    __shared__ double red[4];
+    const int tid = threadIdx.x;
+    int *hdr = reinterpret_cast<int *>(a.ill);
+    const int n = min(hdr[0], a.ill_cap);
+    const int S = a.n_samples;
+    for (int it = blockIdx.x; it < n; it += gridDim.x) {
+        __syncthreads();
+        if (tid < NB_ILL_RECORD_FLOATS) rec[tid] = a.ill[NB_ILL_HEADER_FLOATS + (long long)it * NB_ILL_RECORD_FLOATS + tid];
+        __syncthreads();
+        const long long ray = __float_as_int(rec[0]);
+        const float z = rec[4];
+        if (tid < 32) {  // (level, corner): weight and U row, with the march's own arithmetic (prep_sequential, wt_build)
+            const int L = tid >> 3, corner = tid & 7;
+            const float px = __fadd_rn(a.ray_o[ray * 3 + 0], __fmul_rn(a.ray_d[ray * 3 + 0], z)),
+                        py = __fadd_rn(a.ray_o[ray * 3 + 1], __fmul_rn(a.ray_d[ray * 3 + 1], z)),
+                        pz = __fadd_rn(a.ray_o[ray * 3 + 2], __fmul_rn(a.ray_d[ray * 3 + 2], z));
+            const GridCoord g = grid_coords(a.sc, px, py, pz);
+            Lvl lv;
+            lv.D = a.sc.dhw[L][0]; lv.H = a.sc.dhw[L][1]; lv.W = a.sc.dhw[L][2];
+            lv.fmx = a.sc.fm1[L][2]; lv.fmy = a.sc.fm1[L][1]; lv.fmz = a.sc.fm1[L][0];
+            lv.fpx = a.sc.fp1[L][2]; lv.fpy = a.sc.fp1[L][1]; lv.fpz = a.sc.fp1[L][0];
+            const LvlIdx q = level_index(lv, g);
+            const float fx = (float)q.x0, fy = (float)q.y0, fz = (float)q.z0;
+            const int dx = corner & 1, dy = (corner >> 1) & 1, dz = corner >> 2;
+            const float wx = dx ? q.ix - fx : (fx + 1.f) - q.ix, wy = dy ? q.iy - fy : (fy + 1.f) - q.iy, wz = dz ? q.iz - fz : (fz + 1.f) - q.iz;
+            const int xx = q.x0 + dx, yy = q.y0 + dy, zz = q.z0 + dz;
+            const bool inb = (unsigned)xx < (unsigned)lv.W && (unsigned)yy < (unsigned)lv.H && (unsigned)zz < (unsigned)lv.D;
+            int row = -1;
+            if (inb) {
+                const int rid = a.fold.grid[L][((size_t)zz * lv.H + yy) * lv.W + xx];
+                if (rid >= 0) row = a.fold.row_base[L] + rid;
+            }
+            cw[tid] = (wx * wy) * wz;
+            crow[tid] = row;
+        }
+        __syncthreads();
+        {
+            double s = (double)a.pk[F_OFF_B0 + frag_bias_index(tid)];
+            for (int c = 0; c < 32; ++c) {
+                if (crow[c] < 0) continue;  // uniform
+                const _Float16 *u = reinterpret_cast<const _Float16 *>(a.fold.urows) + (size_t)crow[c] * 512;
+                s = fma((double)cw[c], (double)(float)u[tid] + (double)(float)u[256 + tid], s);
+            }
+            h[0][tid] = fmaxf((float)s, 0.f);
+        }
+        __syncthreads();
+        h[1][tid] = fmaxf((float)((double)a.pk[F_OFF_B1 + frag_bias_index(tid)] + frag_row_dot(a.pk + F_OFF_B0 + 256, h[0], tid)), 0.f);
+        __syncthreads();
+        const float h3 = fmaxf((float)((double)a.pk[F_OFF_B2 + frag_bias_index(tid)] + frag_row_dot(a.pk + F_OFF_B1 + 256, h[1], tid)), 0.f);
+        {
+            const int t = tid >> 5, i = tid & 31;  // alpha_fc: [hi][q] with column col_hidden(q, hi)
+            double p = (double)a.pk[F_OFF_AW + ((i >> 2) & 1) * 128 + 16 * t + (i & 3) + 4 * (i >> 3)] * (double)h3;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) p += __shfl_xor(p, m);
+            if ((tid & 63) == 0) red[tid >> 6] = p;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const float sigma = (float)(((red[0] + red[1]) + (red[2] + red[3])) + (double)a.pk[F_OFF_AB]);
+            RayAccum ra;
+            ra.T = rec[1]; ra.depth = rec[2]; ra.accw = rec[3];
+            ra.cr = rec[8]; ra.cg = rec[9]; ra.cb = rec[10];
+            const float out4[4] = {rec[12], rec[13], rec[14], sigma};
+            const float w = ra.add(out4, z, rec[5]);
+            ra.store(a, ray);
+            a.weights[ray * S + (S - 1)] = w;
+            if (a.raw) a.raw[(ray * S + (S - 1)) * 4 + 3] = sigma;
+            if ((sigma > 0.f) != (rec[6] > 0.f)) atomicAdd(&hdr[1], 1);  // the march had taken the other branch of the step
+        }
     }
 }
 
@@ -1317,9 +1450,14 @@ int pack_fold_stream(const nb_mlp_params *p, float *packed, long long stream_off
 int launch_march_fold(MarchArgs a, long long stream_off, hipStream_t st) {
     a.n_wave_groups = (int)nb_ceil_div(a.ray_order ? a.n_slots : a.n_rays, 64);
     const char *stream = reinterpret_cast<const char *>(a.pk + stream_off);
+    if (a.ill) NB_REQUIRE(hipMemsetAsync(a.ill, 0, NB_ILL_HEADER_FLOATS * sizeof(float), st) == hipSuccess, "nb_march: hipMemsetAsync(ill_scratch) failed");
     if (a.cull.n_views) hipLaunchKernelGGL((nb_march_fold_kernel<0, true>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     else hipLaunchKernelGGL((nb_march_fold_kernel<0, false>), dim3(a.n_wave_groups), dim3(256), 0, st, a, stream);
     NB_CHECK_LAUNCH("nb_march_fold_kernel");
+    if (a.ill) {
+        hipLaunchKernelGGL(nb_march_fixup_kernel, dim3(NB_ILL_FIXUP_BLOCKS), dim3(256), 0, st, a);
+        NB_CHECK_LAUNCH("nb_march_fixup_kernel");
+    }
     return NB_OK;
 }
 

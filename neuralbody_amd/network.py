@@ -295,6 +295,9 @@ class Network(nn.Module):
         self.precision = precision or os.environ.get("NB_PRECISION", DEFAULT_PRECISION)
         if self.precision not in ("auto", "f32", "f16f6"):
             raise ValueError("precision must be 'auto', 'f32' or 'f16f6'")
+        # 'f16f6': the march lists the rays whose LAST density it cannot sign (the reference's 1e10 interval makes that sample's alpha
+        # a step function, nerf_net_utils.py:28) and recomputes those at fp32 level (include/nb_hip.h, nb_march `ill_scratch`)
+        self.last_sample_fixup = os.environ.get("NB_LAST_SAMPLE_FIXUP", "1") != "0"
         self._auto = None  # (weight key, chosen arithmetic, statistic) of precision 'auto'
         self._lb_cache = None  # (latent_index tensor, versions, bias) of latent_bias()
         self._foreign_fold = None  # (volume tensors + versions, fc_0 key, storage, planes) of volumes that came as a plain list
@@ -589,4 +592,4 @@ class Network(nn.Module):
             self._t_vals[key] = t_vals
         return ops.march(scene, self.packed_weights(prec), lb, ray_o, ray_d, near, far, t_vals, t_rand,
                          white_bkgd=white_bkgd, want_raw=want_raw, precision=prec, ray_order=ray_order,
-                         cull=cull, order_covers_all=order_covers_all)
+                         cull=cull, order_covers_all=order_covers_all, fixup=self.last_sample_fixup)

@@ -17,6 +17,7 @@ TAP = {"F": (0, 352), "h1": (352, 608), "h2": (608, 864), "h3": (864, 1120), "G"
 # bench.py sets this to a list to collect (start, end) HIP events bracketing every nb_march launch on
 # the stream it is enqueued on
 MARCH_EVENTS = None
+FIXUP_CAP = 32768  # rays the march's last-sample fix-up list holds by default (2 MB of scratch; the bench view lists ~50)
 
 
 def _stream():
@@ -246,10 +247,13 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
 
 
 def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=None, white_bkgd=False,
-          want_raw=False, precision="f32", ray_order=None, cull=None, order_covers_all=False):
+          want_raw=False, precision="f32", ray_order=None, cull=None, order_covers_all=False, fixup=True):
     """nb_march: all rays of one batch element -> dict of per-ray outputs.  With a `ray_order` the kernel stores only the rays
     its slots name: unless the caller vouches that every ray has a slot (`order_covers_all`, e.g. the slot list of a fully
-    covered image) the outputs start out as zeros, so a ray without a slot reads 0 and never uninitialised memory."""
+    covered image) the outputs start out as zeros, so a ray without a slot reads 0 and never uninitialised memory.
+    `fixup` (precision 'f16f6'): hand the call the scratch of its last-sample fix-up (include/nb_hip.h, `ill_scratch`) — True:
+    room for min(n, FIXUP_CAP) rays, an int: for that many; the result then carries it as 'ill_scratch' (int32 view: [rays
+    listed, rays whose 1e10-interval step changed side, ...])."""
     sc, _keep = scene
     _req(packed, torch.float32, (mlp_pack_size(),), "packed")
     _req(latent_bias, torch.float32, (int(_lib.lib().nb_mlp_latent_bias_size()),), "latent_bias")
@@ -276,6 +280,10 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
     weights = alloc((n, S), dtype=torch.float32, device=dev)
     depth = alloc((n,), dtype=torch.float32, device=dev)
     raw = alloc((n, S, 4), dtype=torch.float32, device=dev) if want_raw else None
+    ill, ill_bytes = None, 0
+    if fixup and precision == "f16f6" and n > 0:
+        ill_bytes = _lib.ill_scratch_bytes(min(n, FIXUP_CAP) if fixup is True else max(int(fixup), 1))
+        ill = torch.empty(ill_bytes // 4, dtype=torch.int32, device=dev)
     ev = None
     if MARCH_EVENTS is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -284,13 +292,15 @@ def march(scene, packed, latent_bias, ray_o, ray_d, near, far, t_vals, t_rand=No
                               n, S, ptr(t_vals), ptr(t_rand), ptr(ray_order), n_slots,
                               C.byref(cull[0]) if cull is not None else None, 1 if white_bkgd else 0, ptr(rgb), ptr(disp),
                               ptr(acc),
-                              ptr(weights), ptr(depth), ptr(raw), _lib.PRECISIONS[precision], _stream()), "nb_march")
+                              ptr(weights), ptr(depth), ptr(raw), ptr(ill), ill_bytes, _lib.PRECISIONS[precision], _stream()), "nb_march")
     if ev is not None:
         ev[1].record()
         MARCH_EVENTS.append(ev)
     ret = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": weights, "depth_map": depth}
     if want_raw:
         ret["raw"] = raw
+    if ill is not None:
+        ret["ill_scratch"] = ill
     return ret
 
 

@@ -35,22 +35,61 @@ def shard_tile_rows(H, rank, world, tile=TILE):
     return min(b0 * tile, int(H)), min(b1 * tile, int(H))
 
 
-def shard_range_tiled(n, rank, world, H, W, mask=None, tile=TILE):
-    """[begin, end) of the compacted ray list (pixel order) for `rank` such that the range is exactly the rays of whole
-    `tile`-row bands of the H x W image: every 8 x 8 pixel tile of the march then belongs to ONE rank with all of its rays, so the
-    rank marches the same workgroups over the same voxel lists as a single GPU rendering the whole image would — its share of the
-    image is bit-identical to that render (a range that cuts tiles agrees to rounding only: DESIGN.md §3).  `mask` [H*W] (bool /
-    uint8, host or device; None = every pixel has a ray, n == H * W): which pixels carry a ray; its row sums are read back once."""
-    r0, r1 = shard_tile_rows(H, rank, world, tile)
+def band_ray_counts(mask, H, W, tile=TILE):
+    """Cumulative ray count in front of every `tile`-row band of the H x W image: host int64 [bands + 1] (ONE device -> host
+    read-back when the mask lives on the device).  mask [H*W] bool / uint8: which pixels carry a ray."""
+    H, W = int(H), int(W)
+    m = (torch.as_tensor(mask).reshape(H, W) != 0).sum(1).to(torch.int64)  # rays per pixel row
+    bands = (H + tile - 1) // tile
+    if H % tile:
+        m = torch.cat([m, torch.zeros(bands * tile - H, dtype=torch.int64, device=m.device)])
+    per_band = m.view(bands, tile).sum(1).cpu()
+    return torch.cat([torch.zeros(1, dtype=torch.int64), per_band.cumsum(0)])
+
+
+def balanced_band_cuts(cum, world):
+    """Band indices c_0 = 0 <= c_1 <= ... <= c_world = bands that cut the image into `world` runs of whole bands holding as equal
+    a number of RAYS as whole bands allow: c_r = the band border whose cumulative count is nearest to r / world of the total
+    (ties: the earlier border).  A fully covered image gets equal band counts; a partially covered view (mask_at_box: every
+    real test view) gets narrow shares where the subject is and wide ones over the empty top / bottom rows."""
+    import bisect
+
+    cum = [int(v) for v in cum]
+    bands, total = len(cum) - 1, cum[-1]
+    scaled = [c * world for c in cum]  # exact integer comparison of cum[k] / total against r / world
+    cuts = [0]
+    for r in range(1, world):
+        t = total * r
+        i = bisect.bisect_left(scaled, t)  # first border with at least r / world of the rays in front of it
+        k = i if i <= bands and (i == 0 or scaled[i] - t < t - scaled[i - 1]) else i - 1
+        cuts.append(max(min(k, bands), cuts[-1]))
+    return cuts + [bands]
+
+
+def shard_ranges_tiled(n, world, H, W, mask=None, tile=TILE):
+    """The ray range [begin, end) of EVERY rank such that each range is exactly the rays of whole `tile`-row bands of the
+    H x W image: every 8 x 8 pixel tile of the march then belongs to ONE rank with all of its rays, so the rank marches the same
+    workgroups over the same voxel lists as a single GPU rendering the whole image would — its share of the image is
+    bit-identical to that render (a range that cuts tiles agrees to rounding only: DESIGN.md §3).  `mask` [H*W] (bool / uint8,
+    host or device; None = every pixel has a ray, n == H * W): which pixels carry a ray.  With a mask the band borders are
+    chosen so that the ranks hold equal numbers of rays (`balanced_band_cuts`), from ONE read-back of the per-band counts."""
     if mask is None:
         if int(n) != int(H) * int(W):
             raise ValueError("%d rays for a %d x %d image: pass the pixel mask of a partially covered view" % (n, H, W))
-        return r0 * int(W), r1 * int(W)
-    m = torch.as_tensor(mask).reshape(int(H), int(W))
-    rows = torch.cat([torch.zeros(1, dtype=torch.int64), (m != 0).sum(1).to(torch.int64).cpu().cumsum(0)])
-    if int(rows[-1]) != int(n):
-        raise ValueError("the mask holds %d rays, the batch %d" % (int(rows[-1]), n))
-    return int(rows[r0]), int(rows[r1])
+        rows = [shard_tile_rows(H, r, world, tile) for r in range(world)]
+        return [(r0 * int(W), r1 * int(W)) for r0, r1 in rows]
+    cum = band_ray_counts(mask, H, W, tile)
+    if int(cum[-1]) != int(n):
+        raise ValueError("the mask holds %d rays, the batch %d" % (int(cum[-1]), n))
+    cuts = balanced_band_cuts(cum, world)
+    return [(int(cum[cuts[r]]), int(cum[cuts[r + 1]])) for r in range(world)]
+
+
+def shard_range_tiled(n, rank, world, H, W, mask=None, tile=TILE):
+    """One rank's entry of `shard_ranges_tiled` (callers that need every rank's range take the list: one read-back)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad rank/world %d/%d" % (rank, world))
+    return shard_ranges_tiled(n, world, H, W, mask, tile)[rank]
 
 
 def all_gather_tiles(tile, group=None, sizes=None):
@@ -92,15 +131,28 @@ def render_sharded(renderer, batch, group=None, keys=("rgb_map",), prefetched=No
 
 def shard_ranges(renderer, batch, world):
     """The ray range of every rank: whole 8-row tile bands when the renderer knows the image geometry (cfg.H, cfg.W: the march
-    then works in 8 x 8 pixel tiles and a rank's share is bit-identical to the single-GPU render), plain balanced ranges
-    otherwise (ray lists without an image, e.g. training batches)."""
+    then works in 8 x 8 pixel tiles and a rank's share is bit-identical to the single-GPU render; a partially covered view's
+    bands are dealt so that the ranks hold equal numbers of rays), plain balanced ranges otherwise (ray lists without an image,
+    e.g. training batches)."""
     n = batch["ray_o"].shape[1]
     cfg = getattr(renderer, "cfg", None)
     H, W = (getattr(cfg, "H", None), getattr(cfg, "W", None)) if cfg is not None else (None, None)
     mask = batch.get("mask_at_box")
-    if H and W and mask is not None and mask.numel() == int(H) * int(W) and n >= 64:
-        full = n == int(H) * int(W)
-        return [shard_range_tiled(n, r, world, H, W, None if full else mask.reshape(-1)) for r in range(world)]
+    if H and W and mask is not None and mask.numel() == int(H) * int(W) and n >= 1:
+        if n == int(H) * int(W):
+            return shard_ranges_tiled(n, world, H, W, None)
+        # one read-back of the per-band ray counts per mask: kept on the renderer with the mask tensor itself (identity +
+        # version + the caller's frame token, like Renderer._tile_order: the entry holds the tensor, its address cannot be recycled)
+        key = (mask._version, int(world), int(H), int(W), batch.get("frame_token"))
+        c = getattr(renderer, "_shard_cache", None)
+        if c is not None and c[0] is mask and c[1] == key:
+            return list(c[2])
+        ranges = shard_ranges_tiled(n, world, H, W, mask.reshape(-1))
+        try:
+            renderer._shard_cache = (mask, key, ranges)
+        except AttributeError:  # a renderer that takes no attributes
+            pass
+        return list(ranges)
     return [shard_range(n, r, world) for r in range(world)]
 
 

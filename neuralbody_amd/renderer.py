@@ -181,6 +181,9 @@ class Renderer:
                                    far[0, b:e].contiguous(), feature_volume, sp_input, self.cfg.N_samples, t_rand=tr,
                                    white_bkgd=self.cfg.white_bkgd, want_raw=want_raw or noisy, ray_order=ray_order, cull=cull,
                                    order_covers_all=covers)
+        # the scratch of the march's last-sample fix-up ('f16f6'; include/nb_hip.h `ill_scratch`): int32 [0] = rays listed,
+        # [1] = rays whose last alpha changed side — diagnostics for bench.py / the tests, never read back by the product path
+        self.last_ill = ret.pop("ill_scratch", None)
         if noisy:
             # raw_noise_std > 0 (nerf_net_utils.py:31-35; no shipped config): the march delivers `raw`, the noise is added to the
             # densities and the rays are composited again by nb_composite with the z values of the same sampling
@@ -301,7 +304,7 @@ class Renderer:
         beyond rounding: it decides which rays share a workgroup, i.e. a voxel list."""
         H, W = getattr(self.cfg, "H", None), getattr(self.cfg, "W", None)
         mask = batch.get("mask_at_box")
-        if not H or not W or mask is None or mask.numel() != int(H) * int(W) or e - b < 64:
+        if not H or not W or mask is None or mask.numel() != int(H) * int(W) or e <= b:
             return None
         H, W, dev = int(H), int(W), mask.device
         geo = getattr(self, "_slot_pixels", None)

@@ -21,7 +21,7 @@ def test_library_exports_every_header_symbol(lib):
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and include/nb_hip.h drifted"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.nb_abi_version() == _lib.ABI_VERSION == 19
+    assert lib.nb_abi_version() == _lib.ABI_VERSION == 20
 
 
 def test_sizes_and_struct_layout(lib):
@@ -57,10 +57,25 @@ def test_ctypes_structs_match_the_header_compiled_by_gcc(tmp_path):
     assert got == want, (got, want)
 
 
+def test_ill_scratch_constants_match_the_header(tmp_path):
+    """NB_ILL_* of include/nb_hip.h (the last-sample fix-up's scratch) == the numbers _lib.py sizes its buffer by."""
+    import shutil
+    import subprocess
+
+    src = tmp_path / "ill.c"
+    src.write_text('#include <stdio.h>\n#include "nb_hip.h"\nint main(void) { printf("%d %d %.9g %.9g\\n", (int)NB_ILL_SCRATCH_BYTES(1000), '
+                   '(int)NB_ILL_SCRATCH_BYTES(0), (double)NB_ILL_SIGMA, (double)NB_ILL_T_MIN); return 0; }\n')
+    exe = tmp_path / "ill"
+    subprocess.check_call([shutil.which("gcc"), "-I", os.path.dirname(_lib.HEADER), str(src), "-o", str(exe)])
+    got = subprocess.check_output([str(exe)]).split()
+    assert int(got[0]) == _lib.ill_scratch_bytes(1000) and int(got[1]) == _lib.ill_scratch_bytes(0) == 64
+    assert abs(float(got[2]) - _lib.ILL_SIGMA) < 1e-9 and abs(float(got[3]) - _lib.ILL_T_MIN) < 1e-12
+
+
 def test_error_codes_without_touching_a_device(lib):
     # NULL scene -> NB_EINVAL and a message, no crash, no launch
     rc = lib.nb_march(None, None, None, None, None, None, None, 10, 64, None, None, None, 0, None, 0, None, None, None,
-                      None, None, None, 0, None)
+                      None, None, None, None, 0, 0, None)
     assert rc == -1
     assert b"nb_march" in lib.nb_last_error()
     rc = lib.nb_composite(None, None, None, 4, 0, 0, None, None, None, None, None, None)

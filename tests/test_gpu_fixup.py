@@ -1,0 +1,133 @@
+"""The last-sample fix-up of the default arithmetic (nb_march `ill_scratch`, include/nb_hip.h; nerf_net_utils.py:28 gives a ray's
+last sample the interval 1e10, so that sample's alpha is a step function of the sign of its density).
+
+The bench view holds ~6 rays per 262 144 whose last density is within the arithmetic's error of zero; to exercise the fix-up on
+more than a handful the test moves alpha_fc's bias by minus the MEDIAN last density of the view, which puts the densest part of
+the distribution on the step.  Reference: the exact-fp32 kernel on the same volumes (itself held to the oracle and the reference
+fixtures by the other tests)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from neuralbody_amd import _lib, ops
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _render(net, rend, pose, precision, fixup, vols):
+    net.precision = precision
+    net.last_sample_fixup = fixup
+    with torch.no_grad():
+        out = rend.render(pose, want_raw=True, feature_volume=vols)
+    head = None if rend.last_ill is None else rend.last_ill[:2].tolist()
+    return {k: v[0].clone() for k, v in out.items()}, head
+
+
+@pytest.mark.parametrize("size,n_samples", [(512, 64)])
+def test_last_sample_fixup_restores_every_ray(size, n_samples):
+    dev = torch.device(DEV)
+    sd, body, net, rend, bd, n = bench.build_scene(dev, size, size, n_samples, "f32")
+    pose = bench.build_poses(dev, body, bd, size, size, n_poses=2)[1]
+    net.eval()  # one set of volumes for every render below (train-mode statistics are summed with atomics)
+    with torch.no_grad():
+        vols = net.encode_sparse_voxels(rend.prepare_sp_input(pose))
+        first, _ = _render(net, rend, pose, "f32", True, vols)
+        shift = float(first["raw"][:, -1, 3].median())
+        net.alpha_fc.bias -= shift  # the median last density now sits on the step
+    ref, head32 = _render(net, rend, pose, "f32", True, vols)
+    assert head32 is None  # the exact kernel takes no scratch
+    plain, head0 = _render(net, rend, pose, "f16f6", False, vols)
+    assert head0 is None
+    fixed, head = _render(net, rend, pose, "f16f6", True, vols)
+    torch.cuda.synchronize()
+
+    sig_ref = ref["raw"][:, -1, 3]
+    sig_plain = plain["raw"][:, -1, 3]
+    sig_fixed = fixed["raw"][:, -1, 3]
+    t_last = 1.0 - plain["weights"][:, :-1].sum(1)
+    decidable = sig_ref.abs() >= bench.FP32_SIGMA
+
+    def rgb_err(o):
+        return (o["rgb_map"] - ref["rgb_map"]).abs().max(1).values
+
+    e_plain, e_fixed = rgb_err(plain), rgb_err(fixed)
+    n_bad_plain = int((e_plain[decidable] > 1e-4).sum())
+    n_bad_fixed = int((e_fixed[decidable] > H.RGB_TOL).sum())
+    listed_expect = int(((sig_plain.abs() < _lib.ILL_SIGMA) & (t_last > _lib.ILL_T_MIN)).sum())
+    changed_expect = int(((sig_fixed > 0) != (sig_plain > 0)).sum())
+    print("alpha bias shifted by %.3f: %d rays within %.0e of the step; un-fixed f16f6 vs f32: %d rays beyond 1e-4 (worst %.3f); "
+          "fixed: worst %.2e over %d decidable rays, %d listed (expected %d), %d changed side (expected %d)" % (
+              -shift, int((sig_ref.abs() < _lib.ILL_SIGMA).sum()), _lib.ILL_SIGMA, n_bad_plain, float(e_plain.max()),
+              float(e_fixed[decidable].max()), int(decidable.sum()), head[0], listed_expect, head[1], changed_expect))
+    assert n_bad_plain >= 1, "the construction no longer produces a single flipped ray: the test proves nothing"
+    assert n_bad_fixed == 0, "rays beyond tolerance with the fix-up: %d (worst %.3e)" % (n_bad_fixed, float(e_fixed[decidable].max()))
+    # rays the fp32 kernel itself cannot sign stay inside their flip bound
+    und = ~decidable
+    assert bool((e_fixed[und] <= t_last[und] + H.RGB_TOL).all())
+    # the other outputs of the patched rays
+    for k, tol in (("acc_map", 2e-4), ("depth_map", 2e-4), ("weights", 2e-4), ("disp_map", 2e-3)):
+        H.assert_close(fixed[k][decidable].cpu().numpy(), ref[k][decidable].cpu().numpy(), tol, k)
+    # fp32-level densities on the listed rays: the patched raw output agrees with the exact kernel's
+    lst = (sig_plain.abs() < _lib.ILL_SIGMA) & (t_last > 2 * _lib.ILL_T_MIN)
+    assert float((sig_fixed[lst] - sig_ref[lst]).abs().max()) <= 2e-5
+    assert float((sig_plain[lst] - sig_ref[lst]).abs().max()) <= _lib.ILL_SIGMA / 4, "the band is no longer a wide margin over the arithmetic's error"
+    # bookkeeping of the scratch header
+    assert abs(head[0] - listed_expect) <= 2 and head[0] <= ops.FIXUP_CAP  # (T_last is re-derived from the weights here: rays at T_MIN)
+    assert head[1] == changed_expect and head[1] >= n_bad_plain
+    # rays that were not listed are untouched bit for bit
+    untouched = ~((sig_plain.abs() < _lib.ILL_SIGMA) & (t_last > 0.5 * _lib.ILL_T_MIN))
+    assert torch.equal(fixed["rgb_map"][untouched], plain["rgb_map"][untouched])
+
+
+def test_fixup_list_overflow_keeps_the_march_result():
+    """More candidate rays than the list holds: alpha_fc zeroed -> EVERY ray's last density is exactly alpha_fc.bias = 1e-3, inside
+    the band with T_last = 1.  With a list of 1000 rays the first 1000 to arrive are recomputed (to the same value: this density
+    does not depend on the arithmetic), the others keep the march's result; the header counts all of them.  With room for all
+    of them every ray is recomputed — and still comes out the same."""
+    dev = torch.device(DEV)
+    sd, body, net, rend, bd, n = bench.build_scene(dev, 128, 128, 16, "f16f6")
+    net.eval()
+    with torch.no_grad():
+        net.alpha_fc.weight.zero_()
+        net.alpha_fc.bias.fill_(1e-3)
+        vols = net.encode_sparse_voxels(rend.prepare_sp_input(bd))
+    plain, _ = _render(net, rend, bd, "f16f6", False, vols)
+    small, head_small = _render(net, rend, bd, "f16f6", 1000, vols)
+    fixed, head = _render(net, rend, bd, "f16f6", True, vols)
+    torch.cuda.synchronize()
+    assert n == 128 * 128 and head_small == [n, 0] and head == [n, 0]
+    for k in ("rgb_map", "acc_map", "depth_map", "weights", "disp_map", "raw"):
+        assert H.same_result(small[k], plain[k], "f16f6", tol=1e-6), k
+        assert H.same_result(fixed[k], plain[k], "f16f6", tol=1e-6), k
+    assert float(fixed["acc_map"].min()) > 0.99  # sigma 1e-3 over the 1e10 interval: every ray ends opaque
+
+
+def test_fixup_cost_with_thousands_of_listed_rays():
+    """What the list costs when it is long (the median-shifted bench view: ~12.5 k of 262 144 rays listed): the march with and
+    without its fix-up, HIP events.  Informational bound: the fix-up stays below 15 % of the march."""
+    dev = torch.device(DEV)
+    sd, body, net, rend, bd, n = bench.build_scene(dev, 512, 512, 64, "f16f6")
+    net.eval()
+    with torch.no_grad():
+        vols = net.encode_sparse_voxels(rend.prepare_sp_input(bd))
+        first, _ = _render(net, rend, bd, "f16f6", False, vols)
+        net.alpha_fc.bias -= float(first["raw"][:, -1, 3].median())
+    ms = {}
+    for fix in (False, True, False, True):
+        _render(net, rend, bd, "f16f6", fix, vols)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            net.last_sample_fixup = fix
+            with torch.no_grad():
+                rend.render(bd, feature_volume=vols)
+        e1.record()
+        torch.cuda.synchronize()
+        ms[fix] = e0.elapsed_time(e1) / 3
+    listed = int(rend.last_ill[0])
+    print("march of a 512 x 512 x 64 view: %.3f ms, with the fix-up of %d listed rays %.3f ms" % (ms[False], listed, ms[True]))
+    assert listed > 4096 and ms[True] <= 1.15 * ms[False]

@@ -32,9 +32,10 @@ def _check(size, n_samples, n_check, precision):
         ref = orc.render(orc.tensor_state_dict(sd), b, n_samples=n_samples, training=True,
                          feature_volume=[v.detach().float().cpu().contiguous() for v in vols])
     # The last sample of a ray has the interval 1e10 (raw2outputs, nerf_net_utils.py:28): its alpha is 0 or 1 by the SIGN of its
-    # density.  A ray whose last density is within bench.ILL_SIGMA of zero can flip under any arithmetic; it then moves by at
-    # most T_last (the transmittance in front of the last sample).  Such rays are NOT dropped: they must be few, each must stay
-    # inside its own flip bound, and the arithmetics with fp32-class density error must reproduce them like any other ray.
+    # density.  The default arithmetic recomputes the densities it cannot sign at fp32 level (nb_march's `ill_scratch`), so every
+    # ray is held to the SAME tolerance under both arithmetics; only a ray whose last density is within the oracle's own fp32
+    # rounding of zero (bench.FP32_SIGMA) is bounded by T_last (the most a flipped last alpha can move) instead.  Rays within
+    # bench.ILL_SIGMA of the step are counted and printed: they must be few.
     sigma_last = ref["raw"][0].reshape(n_check, n_samples, 4)[:, -1, 3]
     t_last = (1.0 - ref["weights"][0][:, :-1].sum(1)).numpy()
     ok = (sigma_last.abs() >= bench.ILL_SIGMA)
@@ -44,7 +45,7 @@ def _check(size, n_samples, n_check, precision):
     okn = ok.numpy()
     all_err = np.abs(out["rgb_map"][0, sel.to(dev)].cpu().numpy() - ref["rgb_map"][0].numpy()).max(1)
     for i in np.nonzero(~okn)[0]:
-        bound = H.RGB_TOL if precision == "f32" and abs(float(sigma_last[i])) > 2e-5 else float(t_last[i]) + H.RGB_TOL
+        bound = H.RGB_TOL if abs(float(sigma_last[i])) > bench.FP32_SIGMA else float(t_last[i]) + H.RGB_TOL
         assert all_err[i] <= bound, "ill-conditioned ray %d: err %.3e > %.3e (sigma_last %.2e, T_last %.2e)" % (
             i, all_err[i], bound, float(sigma_last[i]), t_last[i])
     err = H.assert_close(out["rgb_map"][0, seld].cpu().numpy(), ref["rgb_map"][0].numpy()[okn], H.RGB_TOL, "rgb_map", rel=False)

@@ -104,13 +104,15 @@ def _worker_tiled(rank, world, port, H, W, covered, out_dir):
         b, e = ren.seen
         full = FakeRenderer().render(batch)
         assert torch.equal(got["rgb_map"], full["rgb_map"]) and torch.equal(got["acc_map"], full["acc_map"])
-        # the range is the rays of whole 8-row bands: its first / last ray sit on band borders of the pixel grid
+        # the range is the rays of whole 8-row bands: it starts with the first ray of a band and ends with the last ray of one
         pix = torch.nonzero(mask).reshape(-1)
-        r0, r1 = parallel.shard_tile_rows(H, rank, world)
-        assert (r0 % 8 == 0 or r0 == H) and (r1 % 8 == 0 or r1 == H)
+        band = torch.div(pix, 8 * W, rounding_mode="floor")
         if e > b:
-            assert int(pix[b]) // W >= r0 and int(pix[e - 1]) // W < r1
-        assert b == int((pix < r0 * W).sum()) and e == int((pix < r1 * W).sum())
+            assert b == 0 or int(band[b - 1]) < int(band[b])
+            assert e == n or int(band[e - 1]) < int(band[e])
+        if covered:
+            r0, r1 = parallel.shard_tile_rows(H, rank, world)
+            assert (b, e) == (r0 * W, r1 * W)
         np.save(os.path.join(out_dir, "ok_%d.npy" % rank), np.array([b, e]))
     finally:
         dist.destroy_process_group()
@@ -124,6 +126,32 @@ def test_tile_aligned_sharding_gloo(tmp_path, world, H, W, covered):
     mp.spawn(_worker_tiled, args=(world, port, H, W, covered, str(tmp_path)), nprocs=world, join=True)
     ranges = [np.load(tmp_path / ("ok_%d.npy" % r)) for r in range(world)]
     assert ranges[0][0] == 0 and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+
+
+def test_partially_covered_view_is_split_by_rays_not_by_rows():
+    """a mask_at_box view (the subject in the middle third of the rows) — equal band counts would give the outer ranks
+    nothing and the middle ranks everything; the cuts follow the cumulative ray count instead, still on band borders."""
+    H, W, world = 256, 64, 8
+    mask = torch.zeros(H, W, dtype=torch.bool)
+    mask[88:168, 10:50] = True  # 80 rows x 40 pixels = 3200 rays in rows 88..167 (bands 11..20)
+    n = int(mask.sum())
+    ranges = parallel.shard_ranges_tiled(n, world, H, W, mask.reshape(-1))
+    assert ranges[0][0] == 0 and ranges[-1][1] == n and all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+    sizes = [e - b for b, e in ranges]
+    assert max(sizes) <= 2 * 320 and min(sizes) >= 320  # 10 bands of 320 rays over 8 ranks: one or two bands each
+    assert all(b % 320 == 0 and e % 320 == 0 for b, e in ranges)  # whole bands
+    rows_only = [parallel.shard_tile_rows(H, r, world) for r in range(world)]  # what round 5 did: ranks 0, 1, 6, 7 got no ray at all
+    assert sum(int(mask[r0:r1].sum()) == 0 for r0, r1 in rows_only) >= 4
+    assert parallel.shard_range_tiled(n, 3, world, H, W, mask.reshape(-1)) == ranges[3]
+    # the cuts are the nearest band borders to r / world of the rays; one read-back serves every rank
+    cum = parallel.band_ray_counts(mask.reshape(-1), H, W)
+    assert cum.tolist()[11] == 0 and cum.tolist()[21] == n and len(cum) == H // 8 + 1
+    assert parallel.balanced_band_cuts([0, 10, 10, 10, 20], 2) == [0, 1, 4]  # ties go to the earlier border
+    assert parallel.balanced_band_cuts([0, 0, 0], 4) == [0, 0, 0, 0, 2]  # an empty view: the bands go to the last rank, which holds no ray either
+    # an image height that is not a multiple of the band height
+    m2 = torch.ones(20, 16, dtype=torch.bool)
+    r2 = parallel.shard_ranges_tiled(320, 2, 20, 16, m2.reshape(-1))
+    assert r2 == [(0, 128), (128, 320)]  # borders at 0 / 128 / 256 / 320 rays: 128 is nearest to 160 (tie with none)
 
 
 def test_shard_tile_rows_balance():
