@@ -303,6 +303,8 @@ class Network(nn.Module):
         self._foreign_fold = None  # (volume tensors + versions, fc_0 key, storage, planes) of volumes that came as a plain list
         self._sat_checked = None  # fc_0 weight key whose first fold build had its saturation count read (precision 'auto')
         self._planes_overflow = None  # ... and, if that count was not zero, the key again: 'auto' = 'f32' for these weights
+        self.last_ill = None
+        self._sat_pending = None  # (fc_0 key, counter tensor) of a later frame's planes, read at the next host synchronisation
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
         self.voxel_size = [float(v) for v in voxel_size]
@@ -327,7 +329,7 @@ class Network(nn.Module):
     def __getstate__(self):
         st = dict(self.__dict__)
         st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None, _foreign_fold=None,
-                  _sat_checked=None, _planes_overflow=None)
+                  _sat_checked=None, _planes_overflow=None, _sat_pending=None, last_ill=None)
         return st
 
     def __deepcopy__(self, memo):
@@ -482,10 +484,32 @@ class Network(nn.Module):
     def _auto_checks_planes(self, key, fold):
         """precision 'auto', once per fc_0 version: read the planes' saturation count (one 4-byte read-back); a non-zero count
         means fc_0 . V left the fp16 range somewhere, and this Network takes the exact kernel from here on (with a warning)."""
-        if self.precision != "auto" or self._sat_checked == key:
+        if self.precision != "auto":
+            return
+        if self._sat_checked == key:
+            # a later frame of the same weights: saturation depends on the frame's volumes too, but reading its counter here would
+            # drain the launch queue once per frame.  The counter is parked instead and read where the host waits for the device
+            # anyway (`check_pending_saturation`, called by Renderer at its per-frame out_sh read-back): a frame whose products
+            # leave the fp16 range is marched clamped ONCE, then 'auto' warns and takes 'f32' for these weights.
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(fold[1][1].device))  # the stream that is building these planes (maybe the prefetch one)
+            self._sat_pending = (key, fold[1][1], ev)
             return
         self._sat_checked = key
-        n = int(fold[1][1])
+        self._note_saturation(key, int(fold[1][1]))
+
+    def check_pending_saturation(self):
+        """Read the saturation counter of the last fold planes built since the previous check (one 4-byte read-back; call it
+        where the host synchronises with the device anyway).  Returns the count (0: nothing pending or nothing saturated)."""
+        pend = getattr(self, "_sat_pending", None)
+        if pend is None or self.precision != "auto" or not pend[2].query():  # (planes still being built: look again next time)
+            return 0
+        self._sat_pending = None
+        n = int(pend[1])
+        self._note_saturation(pend[0], n)
+        return n
+
+    def _note_saturation(self, key, n):
         if n:
             import warnings
 
@@ -590,6 +614,10 @@ class Network(nn.Module):
         if t_vals is None:
             t_vals = torch.linspace(0.0, 1.0, steps=int(n_samples)).to(ray_o.device)  # if_clight_renderer.py:13
             self._t_vals[key] = t_vals
-        return ops.march(scene, self.packed_weights(prec), lb, ray_o, ray_d, near, far, t_vals, t_rand,
-                         white_bkgd=white_bkgd, want_raw=want_raw, precision=prec, ray_order=ray_order,
-                         cull=cull, order_covers_all=order_covers_all, fixup=self.last_sample_fixup)
+        ret = ops.march(scene, self.packed_weights(prec), lb, ray_o, ray_d, near, far, t_vals, t_rand,
+                        white_bkgd=white_bkgd, want_raw=want_raw, precision=prec, ray_order=ray_order,
+                        cull=cull, order_covers_all=order_covers_all, fixup=self.last_sample_fixup)
+        # the scratch of the march's last-sample fix-up ('f16f6'; include/nb_hip.h `ill_scratch`): int32 [0] = rays listed,
+        # [1] = rays whose last alpha changed side — diagnostics for bench.py / the tests, never read back by the product path
+        self.last_ill = ret.pop("ill_scratch", None)
+        return ret

@@ -237,6 +237,8 @@ def decode_points(scene, packed, latent_bias, wpts, viewdir=None, density_only=F
         _req(latent_bias, torch.float32, (int(_lib.lib().nb_mlp_latent_bias_size()),), "latent_bias")
     out = torch.empty((n, 1 if density_only else 4), dtype=torch.float32, device=wpts.device)
     dbg = None
+    if debug and density_only:
+        raise ValueError("decode_points: the activation tap (debug) is written by the colour decode only; density_only has none")
     if debug:  # the kernel writes columns [0, 1594) of every point's tap; the six pad columns are cleared (a strided 1.5 MB fill,
         dbg = torch.empty((n, DBG_WIDTH), dtype=torch.float32, device=wpts.device)  # not the 419 MB of a training batch)
         dbg[:, TAP["PE"][1]:].zero_()
@@ -742,6 +744,7 @@ class ZeroArena:
 
     def __init__(self, n_bytes, device):
         self.buf = torch.zeros((int(n_bytes) + 7) // 8, dtype=torch.float64, device=device).view(torch.uint8)
+        self.slack = self.buf.numel() - int(n_bytes)  # rounding of the buffer to whole doubles
         self.off = 0
 
     @staticmethod

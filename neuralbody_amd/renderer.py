@@ -87,6 +87,11 @@ class Renderer:
             return list(c[2])
         out_sh, _ = torch.max(t, dim=0)
         val = out_sh.tolist()
+        # the host has just waited for the device: the moment to look at the previous frame's fold-plane saturation counter
+        # (precision 'auto'; Network._auto_checks_planes parks it instead of draining the queue once per frame)
+        chk = getattr(self.net, "check_pending_saturation", None)
+        if chk is not None and t.is_cuda:
+            chk()
         self._out_sh_cache = (t, (t._version, token), val)
         return list(val)
 
@@ -181,9 +186,7 @@ class Renderer:
                                    far[0, b:e].contiguous(), feature_volume, sp_input, self.cfg.N_samples, t_rand=tr,
                                    white_bkgd=self.cfg.white_bkgd, want_raw=want_raw or noisy, ray_order=ray_order, cull=cull,
                                    order_covers_all=covers)
-        # the scratch of the march's last-sample fix-up ('f16f6'; include/nb_hip.h `ill_scratch`): int32 [0] = rays listed,
-        # [1] = rays whose last alpha changed side — diagnostics for bench.py / the tests, never read back by the product path
-        self.last_ill = ret.pop("ill_scratch", None)
+        self.last_ill = getattr(self.net, "last_ill", None)  # header of the march's last-sample fix-up (diagnostics)
         if noisy:
             # raw_noise_std > 0 (nerf_net_utils.py:31-35; no shipped config): the march delivers `raw`, the noise is added to the
             # densities and the rays are composited again by nb_composite with the z values of the same sampling

@@ -96,6 +96,12 @@ BWD_INPUT_SPLIT = os.environ.get("NB_ENC_SPLIT", "1") != "0"  # backward-input c
 BWD_INPUT_STRIDED = os.environ.get("NB_ENC_SPLIT_STRIDED", "1") != "0"  # ... those of the strided layers too (0: exact-fp32 kernel)
 
 
+def bwd_input_on_pipe(cin, stride):
+    """Does a layer's backward-input product run on the matrix-pipe convolution kernels (which write their result) rather than
+    on the exact-fp32 kernel (which scatters with atomics into a zeroed buffer)?  ONE predicate for the arena plan and the pass."""
+    return bool(BWD_INPUT_SPLIT and cin >= 32 and (stride == 1 or BWD_INPUT_STRIDED))
+
+
 DECODER_ARENA = [((n,), torch.float32) for n in (3, 1, 128, 256, 256, 256, 256, 256)]  # decoder_backward's zeros(), in order
 
 
@@ -114,7 +120,7 @@ def arena_requests(net, ctx):
         cin, cout = int(w.shape[3]), int(w.shape[4])
         req.append(((2 * cout,), torch.float64))
         req.append(((3, 3, 3, cin, cout), torch.float32))
-        if not (BWD_INPUT_SPLIT and rec["stride"] == 1 and cin >= 32):
+        if not bwd_input_on_pipe(cin, rec["stride"]):
             req.append(((max(int(rec["n_in_max"]), 1), cin), torch.float32))
     req.append(((6890, 16), torch.float32))
     req.append((tuple(net.latent.weight.shape), torch.float32))
@@ -149,7 +155,7 @@ def encoder_backward(xyzc_net, ctx, drows_dense, arena=None):
         # TRANSPOSED gather (nb_enc_conv16 with stride = -2: input voxel p takes output voxel (p - 1 + k) / 2 where that divides) —
         # and runs on the forward's matrix-pipe kernels with bf16 head / remainder operands (NB_CONV_BF16; gradients span more
         # binades than an un-scaled fp16 head holds).  The 16-channel layers keep the exact-fp32 kernel.
-        on_pipe = BWD_INPUT_SPLIT and cin >= 32 and (rec["stride"] == 1 or BWD_INPUT_STRIDED)
+        on_pipe = bwd_input_on_pipe(cin, rec["stride"])
         dx_split = None
         take = (lambda shape, dt=torch.float32: arena.take(shape, dt)) if arena is not None else (lambda shape, dt=torch.float32: None)  # noqa: E731
         if BWD_INPUT_SPLIT and cin >= 32:  # (the weight gradient of every >= 32-channel layer takes the planes too)
@@ -257,6 +263,9 @@ class RenderFunction(torch.autograd.Function):
         g.update(ge)
         g["c.weight"] = dcodes
         glat = arena.take(tuple(net.latent.weight.shape)) if arena is not None else torch.zeros_like(net.latent.weight)
+        if arena is not None and arena.off != arena.buf.numel() - arena.slack:
+            raise RuntimeError("backward pass took %d bytes of its zero arena, the plan (arena_requests) holds %d: the plan no longer "
+                               "mirrors the pass" % (arena.off, arena.buf.numel() - arena.slack))
         glat.index_copy_(0, li.reshape(-1)[:1].long(), g.pop("latent.row")[None])
         g["latent.weight"] = glat
         out = []

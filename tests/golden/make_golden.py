@@ -93,6 +93,40 @@ def run_scene(name):
     print(name, "rays", out["rgb_map"].shape[1], "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_bench(tag):
+    """The BENCH scene at the headline size through the unmodified reference: scenes.N_BENCH_RAYS rays spread over pose 1 of the
+    timed cycle, the encoder at the full out_sh (dense stand-in: ~1 min of CPU), train-mode BatchNorm as run.py renders.  The
+    fixture holds the reference's maps for those rays + the last sample's density and the transmittance in front of it."""
+    ns = rh.load()
+    r, sd, body, batch, pick = scenes.build_bench(tag)
+    cfg = ns.cfg
+    cfg.N_samples = r["n_samples"]
+    cfg.white_bkgd = False
+    cfg.perturb = 0.0
+    cfg.raw_noise_std = 0.0
+    net = rh.make_reference_network(sd, train_mode=True)
+    ren = rh.make_reference_renderer(net)
+    tb = rh.torch_batch(batch)
+    with torch.no_grad():
+        out = ren.render(tb)
+        sp_input = ren.prepare_sp_input(tb)
+        vols = net.encode_sparse_voxels(sp_input)
+        wpts, z_vals = ren.get_sampling_points(tb["ray_o"], tb["ray_d"], tb["near"], tb["far"])
+        viewdir = tb["ray_d"] / torch.norm(tb["ray_d"], dim=2, keepdim=True)
+        raw = ren.get_density_color(wpts, viewdir, lambda x, v: net.calculate_density_color(x, v, vols, sp_input))
+    g = {k: v.numpy() for k, v in out.items()}
+    raw = raw.numpy().reshape(len(pick), r["n_samples"], 4)
+    g["sigma_last"] = raw[:, -1, 3]
+    g["t_last"] = 1.0 - g["weights"][0][:, :-1].sum(1)
+    g["pick"] = pick
+    g["input_digest"] = np.array(input_digest(sd, batch))
+    for li, v in enumerate(vols):
+        g["vol%d_nonzero_voxels" % li] = np.array(int((v[0].abs().sum(0) > 0).sum()))
+    path = os.path.join(OUT, "bench_%s.npz" % tag)
+    np.savez_compressed(path, **g)
+    print("bench", tag, "rays", out["rgb_map"].shape[1], "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 def run_raygen():
     """get_rays / get_near_far (if_nerf_data_utils.py:8-21,54-69) and image_rays
     (render_utils.py:120-137) on a non-square camera."""
@@ -331,7 +365,7 @@ def run_trained():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh", "novel", "trained"]
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh", "novel", "trained"] + ["bench:" + t for t in scenes.BENCH]
     for n in names:
         if n == "raygen":
             run_raygen()
@@ -345,5 +379,7 @@ if __name__ == "__main__":
             run_novel()
         elif n in ("mmsk", "msk"):
             run_masked(n)
+        elif n.startswith("bench:"):
+            run_bench(n.split(":", 1)[1])
         else:
             run_scene(n)

@@ -182,3 +182,27 @@ def build_novel():
         cams["T"].append((T.reshape(3, 1) * 1000.0).tolist())
     center = body["world_verts"].mean(0).astype(np.float64)
     return r, body, cams, center
+
+
+# The BENCH scene (bench.build_scene / build_poses: body seed 0, weights seed 0 with 230 frames, the full-coverage camera of pose 1 —
+# the view bench.py's parity leg and tests/test_gpu_fullsize.py check) as a ray-list batch of N_BENCH_RAYS rays spread over the
+# image: what the unmodified reference renders at the headline size (make_golden.run_bench), so that parity AT SIZE is held
+# against the reference itself and not only against the port.
+BENCH_POSE = 1
+N_BENCH_RAYS = 384
+BENCH = {"512x64": dict(size=512, n_samples=64), "1024x128": dict(size=1024, n_samples=128)}
+
+
+def build_bench(tag):
+    """-> (recipe, state_dict_np, body, batch_np of the picked rays, picked ray indices into the H*W rays of the view)"""
+    r = BENCH[tag]
+    H = W = r["size"]
+    sd = syn.make_weights(0, num_train_frame=230)
+    body = syn.make_body(seed=0)
+    i = BENCH_POSE
+    K, R, T = syn.full_coverage_camera(body, H, W, yaw=0.35 + 0.12 * i, pitch=0.1 - 0.03 * i)
+    ray_o, ray_d, near, far, mask = syn.host_image_rays(H, W, K, R, T, body["can_bounds"])
+    assert mask.all()
+    pick = np.linspace(0, H * W - 1, N_BENCH_RAYS).astype(np.int64)
+    batch = syn.make_batch(body, ray_o[pick], ray_d[pick], near[pick], far[pick], np.ones(len(pick), bool))
+    return r, sd, body, batch, pick

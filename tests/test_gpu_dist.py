@@ -100,3 +100,26 @@ def test_bench_under_torch_distributed_run():
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
         assert j["n_gpus"] == 1 and j["scaling"] == scaling and j["value"] > 0 and j["roofline"]["avg_launch_ms"] > 0
+        if scaling == "weak":  # a weak run under a launcher carries the strong leg (one view per step, rays split over the ranks)
+            sl = j["strong_leg"]
+            assert sl["ms_per_step"] > 0 and sl["per_rank"][0]["march_ms"] > 0 and sl["per_rank"][0]["allgather_ms"] > 0
+            assert 0.5 < sl["measured_speedup_vs_one_gpu_view"] < 2.0  # one rank: the same work, plus or minus the launch-thread jitter
+        else:
+            assert "strong_leg" not in j
+
+
+def test_bare_bench_command():
+    """`python bench.py --gpus 1 ...` exactly as the driver types it (no launcher, no RANK in the environment): one process, no
+    process group, the JSON line with roofline and parity objects."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-extras",
+                          "--no-cpu-baseline", "--size", "128"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["value"] > 0 and "per_rank" not in j and "strong_leg" not in j
+    # --gpus 2 on this one-GPU box: refused with a message, not a traceback (the launcher checks the device count first)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "HIP device(s) visible" in out.stderr

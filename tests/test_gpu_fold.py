@@ -219,6 +219,26 @@ def test_planes_that_leave_the_fp16_range_are_counted_and_auto_takes_the_exact_k
     assert H.same_bits(out["rgb_map"], ref["rgb_map"])
 
 
+def test_a_later_frame_that_saturates_is_noticed_at_the_next_host_synchronisation():
+    """saturation depends on the frame's volumes as well as on fc_0, and 'auto' reads the counter only once per weight
+    version (a read-back per frame would drain the launch queue).  A later frame's counter is parked and read where the host waits
+    for the device anyway — the renderer's per-frame out_sh read-back: the frame that saturates is marched clamped once, the next
+    frame warns and runs on the exact kernel."""
+    r, sd, body, net, bd, rend = _small(precision="auto", train=False)
+    with torch.no_grad():
+        rend.render(bd)  # first frame of these weights: counter read, 0
+        assert net.march_precision() == "f16f6" and net._sat_pending is None
+        net.c.weight.mul_(1e6)  # the vertex codes of a "later frame": BatchNorm (eval: running statistics) lets the scale through
+        frame2 = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in bd.items()}  # fresh tensors: a DataLoader's next batch
+        rend.render(frame2)
+        assert net._sat_pending is not None and net.march_precision() == "f16f6"  # parked, not read
+        torch.cuda.synchronize()
+        frame3 = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in bd.items()}
+        with pytest.warns(UserWarning, match="exceed the fp16 range"):
+            rend.render(frame3)  # its out_sh read-back looks at frame 2's counter first
+        assert net.march_precision() == "f32"
+
+
 def test_planes_of_foreign_volumes_are_sized_by_their_rows_and_kept():
     """A plain list of dense volumes: the planes hold as many rows as the volumes have non-zero voxels (not one per
     voxel of the grid), and a second decode of the same tensors reuses them."""

@@ -53,6 +53,25 @@ def test_oracle_render_with_trained_weights_matches_reference_golden(golden_dir)
     assert float(np.abs(params["fc_1.weight"] - base["fc_1.weight"]).max()) > 0.02
 
 
+@pytest.mark.parametrize("tag", ["512x64"])
+def test_oracle_on_the_bench_scene_matches_the_reference_run(tag, golden_dir):
+    """Parity AT SIZE held against the reference itself: 384 rays of the headline 512 x 512 x 64 view (pose 1
+    of bench.py's timed cycle, full out_sh, train-mode BatchNorm) as the unmodified reference renders them
+    (make_golden.py::run_bench) — the oracle that bench.py and tests/test_gpu_fullsize.py check every ray against reproduces
+    them.  (The 1024 x 1024 x 128 fixture is the same scene and encoder through another camera: the GPU test reads it.)"""
+    g = np.load(os.path.join(golden_dir, "bench_%s.npz" % tag))
+    r, sd, body, batch, pick = scenes.build_bench(tag)
+    assert _digest(sd, batch) == str(g["input_digest"]), "seeded inputs drifted from the fixture"
+    assert np.array_equal(pick, g["pick"]) and len(pick) == scenes.N_BENCH_RAYS
+    with torch.no_grad():
+        out = orc.render(orc.tensor_state_dict(sd), batch, n_samples=r["n_samples"], training=True)
+    for k in ("rgb_map", "disp_map", "acc_map", "weights", "depth_map"):
+        _close(out[k].numpy(), g[k], tol=2e-5, name=k)
+    raw = out["raw"][0].reshape(len(pick), r["n_samples"], 4).numpy()
+    _close(raw[:, -1, 3], g["sigma_last"], tol=1e-4, name="sigma_last")  # two fp32 evaluations of a 256-term sum with |terms| ~ 10
+    assert float(g["rgb_map"].max() - g["rgb_map"].min()) > 0.3 and float(np.abs(g["sigma_last"]).min()) > 1e-3
+
+
 @pytest.mark.parametrize("name", list(scenes.SCENES))
 def test_oracle_render_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, "scene_%s.npz" % name))

@@ -180,3 +180,46 @@ def test_shard_range_tiles_exactly():
             assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 0
     with pytest.raises(ValueError):
         parallel.shard_range(10, 2, 2)
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(argv, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, cwd=ROOT, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_launches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver that ran `python bench.py --gpus 1` will type next):
+    the process re-executes itself under torch.distributed.run, two ranks rendezvous on 127.0.0.1 (gloo here: --dry-run runs the
+    launch / barrier / MAX-over-ranks / per-rank bookkeeping with stub steps and no HIP path), rank 0 prints ONE JSON line."""
+    import json
+
+    out = _bench(["--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["dry_run"] is True and j["value"] is None and j["n_gpus"] == 2 and j["backend"] == "gloo"
+    assert [r["rank"] for r in j["per_rank"]] == [0, 1] and [r["march_ms"] for r in j["per_rank"]] == [2.0, 4.0]
+    assert j["ms_per_step"] >= 4.0  # the MAX over the ranks: rank 1's stub step sleeps 4 ms
+    assert "re-executing under torch.distributed.run" in out.stderr
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 64:
+        pytest.skip("a box with 64 devices")
+    out = _bench(["--gpus", "64", "--steps", "1"])
+    assert out.returncode != 0 and "HIP device(s) visible" in out.stderr and "Traceback" not in out.stderr
+
+
+def test_bench_names_a_world_size_mismatch():
+    out = _bench(["--gpus", "2", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                                                "MASTER_PORT": str(_free_port())})
+    assert out.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in out.stderr
