@@ -96,6 +96,53 @@ class FeatureVolumes(Sequence):
         return iter(self.dense())
 
 
+class BatchedFeatureVolumes(Sequence):
+    """`encode_sparse_voxels` of a batch of B > 1 frames: a read-only sequence of four [B,C,D,H,W] tensors like the reference's list
+    (concatenated from the frames' volumes on first access), with `frames[b]` = frame b's own FeatureVolumes, which is what this
+    package's render / decode paths take (no [B, ...] tensor is made for them)."""
+
+    def __init__(self, frames):
+        self.frames = list(frames)
+        self._dense = None
+
+    def dense(self):
+        if self._dense is None:
+            self._dense = [torch.cat([f[l] for f in self.frames], 0) for l in range(4)]
+        return self._dense
+
+    def __len__(self):
+        return 4
+
+    def __getitem__(self, i):
+        return self.dense()[i]
+
+    def __iter__(self):
+        return iter(self.dense())
+
+
+def frame_sp_input(sp_input, b):
+    """The sp_input of batch element b alone (batch_size 1): its rows of `coord` (equal counts per element, as
+    if_clight_renderer.py:33-38 builds them; batch-index column 0), its bounds / R / Th / latent_index, the batch's common out_sh."""
+    B = int(sp_input.get("batch_size", 1))
+    coord = sp_input["coord"]
+    n = coord.shape[0] // B
+    c = coord[b * n:(b + 1) * n]
+    if c.dim() == 2 and c.shape[1] == 4:
+        c = torch.cat([torch.zeros_like(c[:, :1]), c[:, 1:]], dim=1)
+    out = {"coord": c, "out_sh": list(sp_input["out_sh"]), "batch_size": 1}
+    for k in ("bounds", "R", "Th", "latent_index"):
+        if k in sp_input:
+            out[k] = sp_input[k][b:b + 1]
+    return out
+
+
+def frame_volumes(feature_volume, b):
+    """Frame b's volumes out of what encode_sparse_voxels returned for a batch (or out of a plain list of [B,C,D,H,W] tensors)."""
+    if isinstance(feature_volume, BatchedFeatureVolumes):
+        return feature_volume.frames[b]
+    return [v[b:b + 1] for v in feature_volume]
+
+
 class SparseConv3dParam(nn.Module):
     """Holds the weight of one SubMConv3d / SparseConv3d in spconv 1.x layout [kD,kH,kW,Cin,Cout]
     (bias=False).  The convolution itself runs in nb_enc_conv."""
@@ -441,7 +488,8 @@ class Network(nn.Module):
             vols = [v if v.dim() == 4 else ops.volume_as_channels_last(v) for v in feature_volume]
         R, Th, bounds = sp_input["R"], sp_input["Th"], sp_input["bounds"]
         if R.numel() != 9 or bounds.numel() != 6:
-            raise NotImplementedError("batch size 1 only (train.batch_size / test batch are 1 in every shipped config)")
+            raise ValueError("make_scene describes ONE frame: R / Th / bounds of a batch go through frame_sp_input (Renderer.render and "
+                             "calculate_density(_color) loop the batch)")
         out_sh = [int(s) for s in sp_input["out_sh"]]
         fold = self._fold_planes(feature_volume, vols) if precision == "f16f6" else None
         dev = feature_volume.rows[0].device if lazy else vols[0].device
@@ -527,8 +575,16 @@ class Network(nn.Module):
     # ------------------------------------------------------------------ reference API
     def encode_sparse_voxels(self, sp_input, save=None):
         coord = sp_input["coord"]
-        if int(sp_input.get("batch_size", 1)) != 1:
-            raise NotImplementedError("batch size 1 only")
+        B = int(sp_input.get("batch_size", 1))
+        if B != 1:
+            # B > 1 frames = B independent passes (BatchNorm statistics per frame).  The reference itself cannot run this case:
+            # it pairs ONE set of 6890 codes with the B * 6890 coordinates (latent_xyzc.py:35-36), which spconv indexes out of
+            # bounds — so the only defined semantics are its own B = 1 results, frame by frame
+            if save is not None:
+                raise NotImplementedError("the differentiable path encodes one frame per pass (Renderer.render loops the batch)")
+            if coord.dim() != 2 or coord.shape[0] % B:
+                raise ValueError("encode_sparse_voxels: coord %s does not hold equal row counts for %d frames" % (tuple(coord.shape), B))
+            return BatchedFeatureVolumes([self.encode_sparse_voxels(frame_sp_input(sp_input, b)) for b in range(B)])
         c3 = sp_input.get("_coord_dhw")  # Renderer.prepare_sp_input: the [n, 3] tensor the [n, 4] one was built from
         if c3 is not None and c3.dim() == 2 and c3.shape == (coord.shape[0], 3) and c3.dtype == torch.int32 and c3.is_contiguous():
             coord = c3
@@ -582,13 +638,17 @@ class Network(nn.Module):
         return ops.decode_points(scene, packed, lb, p, v, density_only=density_only, precision=prec)
 
     def calculate_density(self, wpts, feature_volume, sp_input):
-        if wpts.shape[0] != 1:
-            raise NotImplementedError("batch size 1 only")
+        B = wpts.shape[0]
+        if B != 1:  # frame by frame: every element has its own volumes, pose and bounds
+            return torch.cat([self.calculate_density(wpts[b:b + 1], frame_volumes(feature_volume, b), frame_sp_input(dict(sp_input, batch_size=B), b))
+                              for b in range(B)], 0)
         return self._decode(wpts, None, feature_volume, sp_input, True).view(1, -1, 1)
 
     def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
-        if wpts.shape[0] != 1:
-            raise NotImplementedError("batch size 1 only")
+        B = wpts.shape[0]
+        if B != 1:
+            return torch.cat([self.calculate_density_color(wpts[b:b + 1], viewdir[b:b + 1], frame_volumes(feature_volume, b),
+                                                           frame_sp_input(dict(sp_input, batch_size=B), b)) for b in range(B)], 0)
         return self._decode(wpts, viewdir, feature_volume, sp_input, False).view(1, -1, 4)
 
     def forward(self, sp_input, grid_coords, viewdir, light_pts):

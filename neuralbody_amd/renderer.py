@@ -139,10 +139,7 @@ class Renderer:
         ray_o, ray_d, near, far = batch["ray_o"], batch["ray_d"], batch["near"], batch["far"]
         n_batch, n_pixel = ray_o.shape[:2]
         if n_batch != 1:
-            raise NotImplementedError(
-                "batch size 1 only: the reference's own Network pairs ONE set of 6890 vertex codes with the coordinates of the "
-                "whole batch (latent_xyzc.py:35-36: features [6890, 16], indices [B * 6890, 4]), which spconv rejects for B > 1 — "
-                "every shipped config renders and trains with batch size 1")
+            return self._render_frames(batch, n_batch, t_rand, want_raw, ray_range, feature_volume, raw_noise)
         if torch.is_grad_enabled() and ray_range is None and any(p.requires_grad for p in self.net.parameters()):
             # training step (lib/train/trainers/if_nerf_clight.py:18-36): differentiable HIP path
             from . import training
@@ -197,6 +194,24 @@ class Renderer:
             ret = {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": weights, "depth_map": depth,
                    **({"raw": raw} if want_raw else {})}
         return {k: v[None] for k, v in ret.items()}
+
+    def _render_frames(self, batch, n_batch, t_rand, want_raw, ray_range, feature_volume, raw_noise):
+        """A batch of B > 1 frames (lib/config/config.py:81 defaults train.batch_size to 4; every shipped YAML sets 1): B renders of
+        one frame each — differentiable or not — stacked along the batch dimension.  The reference itself cannot run this case (its
+        Network pairs ONE set of 6890 vertex codes with the B * 6890 coordinates of the batch, latent_xyzc.py:35-36, which spconv
+        indexes out of bounds), so the semantics are its own B = 1 results frame by frame, with the batch's common out_sh
+        (if_clight_renderer.py:40-41: the maximum over the batch) — BatchNorm statistics are per frame."""
+        from .network import frame_volumes
+
+        out_sh = torch.max(batch["out_sh"], dim=0, keepdim=True)[0]
+        outs = []
+        for b in range(n_batch):
+            sub = {k: (v[b:b + 1] if isinstance(v, torch.Tensor) and v.dim() >= 1 and v.shape[0] == n_batch else v) for k, v in batch.items()}
+            sub["out_sh"] = out_sh
+            fv = None if feature_volume is None else frame_volumes(feature_volume, b)
+            outs.append(self.render(sub, t_rand=None if t_rand is None else t_rand[b:b + 1], want_raw=want_raw, ray_range=ray_range,
+                                    feature_volume=fv, raw_noise=None if raw_noise is None else raw_noise[b:b + 1]))
+        return {k: torch.cat([o[k] for o in outs], 0) for k in outs[0]}
 
     # -- the encoder of the NEXT frame under the march of this one (no counterpart in the reference, whose render() is one
     # synchronous pass: if_clight_renderer.py:94-122)

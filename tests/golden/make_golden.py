@@ -127,6 +127,38 @@ def run_bench(tag):
     print("bench", tag, "rays", out["rgb_map"].shape[1], "->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
 
 
+def run_batch2():
+    """scenes.BATCH2: the reference renderer on each of the two frames (B = 1, the batch's common out_sh), outputs stacked —
+    the B > 1 semantics (the reference itself indexes its 6890 codes out of bounds for B > 1, latent_xyzc.py:35-36)."""
+    ns = rh.load()
+    r, sd, batch, frames = scenes.build_batch2()
+    cfg = ns.cfg
+    cfg.N_samples = r["n_samples"]
+    cfg.white_bkgd = False
+    cfg.perturb = 0.0
+    cfg.raw_noise_std = 0.0
+    outs = []
+    for f in frames:
+        net = rh.make_reference_network(sd, train_mode=True)  # a fresh module per frame: the running statistics start alike
+        ren = rh.make_reference_renderer(net)
+        with torch.no_grad():
+            outs.append(ren.render(rh.torch_batch(f)))
+    g = {k: np.concatenate([o[k].numpy() for o in outs], 0) for k in outs[0]}
+    g["input_digest"] = np.array(input_digest(sd, batch))
+    try:  # what the unmodified reference does with the B = 2 batch itself: recorded, not asserted
+        net = rh.make_reference_network(sd, train_mode=True)
+        with torch.no_grad():
+            rh.make_reference_renderer(net).render(rh.torch_batch(batch))
+        g["reference_runs_b2"] = np.array(True)
+    except Exception as e:  # noqa: BLE001
+        g["reference_runs_b2"] = np.array(False)
+        g["reference_b2_error"] = np.array("%s: %s" % (type(e).__name__, str(e)[:200]))
+        print("the reference on the B = 2 batch itself:", g["reference_b2_error"])
+    path = os.path.join(OUT, "scene_batch2.npz")
+    np.savez_compressed(path, **g)
+    print("batch2 ->", path, "%.0f KB" % (os.path.getsize(path) / 1024))
+
+
 def run_raygen():
     """get_rays / get_near_far (if_nerf_data_utils.py:8-21,54-69) and image_rays
     (render_utils.py:120-137) on a non-square camera."""
@@ -365,7 +397,7 @@ def run_trained():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh", "novel", "trained"] + ["bench:" + t for t in scenes.BENCH]
+    names = sys.argv[1:] or list(scenes.SCENES) + ["raygen", "train", "mmsk", "msk", "mesh", "novel", "trained", "batch2"] + ["bench:" + t for t in scenes.BENCH]
     for n in names:
         if n == "raygen":
             run_raygen()
@@ -379,6 +411,8 @@ if __name__ == "__main__":
             run_novel()
         elif n in ("mmsk", "msk"):
             run_masked(n)
+        elif n == "batch2":
+            run_batch2()
         elif n.startswith("bench:"):
             run_bench(n.split(":", 1)[1])
         else:

@@ -206,3 +206,35 @@ def build_bench(tag):
     pick = np.linspace(0, H * W - 1, N_BENCH_RAYS).astype(np.int64)
     batch = syn.make_batch(body, ray_o[pick], ray_d[pick], near[pick], far[pick], np.ones(len(pick), bool))
     return r, sd, body, batch, pick
+
+
+# A batch of TWO frames (B = 2; lib/config/config.py:81 defaults train.batch_size to 4, every shipped YAML sets 1).  The
+# reference's own Network cannot run B > 1 (latent_xyzc.py:35-36 pairs 6890 feature rows with B * 6890 coordinates), so the
+# defined semantics — and the fixture, make_golden.run_batch2 — are its B = 1 results frame by frame, each frame encoded at the
+# batch's common out_sh (if_clight_renderer.py:40-41: the maximum over the batch).
+BATCH2 = dict(weights_seed=2, num_train_frame=7, n_samples=64, n_rays=256, mode="train", weights_kw=dict(alpha_bias=0.0, alpha_scale=12.0),
+              frames=[dict(body=_SMALL_BODY, cam=_SMALL_CAM, latent_index=3),
+                      dict(body=dict(seed=5, box=(0.25, 0.32, 0.2), rh=(-0.2, 0.1, 0.3), th=(-0.1, 0.15, 0.05)),
+                           cam=dict(H=32, W=32, focal_factor=3.0, distance=1.4), latent_index=5)])
+
+
+def build_batch2():
+    """-> (recipe, state_dict_np, batch_np with leading dimension 2, [per-frame batch_np at the common out_sh])"""
+    r = BATCH2
+    sd = syn.make_weights(r["weights_seed"], num_train_frame=r["num_train_frame"], **r["weights_kw"])
+    frames = []
+    for f in r["frames"]:
+        body = syn.make_body(**f["body"])
+        c = f["cam"]
+        K, R, T = syn.make_camera(body, c["H"], c["W"], focal_factor=c["focal_factor"], distance=c["distance"])
+        ro, rd, near, far, mask = syn.host_image_rays(c["H"], c["W"], K, R, T, body["can_bounds"])
+        assert ro.shape[0] >= r["n_rays"], ro.shape
+        pick = np.linspace(0, ro.shape[0] - 1, r["n_rays"]).astype(np.int64)
+        frames.append(syn.make_batch(body, ro[pick], rd[pick], near[pick], far[pick], np.ones(len(pick), bool),
+                                     latent_index=f["latent_index"]))
+    out_sh = np.max(np.concatenate([f["out_sh"] for f in frames], 0), 0, keepdims=True)
+    assert not all(np.array_equal(f["out_sh"], out_sh) for f in frames), "the frames should differ in out_sh"
+    batch = {k: np.concatenate([f[k] for f in frames], 0) for k in frames[0]}
+    for f in frames:
+        f["out_sh"] = out_sh.copy()
+    return r, sd, batch, frames

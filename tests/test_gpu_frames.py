@@ -15,6 +15,7 @@ import torch
 
 from tests import synthetic as syn
 from tests import helpers as H
+from tests.golden import scenes
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -228,3 +229,70 @@ def test_rays_without_a_slot_read_zero():
     torch.cuda.synchronize()
     assert bool(torch.isfinite(out["rgb_map"]).all()) and float(out["weights"][0, keep:].abs().max()) == 0.0
     assert float(out["rgb_map"][0, :keep].abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("precision", ["f16f6", "f32"])
+def test_a_batch_of_two_frames_matches_the_reference_frame_by_frame(precision):
+    """B = 2 through Renderer.render, prepare_sp_input / encode_sparse_voxels / calculate_density_color: two
+    frames with their own vertices, pose, bounds, latent index and rays, one common out_sh (the batch maximum).  Fixture: the
+    reference run frame by frame (tests/golden/scene_batch2.npz; the reference itself raises on the B = 2 batch)."""
+    import os
+
+    from neuralbody_amd.network import BatchedFeatureVolumes
+
+    g = np.load(os.path.join(H.GOLDEN, "scene_batch2.npz"))
+    r, sd, batch, frames = scenes.build_batch2()
+    net = H.make_network(sd, DEV, True, precision)
+    rend = H.make_renderer(net, dict(n_samples=r["n_samples"], perturb=False, white_bkgd=False))
+    bd = H.device_batch(batch, DEV)
+    with torch.no_grad():
+        out = rend.render(bd)
+        sp = rend.prepare_sp_input(bd)
+        vols = net.encode_sparse_voxels(sp)
+        again = rend.render(bd, feature_volume=vols)  # the batch's volumes handed back in: frame b marches frames[b]
+    torch.cuda.synchronize()
+    assert out["rgb_map"].shape == (2, r["n_rays"], 3) and out["weights"].shape == (2, r["n_rays"], r["n_samples"])
+    err = H.assert_close(out["rgb_map"].cpu().numpy(), g["rgb_map"], H.RGB_TOL, "rgb_map", rel=False)
+    H.assert_close(out["acc_map"].cpu().numpy(), g["acc_map"], 2e-4, "acc_map")
+    H.assert_close(out["weights"].cpu().numpy(), g["weights"], 2e-4, "weights")
+    H.assert_close(out["depth_map"].cpu().numpy(), g["depth_map"], 2e-4, "depth_map")
+    # (train-mode BatchNorm sums its statistics with atomics: a second encode of the same frame agrees to rounding)
+    H.assert_close(again["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 2e-5, "re-render from the batch's volumes")
+    # the reference API on the batch: four [B,C,D,H,W] volumes at the common out_sh, and the point decoder frame by frame
+    assert isinstance(vols, BatchedFeatureVolumes) and sp["batch_size"] == 2
+    D, Hh, W = sp["out_sh"]
+    assert [tuple(v.shape) for v in vols] == [(2, c, D >> (l + 1), Hh >> (l + 1), W >> (l + 1)) for l, c in enumerate((32, 64, 128, 128))]
+    wpts, z = rend.get_sampling_points(bd["ray_o"][:, ::16], bd["ray_d"][:, ::16], bd["near"][:, ::16], bd["far"][:, ::16])
+    viewdir = bd["ray_d"][:, ::16] / torch.norm(bd["ray_d"][:, ::16], dim=2, keepdim=True)
+    with torch.no_grad():
+        raw = rend.get_density_color(wpts, viewdir, lambda x, v: net.calculate_density_color(x, v, vols, sp))
+        dens = net.calculate_density(wpts.reshape(2, -1, 3), vols, sp)
+    assert raw.shape == (2, wpts.shape[1] * r["n_samples"], 4) and dens.shape == (2, wpts.shape[1] * r["n_samples"], 1)
+    assert float((raw[..., 3:] - dens).abs().max()) <= (2e-3 if precision == "f16f6" else 1e-5)
+    pv = rend.get_pixel_value(bd["ray_o"][:, ::16], bd["ray_d"][:, ::16], bd["near"][:, ::16], bd["far"][:, ::16], vols, sp, bd)
+    H.assert_close(pv["rgb_map"].cpu().numpy(), g["rgb_map"][:, ::16], 6e-5, "unfused path on the batch")
+    print("batch of two frames, %s: rgb L-inf vs the reference run frame by frame %.2e" % (precision, err))
+
+
+def test_a_batch_of_two_frames_trains():
+    """The differentiable path on B = 2: the loss over both frames, gradients = the sum of the two single-frame passes."""
+    r, sd, batch, frames = scenes.build_batch2()
+    tgt = torch.rand((2, r["n_rays"], 3), generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def grads(b_np, target):
+        net = H.make_network(sd, DEV, True, "f32")
+        rend = H.make_renderer(net, dict(n_samples=r["n_samples"], perturb=False, white_bkgd=False))
+        out = rend.render(H.device_batch(b_np, DEV))
+        loss = ((out["rgb_map"] - target) ** 2).sum()
+        loss.backward()
+        return float(loss), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    l2, g2 = grads(batch, tgt)
+    l0, g0 = grads(frames[0], tgt[0:1])
+    l1, g1 = grads(frames[1], tgt[1:2])
+    torch.cuda.synchronize()
+    assert abs(l2 - (l0 + l1)) <= 1e-5 * abs(l2)
+    assert set(g2) == set(g0) == set(g1) and len(g2) >= 60
+    for k in g2:
+        scale = float(g2[k].abs().max()) + 1e-30
+        assert float((g2[k] - (g0[k] + g1[k])).abs().max()) <= 2e-4 * scale, k

@@ -72,6 +72,24 @@ def test_oracle_on_the_bench_scene_matches_the_reference_run(tag, golden_dir):
     assert float(g["rgb_map"].max() - g["rgb_map"].min()) > 0.3 and float(np.abs(g["sigma_last"]).min()) > 1e-3
 
 
+def test_oracle_frame_by_frame_matches_the_batch_of_two_fixture(golden_dir):
+    """scenes.BATCH2 (B = 2): the reference renderer run on each frame at the batch's common out_sh (make_golden.run_batch2; the
+    reference itself cannot run the B = 2 batch — the fixture records the exception it raises) against the oracle frame by frame."""
+    g = np.load(os.path.join(golden_dir, "scene_batch2.npz"))
+    r, sd, batch, frames = scenes.build_batch2()
+    assert _digest(sd, batch) == str(g["input_digest"]), "seeded inputs drifted from the fixture"
+    assert not bool(g["reference_runs_b2"])
+    assert batch["ray_o"].shape == (2, r["n_rays"], 3) and not np.array_equal(batch["out_sh"][0], batch["out_sh"][1])
+    sdt = orc.tensor_state_dict(sd)
+    for b, f in enumerate(frames):
+        assert np.array_equal(f["out_sh"][0], batch["out_sh"].max(0))
+        with torch.no_grad():
+            out = orc.render(dict(sdt), f, n_samples=r["n_samples"], training=True)
+        for k in ("rgb_map", "acc_map", "weights", "depth_map"):
+            _close(out[k].numpy(), g[k][b:b + 1], tol=2e-5, name="%s[%d]" % (k, b))
+    assert float(g["acc_map"].mean()) > 0.1
+
+
 @pytest.mark.parametrize("name", list(scenes.SCENES))
 def test_oracle_render_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, "scene_%s.npz" % name))

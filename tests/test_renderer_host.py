@@ -68,7 +68,8 @@ def test_tile_order_of_a_partial_mask_follows_the_mask():
     order = r._tile_order(batch, n, 0, n)
     _check_slots(order, mask, H, W, 0, n)
     assert r._tile_order(batch, n, 0, n) is order          # same tensor object, same version: cached
-    assert r._tile_order(batch, 40, 0, 40) is None         # fewer than 64 rays: list order
+    assert r._tile_order(batch, n, 5, 5) is None           # an empty range (a rank without rays): nothing to order
+    _check_slots(r._tile_order(batch, n, 0, 40), mask, H, W, 0, 40)  # fewer than 64 rays keep their tiles too (a rank's small share)
     _check_slots(r._tile_order(batch, n, 17, 150), mask, H, W, 17, 150)
 
 
@@ -102,25 +103,37 @@ def test_other_encoding_resolutions_are_refused():
         Network(num_train_frame=3, precision="fp8")
 
 
-def test_batch_size_above_one_is_refused_with_the_reason():
-    """The reference's own Network cannot run B > 1 either (latent_xyzc.py:35-36 pairs 6890 feature rows with B * 6890
-    coordinates); our refusal names that line instead of failing somewhere inside the encoder."""
+def test_a_batch_of_frames_is_split_frame_by_frame():
+    """B > 1 (lib/config/config.py:81 defaults train.batch_size to 4; the reference's own Network cannot run it: latent_xyzc.py:35-36
+    pairs 6890 feature rows with B * 6890 coordinates) = B passes of one frame each.  Host side: `frame_sp_input` cuts sp_input as
+    if_clight_renderer.py:29-52 built it back into frames; `BatchedFeatureVolumes` presents the frames' volumes as the reference's
+    list of [B,C,D,H,W] tensors; make_scene describes one frame and says so."""
+    from neuralbody_amd.network import BatchedFeatureVolumes, FeatureVolumes, frame_sp_input, frame_volumes
+
     r = _renderer(8, 8)
-    with torch.no_grad():
-        with pytest.raises(NotImplementedError, match="latent_xyzc.py:35-36"):
-            r.render(_batch(n_batch=2))
-    net = r.net
-    with pytest.raises(NotImplementedError, match="batch size 1 only"):
-        net.encode_sparse_voxels({"coord": torch.zeros(20, 4, dtype=torch.int32), "out_sh": [32, 32, 32], "batch_size": 2})
-    vols = [torch.zeros(1, c, 2, 2, 2) for c in (32, 64, 128, 128)]
-    sp2 = {"R": torch.eye(3)[None].repeat(2, 1, 1), "Th": torch.zeros(2, 1, 3), "bounds": torch.zeros(2, 2, 3), "out_sh": [32, 32, 32],
-           "latent_index": torch.zeros(2, dtype=torch.long)}
-    with pytest.raises(NotImplementedError, match="batch size 1 only"):
-        net.make_scene([v[0].permute(1, 2, 3, 0).contiguous() for v in vols], sp2)
-    sp1 = dict(sp2, R=torch.eye(3)[None], Th=torch.zeros(1, 1, 3), bounds=torch.zeros(1, 2, 3))
-    with pytest.raises(NotImplementedError, match="batch size 1 only"):
-        net.calculate_density(torch.zeros(2, 5, 3), None, sp1) if False else net.calculate_density_color(
-            torch.zeros(2, 5, 3), torch.zeros(2, 5, 3), None, None)
+    B, n = 3, 5
+    coord = torch.arange(B * n * 3, dtype=torch.int32).view(B, n, 3)
+    batch = {"coord": coord, "out_sh": torch.tensor([[8, 16, 8], [16, 8, 8], [8, 8, 8]]), "bounds": torch.arange(B * 6.0).view(B, 2, 3),
+             "R": torch.eye(3)[None].repeat(B, 1, 1) * torch.arange(1.0, B + 1)[:, None, None], "Th": torch.arange(B * 3.0).view(B, 1, 3),
+             "latent_index": torch.arange(B)}
+    sp = r.prepare_sp_input(batch)
+    assert sp["coord"].shape == (B * n, 4) and sp["batch_size"] == B and sp["out_sh"] == [16, 16, 8]
+    for b in range(B):
+        f = frame_sp_input(sp, b)
+        assert f["batch_size"] == 1 and f["out_sh"] == [16, 16, 8]
+        assert torch.equal(f["coord"][:, 1:], coord[b]) and int(f["coord"][:, 0].abs().sum()) == 0
+        assert torch.equal(f["R"], batch["R"][b:b + 1]) and torch.equal(f["Th"], batch["Th"][b:b + 1])
+        assert torch.equal(f["bounds"], batch["bounds"][b:b + 1]) and torch.equal(f["latent_index"], batch["latent_index"][b:b + 1])
+    frames = [FeatureVolumes([torch.full((1, c, 2, 2, 2), float(b)) for c in (32, 64, 128, 128)]) for b in range(B)]
+    fv = BatchedFeatureVolumes(frames)
+    assert len(fv) == 4 and [tuple(v.shape) for v in fv] == [(B, c, 2, 2, 2) for c in (32, 64, 128, 128)]
+    assert float(fv[2][1].mean()) == 1.0 and frame_volumes(fv, 2) is frames[2]
+    plain = list(fv)
+    assert [tuple(v.shape) for v in frame_volumes(plain, 1)] == [(1, c, 2, 2, 2) for c in (32, 64, 128, 128)]
+    with pytest.raises(ValueError, match="ONE frame"):
+        r.net.make_scene([v[0].permute(1, 2, 3, 0).contiguous() for v in frames[0]], sp)
+    with pytest.raises(ValueError, match="equal row counts"):
+        r.net.encode_sparse_voxels({"coord": torch.zeros(21, 4, dtype=torch.int32), "out_sh": [32, 32, 32], "batch_size": 2})
 
 
 def test_the_differentiable_path_refuses_what_it_does_not_differentiate():
