@@ -144,8 +144,6 @@ class Renderer:
             # training step (lib/train/trainers/if_nerf_clight.py:18-36): differentiable HIP path
             from . import training
 
-            if self.cfg.raw_noise_std != 0.0:
-                raise NotImplementedError("raw_noise_std != 0 on the differentiable path (every shipped config trains with 0)")
             if feature_volume is not None or want_raw or self.make_cull(batch) is not None:
                 raise NotImplementedError("the differentiable path renders all samples of the batch from its own encoder pass: "
                                           "feature_volume / want_raw / sample culling are inference-only (wrap the call in "
@@ -153,7 +151,7 @@ class Renderer:
             if self.cfg.perturb > 0.0 and self.net.training and t_rand is None:
                 t_rand = torch.rand((n_batch, n_pixel, self.cfg.N_samples), device=ray_o.device)
             self._queue_behind_prefetch(ray_o.device)
-            ret = training.render_train(self, batch, t_rand)
+            ret = training.render_train(self, batch, t_rand, raw_noise)
             self._mark_inline_encode(ray_o.device)
             return ret
         self._frame_token = batch.get("frame_token")

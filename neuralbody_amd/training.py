@@ -207,7 +207,7 @@ class RenderFunction(torch.autograd.Function):
     backward are both the HIP path; autograd only carries d rgb_map in and the parameter gradients out."""
 
     @staticmethod
-    def forward(ctx, renderer, batch, t_rand, *params):
+    def forward(ctx, renderer, batch, t_rand, raw_noise, *params):
         net, cfg = renderer.net, renderer.cfg
         if not net.training:
             # nb_enc_bn_relu_bwd implements the batch-statistics BatchNorm backward only; in eval() the forward normalises
@@ -227,6 +227,11 @@ class RenderFunction(torch.autograd.Function):
             scene = net.make_scene(vols, sp_input)
             lb = net.latent_bias(sp_input["latent_index"])
             raw, tap = ops.decode_points(scene, net.packed_weights("f32"), lb, w, v, debug=True, precision="f32")
+            if raw_noise is not None:
+                # raw2outputs adds randn * raw_noise_std to the densities in front of the relu (nerf_net_utils.py:31-35): the noisy
+                # densities are what is composited AND what the backward differentiates through (d sigma is unchanged by an addend)
+                raw = raw.clone()
+                raw.view(-1, S, 4)[..., 3] += raw_noise.reshape(-1, S).to(raw) * float(cfg.raw_noise_std)
             z = z_vals.reshape(-1, S).float().contiguous()
             rd = ray_d.reshape(-1, 3).float().contiguous()
             rgb, disp, acc, weights, depth = ops.composite(raw.view(-1, S, 4), z, rd, cfg.white_bkgd)
@@ -273,7 +278,7 @@ class RenderFunction(torch.autograd.Function):
             gr = g.get(name)
             out.append(None if gr is None else gr.reshape(p.shape))
         assert len(out) == ctx.n_params
-        return (None, None, None) + tuple(out)
+        return (None, None, None, None) + tuple(out)
 
 
 # tests/test_gpu_backward.py sets this to a dict to receive the forward's activations (MLP tap, encoder records) so that
@@ -282,8 +287,9 @@ DEBUG_CAPTURE = None
 MAX_TAP_BYTES = 32 * 2 ** 30  # activation tap kept for the backward pass (ops.DBG_WIDTH floats per sample)
 
 
-def render_train(renderer, batch, t_rand=None):
-    """Renderer.render with gradients: same output dict, rgb_map carries the autograd graph."""
+def render_train(renderer, batch, t_rand=None, raw_noise=None):
+    """Renderer.render with gradients: same output dict, rgb_map carries the autograd graph.  raw_noise: standard-normal
+    [B, n_rays, N_samples] used when cfg.raw_noise_std != 0 (drawn here when None)."""
     n_points = batch["ray_o"].shape[1] * renderer.cfg.N_samples
     tap_bytes = n_points * ops.DBG_WIDTH * 4
     if tap_bytes > MAX_TAP_BYTES:
@@ -293,5 +299,10 @@ def render_train(renderer, batch, t_rand=None):
             "(if_nerf_clight.py); full-image inference must run under torch.no_grad() as run.py:66,98 does."
             % (batch["ray_o"].shape[1], renderer.cfg.N_samples, tap_bytes / 2 ** 30, MAX_TAP_BYTES / 2 ** 30))
     params = [p for _, p in renderer.net.named_parameters()]
-    rgb, disp, acc, weights, depth = RenderFunction.apply(renderer, batch, t_rand, *params)
+    if float(renderer.cfg.raw_noise_std) != 0.0:
+        if raw_noise is None:
+            raw_noise = torch.randn((batch["ray_o"].shape[0], batch["ray_o"].shape[1], renderer.cfg.N_samples), device=batch["ray_o"].device)
+    else:
+        raw_noise = None
+    rgb, disp, acc, weights, depth = RenderFunction.apply(renderer, batch, t_rand, raw_noise, *params)
     return {"rgb_map": rgb, "disp_map": disp, "acc_map": acc, "weights": weights, "depth_map": depth}

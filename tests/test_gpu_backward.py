@@ -425,3 +425,56 @@ def test_training_step_matches_reference_fixture():
         worst = max(worst, e1, e2)
         assert e1 <= FIXTURE_TOL and e2 <= FIXTURE_TOL, (name, e1, e2)
     print("training step vs reference fixture: worst relative deviation %.2e over %d tensors" % (worst, len(list(net.parameters()))))
+
+
+def test_training_step_with_raw_noise():
+    """cfg.raw_noise_std != 0 on the differentiable path (nerf_net_utils.py:31-35: sigma + randn * std in front of the relu; no
+    shipped config trains with it): the forward equals the inference path's render with the same noise realisation (itself held
+    to the reference's formula by test_raw_noise_std_matches_the_reference_formula), the gradients flow through the NOISY
+    densities (checked on alpha_fc.bias, which shifts every density alike, against a central difference of the loss)."""
+    r, sd, body, batch, cam, _ = scenes.build("small_dense")
+    n_use, S = 128, r["n_samples"]
+    b_np = dict(batch)
+    for k in ("ray_o", "ray_d", "near", "far"):
+        b_np[k] = batch[k][:, :n_use]
+    bd = H.device_batch(b_np, DEV)
+    gen = torch.Generator().manual_seed(11)
+    noise = torch.randn(1, n_use, S, generator=gen).to(DEV)
+    target = torch.rand(1, n_use, 3, generator=gen).to(DEV)
+
+    def loss_of(net, grad):
+        rend = H.make_renderer(net, dict(r, white_bkgd=False))
+        rend.cfg.raw_noise_std = 0.7
+        if grad:
+            out = rend.render(bd, raw_noise=noise)
+        else:
+            with torch.no_grad():
+                out = rend.render(bd, raw_noise=noise)
+        return out, ((out["rgb_map"] - target) ** 2).sum()
+
+    net = H.make_network(sd, DEV, True, "f32")
+    out, loss = loss_of(net, True)
+    assert out["rgb_map"].requires_grad
+    loss.backward()
+    g_noisy = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+    assert len(g_noisy) >= 60 and all(bool(torch.isfinite(v).all()) for v in g_noisy.values())
+    with torch.no_grad():
+        inf_out, _ = loss_of(H.make_network(sd, DEV, True, "f32"), False)
+    H.assert_close(out["rgb_map"].detach().cpu().numpy(), inf_out["rgb_map"].cpu().numpy(), 2e-5, "noisy forward, training vs inference path")
+    # without noise the gradients are others
+    net0 = H.make_network(sd, DEV, True, "f32")
+    rend0 = H.make_renderer(net0, dict(r, white_bkgd=False))
+    ((rend0.render(bd)["rgb_map"] - target) ** 2).sum().backward()
+    assert float((net0.alpha_fc.bias.grad - g_noisy["alpha_fc.bias"]).abs().max()) > 1e-3 * float(g_noisy["alpha_fc.bias"].abs().max())
+    # central difference on alpha_fc.bias
+    h = 2e-2
+    vals = []
+    for sgn in (+1, -1):
+        m = H.make_network(sd, DEV, True, "f32")
+        with torch.no_grad():
+            m.alpha_fc.bias += sgn * h
+            vals.append(float(loss_of(m, False)[1]))
+    fd = (vals[0] - vals[1]) / (2 * h)
+    an = float(g_noisy["alpha_fc.bias"][0])
+    print("d loss / d alpha_fc.bias with raw noise: analytic %.5f, central difference %.5f" % (an, fd))
+    assert abs(an - fd) <= 0.05 * max(abs(fd), 1e-3)

@@ -146,9 +146,6 @@ def test_the_differentiable_path_refuses_what_it_does_not_differentiate():
         r.render(b, want_raw=True)
     with pytest.raises(NotImplementedError, match="inference-only"):
         r.render(b, feature_volume=[None])
-    r.cfg.raw_noise_std = 1.0
-    with pytest.raises(NotImplementedError, match="raw_noise_std != 0 on the differentiable path"):
-        r.render(b)
 
 
 def test_prepare_sp_input_keeps_the_reference_layout():
