@@ -43,10 +43,30 @@ using namespace nbm;
 namespace {
 
 // ---------------------------------------------------------------- weight stream (per wave), in 1-KiB pieces
-// phase = NB K blocks x MT output tiles of this wave; per block: for each of its 4 chunks, for each tile: A16 (1 piece);
-// then for each tile: A6h (W_h in fp6, 2 pieces: multiplies the remainder operand), for each tile: A6l (W_l, 2 pieces)
+// phase = NB K blocks x MT output tiles of this wave; per block: for each of its 4 chunks, for each tile: A16 (1 piece: the fp16
+// heads, the main product); then its two CROSS TERMS in execution order, for each tile one fragment: k = 0 W_h (multiplies the
+// remainder operand), k = 1 W_l (multiplies the head operand).  A cross fragment is fp6 e2m3 — 24 bytes of data + its E8M0 scale
+// in the lane's seventh dword, 2 pieces — or, for the terms in NB_FP4_TERMS (bit k), fp4 e2m1 — 16 bytes of data, 1 piece, its
+// scale one byte of the block's SCALE DWORD (byte k MT + m; one 256-byte load per block from behind the pieces).  The cross
+// terms are 2^-11 of the main term, so their weight operand needs few bits: fp4 takes the stream from 176 to 132 pieces per wave
+// and depth step — the stream (L2 -> L1, 64 B/clk/CU) is what the MFMA phases wait for (profiles/r06_march_premises.log) — for
+// 2^-13 instead of 2^-15 relative error per term (profiles/r06_precision_fp4.md).
+#ifndef NB_FP4_TERMS
+#define NB_FP4_TERMS 3
+#endif
+constexpr bool FP4_K[2] = {(NB_FP4_TERMS & 1) != 0, (NB_FP4_TERMS & 2) != 0};
+constexpr bool ANY_FP4 = FP4_K[0] || FP4_K[1];
+// six-bit fragments are two pieces = one (even-aligned) ring entry: when only W_h is four-bit its fragment goes second
+constexpr int TERM_ORDER[2] = {(FP4_K[0] && !FP4_K[1]) ? 1 : 0, (FP4_K[0] && !FP4_K[1]) ? 0 : 1};
+__host__ __device__ constexpr int term_pieces(int k) { return FP4_K[k] ? 1 : 2; }
+// pieces per block (rounded to even: the next block's six-bit fragments stay even-aligned; an odd count leaves one hole)
+__host__ __device__ constexpr int block_pieces(int mt) { return (4 * mt + mt * term_pieces(0) + mt * term_pieces(1) + 1) & ~1; }
+// first piece (inside its block) of the fragment of the cross term executed `slot`-th (0 / 1), tile m
+__host__ __device__ constexpr int cross_piece(int mt, int slot, int m) {
+    return 4 * mt + (slot == 0 ? 0 : mt * term_pieces(TERM_ORDER[0])) + m * term_pieces(TERM_ORDER[slot]);
+}
 constexpr int S_R = 8;  // register ring depth in pieces
-__host__ __device__ constexpr int phase_pieces(int nb, int mt) { return nb * mt * 8; }
+__host__ __device__ constexpr int phase_pieces(int nb, int mt) { return nb * block_pieces(mt); }
 constexpr int N_PH = 4;
 // fc_1, fc_2, the folded colour head over fc_2's outputs (one tile per wave), view_fc over the positional encodings
 constexpr int PH_NB[N_PH] = {4, 4, 4, 2};
@@ -56,9 +76,17 @@ __host__ __device__ constexpr int phase_p0(int ph) {
     for (int i = 0; i < ph; ++i) p += phase_pieces(PH_NB[i], PH_MT[i]);
     return p;
 }
+__host__ __device__ constexpr int phase_s0(int ph) {  // first scale dword of the phase (one per block)
+    int n = 0;
+    for (int i = 0; i < ph; ++i) n += PH_NB[i];
+    return n;
+}
 constexpr int P_L1 = phase_p0(0), P_L2 = phase_p0(1), P_VG = phase_p0(2), P_VP = phase_p0(3), P_TOTAL = phase_p0(4);
-static_assert(P_TOTAL == 176, "pieces per wave per depth step");
-static_assert(P_TOTAL % S_R == 0 && S_R % 2 == 0, "static ring slot of every piece, also across steps; six-bit fragments on even pieces");
+constexpr int N_SCALE = phase_s0(4);                        // 14 scale dwords (256 bytes each) behind the pieces
+constexpr int WAVE_STREAM = P_TOTAL * 1024 + ((N_SCALE * 256 + 1023) & ~1023);  // bytes of one wave's share of the stream
+static_assert(P_TOTAL == (NB_FP4_TERMS == 3 ? 132 : (NB_FP4_TERMS == 0 ? 176 : 160)), "pieces per wave per depth step");
+static_assert(S_R % 2 == 0 && P_L1 % 2 == 0 && P_L2 % 2 == 0 && P_VG % 2 == 0 && P_VP % 2 == 0, "six-bit fragments on even pieces");
+__host__ __device__ constexpr int phase_of_p0(int p0) { return p0 == P_L1 ? 0 : (p0 == P_L2 ? 1 : (p0 == P_VG ? 2 : 3)); }
 
 // fp32 section of the packed blob (written by nb_pack_kernel, nb_march.hip): offsets in floats
 constexpr int F_OFF_B0 = 8 * 44 * 256;
@@ -208,6 +236,10 @@ __device__ __forceinline__ i32x4 load_piece(const WSrc &wl, int p) {
     const u32x4v v = __builtin_amdgcn_raw_buffer_load_b128(wl.rsrc, wl.voff, (p % P_TOTAL) * 1024, 0);
     return i32x4{(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
 }
+// the E8M0 scales of one block's four-bit fragments: one dword per lane (byte k MT + m)
+__device__ __forceinline__ int load_scales(const WSrc &wl, int sidx) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(wl.rsrc, wl.voff >> 2, P_TOTAL * 1024 + sidx * 256, 0);
+}
 template <int P>
 __device__ __forceinline__ void ring_put(WRing &r, const i32x4 v) {
     i32x8 &d = r.f[(P % S_R) / 2];
@@ -229,6 +261,13 @@ __device__ __forceinline__ f32x16 mfma16(const i32x4 a, const i32x4 b, const f32
 // A: fp6 e2m3 (cbsz 2), 24 B of data + the lane's E8M0 scale in register 6; B: bf6 e3m2 (blgp 3), same layout
 __device__ __forceinline__ f32x16 mfma6(const i32x8 a, const i32x8 b, const f32x16 c) {
     return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 2, 3, 0, a[6], 0, b[6]);
+}
+
+// A: fp4 e2m1 (cbsz 4), 16 bytes of data; its E8M0 scale = byte OPSEL of `scales`; B as above
+template <int OPSEL>
+__device__ __forceinline__ f32x16 mfma4(const i32x4 a, int scales, const i32x8 b, const f32x16 c) {
+    const i32x8 a8 = __builtin_shufflevector(a, a, 0, 1, 2, 3, -1, -1, -1, -1);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b, c, 4, 3, OPSEL, scales, 0, b[6]);
 }
 
 template <int I, int N, class F>
@@ -262,7 +301,7 @@ __device__ __forceinline__ void read_b(const char *b16, const char *b6, BOps &x)
         x.m[buf][0] = *reinterpret_cast<const i32x4 *>(b16 + c * CH_BYTES);
         x.m[buf][1] = *reinterpret_cast<const i32x4 *>(b16 + c * CH_BYTES + 1024);
     } else {
-        constexpr int form = 1 - (j - 4);
+        constexpr int form = 1 - TERM_ORDER[j - 4];  // W_h multiplies the remainders (form 1), W_l the heads (form 0)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const char *q = b6 + ((b * 2 + form) * 2 + n) * F6_BYTES;
@@ -279,16 +318,20 @@ struct NoFill {
 // the SAME wave execute under its MFMAs; another wave's do not: profiles/r03_ms6_coexec.md)
 template <int P0, int MT, int NB, bool AHEAD, class Fill = NoFill>
 __device__ __forceinline__ void layer_s(const WSrc &wl, const char *act, int lane, WRing &ring, f32x16 (&acc)[2][2], Fill fill = Fill()) {
-    constexpr int PPB = 8 * MT;  // pieces per block
+    constexpr int PPB = block_pieces(MT);  // pieces per block
     constexpr int PEND = P0 + NB * PPB;
     constexpr int NT = 6 * NB;
+    constexpr int S0 = phase_s0(phase_of_p0(P0));
     const char *b16 = act + lane * 16;
     const char *b6 = act + ACT6_OFF + lane * 16;
     BOps x;
+    int sc[2] = {0, 0};  // scale dwords of the blocks' four-bit fragments: block b in sc[b & 1], loaded one block ahead
+    if constexpr (ANY_FP4) sc[0] = load_scales(wl, S0);
     read_b<0>(b16, b6, x);
     sfor<0, NT>([&](auto tc) {
         constexpr int t = decltype(tc)::value, b = t / 6, j = t % 6, buf = t & 1;
         if constexpr (t + 1 < NT) read_b<t + 1>(b16, b6, x);
+        if constexpr (ANY_FP4 && j == 0 && b + 1 < NB) sc[(b + 1) & 1] = load_scales(wl, S0 + b + 1);
         if constexpr (j < 4) {
             sfor<0, MT>([&](auto mc) {
                 constexpr int m = decltype(mc)::value, P = P0 + b * PPB + j * MT + m;
@@ -298,20 +341,27 @@ __device__ __forceinline__ void layer_s(const WSrc &wl, const char *act, int lan
                 if constexpr (AHEAD || P + S_R < PEND) ring_put<P>(ring, load_piece(wl, P + S_R));
             });
         } else {
-            constexpr int k = j - 4;
+            constexpr int slot = j - 4, k = TERM_ORDER[slot];
             // the operands as pinned 8-register tuples: a 6-of-8 use of two separately allocated 16-byte loads costs two
             // copies per operand
             asm volatile("" : "+v"(x.c[buf][0]), "+v"(x.c[buf][1]));
             sfor<0, MT>([&](auto mc) {
-                constexpr int m = decltype(mc)::value, P = P0 + b * PPB + 4 * MT + (k * MT + m) * 2;
-                static_assert(P % 2 == 0, "a six-bit fragment is one ring entry");
-                i32x8 a = ring.f[(P % S_R) / 2];
-                asm volatile("" : "+v"(a));
-                acc[m][0] = mfma6(a, x.c[buf][0], acc[m][0]);
-                acc[m][1] = mfma6(a, x.c[buf][1], acc[m][1]);
-                if constexpr (AHEAD || P + S_R < PEND) {
-                    ring_put<P>(ring, load_piece(wl, P + S_R));
-                    ring_put<P + 1>(ring, load_piece(wl, P + 1 + S_R));
+                constexpr int m = decltype(mc)::value, P = P0 + b * PPB + cross_piece(MT, slot, m);
+                if constexpr (FP4_K[k]) {
+                    const i32x4 a = ring_get<P>(ring);
+                    acc[m][0] = mfma4<k * MT + m>(a, sc[b & 1], x.c[buf][0], acc[m][0]);
+                    acc[m][1] = mfma4<k * MT + m>(a, sc[b & 1], x.c[buf][1], acc[m][1]);
+                    if constexpr (AHEAD || P + S_R < PEND) ring_put<P>(ring, load_piece(wl, P + S_R));
+                } else {
+                    static_assert(P % 2 == 0, "a six-bit fragment is one ring entry");
+                    i32x8 a = ring.f[(P % S_R) / 2];
+                    asm volatile("" : "+v"(a));
+                    acc[m][0] = mfma6(a, x.c[buf][0], acc[m][0]);
+                    acc[m][1] = mfma6(a, x.c[buf][1], acc[m][1]);
+                    if constexpr (AHEAD || P + S_R < PEND) {
+                        ring_put<P>(ring, load_piece(wl, P + S_R));
+                        ring_put<P + 1>(ring, load_piece(wl, P + 1 + S_R));
+                    }
                 }
             });
         }
@@ -926,7 +976,7 @@ __global__ __launch_bounds__(256, 2) void nb_march_fold_kernel(MarchArgs a, cons
         __syncthreads();
     }
     const __amdgpu_buffer_rsrc_t wrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(stream) + (size_t)wave * P_TOTAL * 1024, 0, P_TOTAL * 1024, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(stream) + (size_t)wave * WAVE_STREAM, 0, WAVE_STREAM, 0x00020000);
     WRing ring;
     WeightStore4 wstore;
     typedef void __attribute__((address_space(3))) *lptr_t;
@@ -1362,7 +1412,24 @@ __device__ __forceinline__ float phase_weight(const nb_mlp_params &p, const floa
     return p.view_w[row * 346 + col];
 }
 
-// one thread per (wave, piece, lane): the lane's 16 bytes
+// fp4 e2m1 (sign, 2 exponent bits of bias 1, 1 mantissa bit: 0 0.5 1 1.5 2 3 4 6), round to nearest (ties to the even code)
+__device__ __forceinline__ unsigned fp4_e2m1_bits(float v) {
+    const unsigned sgn = v < 0.f ? 8u : 0u;
+    const float a = fminf(fabsf(v), 6.f);
+    constexpr float grid[8] = {0.f, 0.5f, 1.f, 1.5f, 2.f, 3.f, 4.f, 6.f};
+    unsigned code = 0;
+    float best = a;
+    for (unsigned c = 1; c < 8; ++c) {
+        const float d = fabsf(a - grid[c]);
+        if (d < best || (d == best && (c & 1u) == 0u)) {
+            best = d;
+            code = c;
+        }
+    }
+    return sgn | code;
+}
+
+// one thread per (wave, piece, lane): the lane's 16 bytes (+, for a four-bit fragment, its scale byte in the block's scale dword)
 __global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f32_blob, unsigned *__restrict__ out, int *__restrict__ stats) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 4 * P_TOTAL * 64) return;
@@ -1377,7 +1444,7 @@ __global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f
         }
         p0 += n;
     }
-    const int mt = PH_MT[ph], ppb = 8 * mt;
+    const int mt = PH_MT[ph], ppb = block_pieces(mt);
     const int rel = piece - p0, b = rel / ppb, r = rel % ppb;
     unsigned w32[4] = {0u, 0u, 0u, 0u};
     if (r < 4 * mt) {  // A16 of chunk j, tile m
@@ -1388,46 +1455,67 @@ __global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f
                               (_Float16)phase_weight(p, f32_blob, ph, row, b, kg, 8 * j + q + 1)};
             w32[q / 2] = __builtin_bit_cast(unsigned, hp);
         }
-    } else {  // six-bit fragment: k = 0 W_h (multiplies the interleaved remainder operand), k = 1 W_l (natural order)
-        const int r6 = r - 4 * mt, k = r6 / (2 * mt), m = (r6 / 2) % mt, half = r6 & 1;
-        const int row = (mt == 2 ? 64 * w + 32 * m : 32 * w) + i;
-        float wv[32], amax = 0.f;
-        for (int e = 0; e < 32; ++e) {
-            const int n = k ? e : 16 * (e & 1) + (e >> 1);
-            const float wt = phase_weight(p, f32_blob, ph, row, b, kg, n);
-            const float h = (float)(_Float16)wt;
-            wv[e] = k ? wt - h : h;
-            amax = fmaxf(amax, fabsf(wv[e]));
-        }
-        int ex = 0;
-        if (amax > 0.f && amax < 3.0e38f) {
-            ex = ilogbf(amax / 7.5f);
-            if (ldexpf(7.5f, ex) < amax) ++ex;  // the smallest power of two with max / 2^ex <= 7.5
-            ex = min(max(ex, -120), 120);
-        }
-        unsigned w8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        for (int e = 0; e < 32; ++e) {
-            const unsigned code = fp6_e2m3_bits(ldexpf(wv[e], -ex));
-            const int bit = 6 * e;
-            w8[bit >> 5] |= code << (bit & 31);
-            if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
-        }
-        w8[6] = (unsigned)(127 + ex);
-        for (int q = 0; q < 4; ++q) w32[q] = w8[4 * half + q];
-        // statistic behind nb_mlp_six_bit_stats_offset(): how many non-zero head weights sit below 1/8 of their block's
-        // maximum, i.e. in e2m3's subnormal range where they keep fewer than 3 bits (per layer: small, non-zero)
-        if (k == 0 && half == 0) {
-            int small = 0, nz = 0;
-            for (int e = 0; e < 32; ++e) {
-                nz += wv[e] != 0.f;
-                small += wv[e] != 0.f && fabsf(wv[e]) < 0.125f * amax;
+    } else {  // a cross fragment: k = 0 W_h (multiplies the interleaved remainder operand), k = 1 W_l (natural order) — or the block's hole
+        int r6 = r - 4 * mt, k = -1, m = 0, half = 0;
+        for (int slot = 0; slot < 2; ++slot) {
+            const int kk = TERM_ORDER[slot], width = mt * term_pieces(kk);
+            if (r6 < width) {
+                k = kk;
+                m = r6 / term_pieces(kk);
+                half = r6 % term_pieces(kk);
+                break;
             }
-            const int layer = ph < 2 ? ph : 2;  // fc_1, fc_2, the folded colour head (both of its K phases)
-            atomicAdd(&stats[2 * layer], small);
-            atomicAdd(&stats[2 * layer + 1], nz);
+            r6 -= width;
+        }
+        if (k >= 0) {
+            const bool four = FP4_K[k];
+            const float top = four ? 6.f : 7.5f;  // largest magnitude of the format
+            const int row = (mt == 2 ? 64 * w + 32 * m : 32 * w) + i;
+            float wv[32], amax = 0.f;
+            for (int e = 0; e < 32; ++e) {
+                const int n = k ? e : 16 * (e & 1) + (e >> 1);
+                const float wt = phase_weight(p, f32_blob, ph, row, b, kg, n);
+                const float h = (float)(_Float16)wt;
+                wv[e] = k ? wt - h : h;
+                amax = fmaxf(amax, fabsf(wv[e]));
+            }
+            int ex = 0;
+            if (amax > 0.f && amax < 3.0e38f) {
+                ex = ilogbf(amax / top);
+                if (ldexpf(top, ex) < amax) ++ex;  // the smallest power of two with max / 2^ex <= top
+                ex = min(max(ex, -120), 120);
+            }
+            if (four) {
+                for (int e = 0; e < 32; ++e) w32[e >> 3] |= fp4_e2m1_bits(ldexpf(wv[e], -ex)) << (4 * (e & 7));
+                unsigned char *sc = reinterpret_cast<unsigned char *>(out) + (size_t)w * WAVE_STREAM + (size_t)P_TOTAL * 1024 +
+                                    (size_t)(phase_s0(ph) + b) * 256 + lane * 4 + (k * mt + m);
+                *sc = (unsigned char)(127 + ex);
+            } else {
+                unsigned w8[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                for (int e = 0; e < 32; ++e) {
+                    const unsigned code = fp6_e2m3_bits(ldexpf(wv[e], -ex));
+                    const int bit = 6 * e;
+                    w8[bit >> 5] |= code << (bit & 31);
+                    if ((bit & 31) > 26) w8[(bit >> 5) + 1] |= code >> (32 - (bit & 31));
+                }
+                w8[6] = (unsigned)(127 + ex);
+                for (int q = 0; q < 4; ++q) w32[q] = w8[4 * half + q];
+            }
+            // statistic behind nb_mlp_six_bit_stats_offset(): how many non-zero head weights sit below 1/8 of their block's
+            // maximum, i.e. where e2m3 keeps fewer than 3 bits and e2m1 none (per layer: small, non-zero)
+            if (k == 0 && half == 0) {
+                int small = 0, nz = 0;
+                for (int e = 0; e < 32; ++e) {
+                    nz += wv[e] != 0.f;
+                    small += wv[e] != 0.f && fabsf(wv[e]) < 0.125f * amax;
+                }
+                const int layer = ph < 2 ? ph : 2;  // fc_1, fc_2, the folded colour head (both of its K phases)
+                atomicAdd(&stats[2 * layer], small);
+                atomicAdd(&stats[2 * layer + 1], nz);
+            }
         }
     }
-    unsigned *dst = out + ((size_t)(w * P_TOTAL + piece) * 64 + lane) * 4;
+    unsigned *dst = reinterpret_cast<unsigned *>(reinterpret_cast<char *>(out) + (size_t)w * WAVE_STREAM) + ((size_t)piece * 64 + lane) * 4;
     for (int q = 0; q < 4; ++q) dst[q] = w32[q];
 }
 
@@ -1435,11 +1523,11 @@ __global__ void nb_pack_fold_kernel(nb_mlp_params p, const float *__restrict__ f
 
 namespace nbm {
 
-long long fold_stream_floats() { return (long long)4 * P_TOTAL * 1024 / 4 + 8; }  // + the six-bit statistic (6 ints, 2 pad)
+long long fold_stream_floats() { return (long long)4 * WAVE_STREAM / 4 + 8; }  // + the six-bit statistic (6 ints, 2 pad)
 
 int pack_fold_stream(const nb_mlp_params *p, float *packed, long long stream_off, hipStream_t st) {
     const long long n = (long long)4 * P_TOTAL * 64;
-    int *stats = reinterpret_cast<int *>(packed + stream_off + (long long)4 * P_TOTAL * 1024 / 4);
+    int *stats = reinterpret_cast<int *>(packed + stream_off + (long long)4 * WAVE_STREAM / 4);
     NB_REQUIRE(hipMemsetAsync(stats, 0, 8 * sizeof(int), st) == hipSuccess, "pack_fold_stream: hipMemsetAsync failed");
     hipLaunchKernelGGL(nb_pack_fold_kernel, dim3(nb_ceil_div(n, 256)), dim3(256), 0, st, *p, packed,
                        reinterpret_cast<unsigned *>(packed + stream_off), stats);

