@@ -559,6 +559,7 @@ def strong_scaling_proxy(args, dev, world=8):
     H = W = args.size
     sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
     poses = build_poses(dev, body, bd, H, W, n_poses=4)
+    rend.use_encoder_graph = bool(getattr(args, "encoder_graph", False))
     if True:
         def loop(rng, n_steps, gather):
             tickets = {}
@@ -773,6 +774,9 @@ def main():
     ap.add_argument("--n-check", type=int, default=None, help="fullview-parity: rays checked (default: every ray of the view)")
     ap.add_argument("--dry-run", action="store_true", help="launch, rendezvous and cross-rank bookkeeping with stub steps: measures nothing")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1 weak runs: skip the strong-scaling leg behind the timed region")
+    ap.add_argument("--encoder-graph", action="store_true",
+                    help="the prefetched encoder pass as ONE HIP graph launch (Renderer.use_encoder_graph): 1.01 -> 0.67 ms per pass on an idle "
+                         "device, 20 us of host time instead of 1 ms; behind a march it changes nothing (profiles/r06_encoder_graph.md)")
     args = ap.parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus, sys.argv[1:], args.dry_run)  # does not return
@@ -832,6 +836,7 @@ def main():
         return
     H = W = args.size
     sd, body, net, rend, bd, n_rays = build_scene(dev, H, W, args.samples, args.precision)
+    rend.use_encoder_graph = bool(args.encoder_graph)  # the prefetched encoder pass as ONE launch (Renderer._replay_encoder_graph)
     S = args.samples
     poses = build_poses(dev, body, bd, H, W)
     from neuralbody_amd.parallel import render_sharded
@@ -1003,7 +1008,7 @@ def main():
                                    "every step encodes one frame and marches one view, the encoder of step i + 1 enqueued on a second HIP stream "
                                    "before the march of step i (Renderer.prefetch; serial_ms_per_step: the same steps on one stream)"
                                    if overlap[0] else "encoder and march one after the other on one stream"),
-                   "encoder_overlap": bool(overlap[0]),
+                   "encoder_overlap": bool(overlap[0]), "encoder_graph": bool(getattr(rend, "use_encoder_graph", False)),
                    "rays_per_view": n_rays, "out_sh": [int(s) for s in body["out_sh"]],
                    "arithmetic": {"f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), trilinear gather on the VALU",
                                   "f16f6": "fc_0 folded into the volume (U = fc_0 . V per active voxel, fp16 head + remainder; the "

@@ -258,12 +258,67 @@ class Renderer:
         self._frame_token = batch.get("frame_token")
         with torch.cuda.stream(side):
             sp_input = self.prepare_sp_input(batch)
-            feature_volume = self.net.encode_sparse_voxels(sp_input)
-            if self.net.march_precision() == "f16f6":
-                self.net.make_scene(feature_volume, sp_input, "f16f6")  # leaves the fold planes on the FeatureVolumes object
+            replayed = self._replay_encoder_graph(batch, sp_input, side) if getattr(self, "use_encoder_graph", False) else None
+            if replayed is not None:
+                sp_input, feature_volume = replayed
+            else:
+                feature_volume = self._encode_for_ticket(sp_input)
             ready = torch.cuda.Event()
             ready.record(side)
         return (self._frame_key(batch), sp_input, feature_volume, ready)
+
+    def _encode_for_ticket(self, sp_input):
+        feature_volume = self.net.encode_sparse_voxels(sp_input)
+        if self.net.march_precision() == "f16f6":
+            self.net.make_scene(feature_volume, sp_input, "f16f6")  # leaves the fold planes on the FeatureVolumes object
+        return feature_volume
+
+    # -- the prefetched pass as a HIP GRAPH (`use_encoder_graph = True`).  The pass is ~48 small launches; enqueued one by one they
+    # cost the launch thread ~20 us each (~1 ms per frame), which a 12 ms march hides — but a rank's share of a view split over 8
+    # GPUs marches in 1.6 ms, and then the launch thread, not the device, sets the step.  Captured once per (frame tensors, weights,
+    # BatchNorm mode) the pass is ONE launch.  A graph owns its memory: every replay rewrites the same index grids, rows and fold
+    # planes, so TWO graphs alternate — the planes the march in front is still reading belong to the other one, and prefetch()
+    # already orders a pass behind the march before the one being enqueued (`_pre_march`), i.e. behind the last reader of the pool
+    # it rewrites.  Keyed on the frame tensors' identity and versions (a graph replays addresses: another frame needs another
+    # capture; loops over the views of ONE frame — turntables, the strong split — reuse it) and on the parameters' versions.
+    ENCODER_GRAPH_SLOTS = 2
+
+    def _encoder_graph_key(self, batch):
+        net = self.net
+        return (self._frame_key(batch), bool(net.training), net.march_precision(),
+                tuple((p.data_ptr(), p._version) for p in net.parameters()))
+
+    def _replay_encoder_graph(self, batch, sp_input, side):
+        """(sp_input, feature_volume) of the frame from a captured pass, or None (the caller then enqueues the pass launch by launch:
+        the first pass of a frame warms the caches — packed weights, the out_sh read-back, 'auto''s one-time checks — that must not
+        sit inside a capture; the next two are the captures themselves, each behind a device synchronisation)."""
+        st = getattr(self, "_enc_graphs", None)
+        key = self._encoder_graph_key(batch)
+        if st is None or not self._same_graph_key(st["key"], key):
+            st = self._enc_graphs = {"key": key, "seen": 0, "slots": [], "turn": 0}
+        st["seen"] += 1
+        if st["seen"] <= 1:
+            return None
+        if len(st["slots"]) < self.ENCODER_GRAPH_SLOTS:
+            g = torch.cuda.CUDAGraph()
+            sp = dict(sp_input)
+            pend = getattr(self.net, "_sat_pending", None)
+            with torch.cuda.graph(g, stream=side):
+                fv = self._encode_for_ticket(sp)
+            self.net._sat_pending = pend  # (a counter parked during capture belongs to no pass)
+            st["slots"].append((g, sp, fv))
+            g.replay()  # capture records, it does not run
+            return sp, fv
+        g, sp, fv = st["slots"][st["turn"]]
+        st["turn"] = (st["turn"] + 1) % len(st["slots"])
+        g.replay()
+        return sp, fv
+
+    @staticmethod
+    def _same_graph_key(a, b):
+        fa, fb = a[0], b[0]
+        return (len(fa) == len(fb) and all((x[0] is y[0] and x[1] == y[1]) if isinstance(x, tuple) else x == y for x, y in zip(fa, fb))
+                and a[1:] == b[1:])
 
     def _frame_key(self, batch):
         return tuple((batch[k], batch[k]._version) for k in self._FRAME_KEYS) + (batch.get("frame_token"),)
