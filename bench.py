@@ -499,12 +499,14 @@ def extras(args, dev):
     a = copy.copy(args)
     a.steps, a.warmup, a.reuse_volumes = 8, 2, False
     tt = turntable_bench(a, dev)
-    a.steps, a.warmup = 6, 2
+    # (6 steps behind 2 warm-ups read 6.7-7.5 ms where `--mode train --steps 20 --warmup 5` reads 5.5: the first steps still grow the
+    # caching allocator's pools and create Adam's state; with 5 warm-ups the two agree)
+    a.steps, a.warmup = 10, 5
     tr = train_bench(a, dev)
     ex = {"turntable_ms_per_view": tt["ms_per_view"], "turntable_rays_per_sec": tt["rays_per_sec"],
           "train_step_ms": tr["value"], "train_ray_samples_per_sec": tr["ray_samples_per_sec"], "train_roofline": tr["roofline"],
           "train_cpu_baseline": _train_cpu_record(),
-          "note": "8 spiral views (512x512x64, each view: nb_raygen + encoder + march + nb_image_assemble) / 6 training steps "
+          "note": "8 spiral views (512x512x64, each view: nb_raygen + encoder + march + nb_image_assemble) / 10 training steps behind 5 warm-ups "
                   "(1024 random rays x 64 jittered samples, forward + backward + clip + Adam); *_ms_per_view / *_march_ms: the timed "
                   "view of this run rendered with the other arithmetics (3 steps each), roofline fraction of each against ITS peak"}
     # the same view in the reference's own precision (exact fp32 MFMA): the record then holds a reference-precision number from

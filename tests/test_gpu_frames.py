@@ -296,3 +296,45 @@ def test_a_batch_of_two_frames_trains():
     for k in g2:
         scale = float(g2[k].abs().max()) + 1e-30
         assert float((g2[k] - (g0[k] + g1[k])).abs().max()) <= 2e-4 * scale, k
+
+
+def test_prefetch_as_a_hip_graph_renders_the_same_views():
+    """Renderer.use_encoder_graph: the prefetched encoder pass captured into two alternating HIP graphs (one launch per pass).  A loop
+    over 7 views of one frame — pass 1 eager, passes 2 and 3 the captures, the rest replays — must give the images of the eager loop
+    (train-mode BatchNorm as run.py renders: its statistics are summed with atomics, so two passes over one frame agree to rounding,
+    not bit for bit), and a change of the weights must drop the captured graphs (they replay addresses AND packed weights)."""
+    import bench
+
+    dev = torch.device(DEV)
+    sd, body, net, rend, bd, n = bench.build_scene(dev, 64, 64, 16, None)
+    poses = bench.build_poses(dev, body, bd, 64, 64, n_poses=4)
+
+    def loop(use_graph, n_views=7):
+        rend.use_encoder_graph = use_graph
+        rend._enc_graphs = None
+        out, ticket = [], None
+        with torch.no_grad():
+            for i in range(n_views):
+                fence = rend.fence()
+                out.append(rend.render(poses[i % 4], prefetched=ticket)["rgb_map"].clone())
+                ticket = rend.prefetch(poses[(i + 1) % 4], after=fence)
+        torch.cuda.synchronize()
+        return out
+
+    eager = loop(False)
+    graph = loop(True)
+    st = rend._enc_graphs
+    assert st is not None and len(st["slots"]) == 2 and st["seen"] == 7
+    for i, (a, b) in enumerate(zip(eager, graph)):
+        assert H.same_result(a, b, "f16f6", tol=2e-5), "view %d differs between the eager and the graph-replayed encoder pass" % i
+    assert float((eager[0] - eager[1]).abs().max()) > 1e-2  # the poses are different views
+    # new weights: the key changes, the graphs are dropped and captured again
+    with torch.no_grad():
+        net.xyzc_net.conv4[6].weight.mul_(-1.0)  # (a scale would be undone by the BatchNorm behind the convolution)
+    g2 = loop(True)
+    assert rend._enc_graphs is not st and len(rend._enc_graphs["slots"]) == 2
+    e2 = loop(False)
+    for a, b in zip(e2, g2):
+        assert H.same_result(a, b, "f16f6", tol=2e-5)
+    assert float((e2[2] - eager[2]).abs().max()) > 1e-3  # ... and the new weights render something else
+    rend.use_encoder_graph = False
