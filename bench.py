@@ -52,11 +52,11 @@ FLOP_PER_SAMPLE = 859904.0  # MLP MACs x 2 as the reference la
 PRECISION_INFO = {
     # feature_fc.latent_fc merged, latent folded into a bias: 331 648 MAC/sample on v_mfma_f32_32x32x2_f32
     "f32": ("f32", "nb_march_kernel", 663296.0, 157.3),
-    # fc_0 folded into the volume; fc_1 / fc_2 / the folded colour head: fp16 main product + two six-bit cross terms (a K=64
-    # fp6 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA, profiles/r02_probe_mxrate.log, and is counted as
+    # fc_0 folded into the volume; fc_1 / fc_2 / the folded colour head: fp16 main product + two narrow cross terms (a K=64
+    # fp4 x bf6 MFMA occupies the matrix pipe as long as ONE K=16 fp16 MFMA, profiles/r05_probe_fp4.log, and is counted as
     # one).  Per wave and depth step of 64 samples: fc_1 96, fc_2 96, the colour head 48 + 24 over the encodings, and 12 per 16
     # voxels of the step's voxel list (8 x 8 pixel tiles of the bench view: 59 voxels = 4.2 chunks on average)
-    "f16f6": ("f16+f6", "nb_march_fold_kernel", 4 * (264 + 12 * 4.2) * 32768 / 64.0, 2500.0),
+    "f16f6": ("f16+f6/f4", "nb_march_fold_kernel", 4 * (264 + 12 * 4.2) * 32768 / 64.0, 2500.0),
 }
 
 
@@ -987,7 +987,7 @@ def main():
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be
     # read from inside the process); the committed summary is quoted when it matches the workload
     traffic = None
-    tfile = {"f16f6": "r05_march_fold_traffic.json"}.get(net.march_precision())
+    tfile = {"f16f6": "r06_march_fold_traffic.json"}.get(net.march_precision())
     tpath = os.path.join(ROOT, "profiles", tfile or "none")
     if tfile and (H, W, S) == (512, 512, 64) and args.scaling == "weak" and os.path.exists(tpath):
         with open(tpath) as f:
@@ -1016,14 +1016,15 @@ def main():
                                   "f16f6": "fc_0 folded into the volume (U = fc_0 . V per active voxel, fp16 head + remainder; the "
                                            "trilinear lookup is an MFMA against the sparse weight matrix of the workgroup's voxel "
                                            "list, three fp16 products, fp32 accumulate); fc_1, fc_2 and the colour head: fp16 head x "
-                                           "fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross terms in 6 bits "
-                                           "(fp6 e2m3 weights, bf6 e3m2 activations, E8M0 scales per 32 K) on "
+                                           "fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross terms in 4 x 6 bits "
+                                           "(fp4 e2m1 weights, bf6 e3m2 activations, E8M0 scales per 32 K) on "
                                            "v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate; four waves share 64 rays, activations in "
                                            "LDS, weights streamed from L2, two workgroups per CU"}[net.march_precision()],
                    "parallelism": "views/rays sharded across %d GPU(s)%s" % (world, ", RCCL all-gather of RGB tiles" if world > 1 else "")},
         "roofline": {"bound": "mfma", "kernel": kernel_name, "achieved": achieved_tflops,
                      "peak": peak, "unit": "TFLOP/s", "frac": achieved_tflops / peak,
-                     "traffic": traffic, "traffic_unit": "bytes/launch (PMC, %s)" % os.path.relpath(tpath, ROOT),
+                     "traffic": traffic, "traffic_unit": "bytes/launch, QUOTED from the committed PMC record of this kernel and workload (%s: separate rocprofv3 --pmc passes, "
+                                                        "tools/pmc_traffic.sh), not measured by this run" % os.path.relpath(tpath, ROOT),
                      "avg_launch_ms": march_ms,
                      "executed_tflops": exec_flop * rays_per_launch * S / (march_ms * 1e-3) / 1e12,
                      "executed_frac": exec_flop * rays_per_launch * S / (march_ms * 1e-3) / 1e12 / peak,
