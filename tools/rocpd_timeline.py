@@ -14,7 +14,7 @@ def short(name):
     return name.replace("void ", "")[:90]
 
 
-def main(path, march="nb_march"):
+def main(path, march="nb_march_fold_kernel"):  # (not "nb_march": nb_march_fixup_kernel follows every march since round 6)
     c = sqlite3.connect(path)
     rows = c.execute("select name, start, end from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if march in r[0]]
