@@ -582,8 +582,26 @@ def strong_scaling_proxy(args, dev, world=8):
             ms = sorted(a.elapsed_time(b) for a, b in ev[2:])
             return ms[len(ms) // 2]
 
+        def loop_once_encoded(rng, n_steps):
+            # the turntable case (BASELINE config 5: 144 views of ONE frame): the frame is encoded once, a step is the march of the
+            # share alone (NovelViewRenderer.reuse_volumes / Renderer.render(feature_volume=...))
+            ev = []
+            with torch.no_grad():
+                vols = net.encode_sparse_voxels(rend.prepare_sp_input(poses[0]))
+                for i in range(n_steps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    rend.render(poses[i % len(poses)], ray_range=rng, feature_volume=vols)
+                    e1.record()
+                    ev.append((e0, e1))
+                torch.cuda.synchronize()
+            ms = sorted(a.elapsed_time(b) for a, b in ev[2:])
+            return ms[len(ms) // 2]
+
         full = loop(None, 8, False)
         shares = [loop(parallel.shard_range_tiled(n_rays, r, world, H, W), 8, dist.is_initialized()) for r in range(world)]
+        full_once = loop_once_encoded(None, 8)
+        shares_once = [loop_once_encoded(parallel.shard_range_tiled(n_rays, r, world, H, W), 8) for r in range(world)]
         g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         tile = torch.zeros((n_rays // world, 3), device=dev)
         ag = None
@@ -597,6 +615,10 @@ def strong_scaling_proxy(args, dev, world=8):
             ag = g0.elapsed_time(g1) / 10
         out = {"strong8_rank_ms": max(shares), "strong8_share_ms": [round(v, 3) for v in shares], "strong8_full_view_ms": full,
                "strong8_allgather_world1_ms": ag, "strong8_predicted_speedup": full / max(shares),
+               "strong8_frame_encoded_once": {"rank_ms": max(shares_once), "full_view_ms": full_once, "predicted_speedup": full_once / max(shares_once),
+                                              "note": "the same shares when the frame is encoded ONCE for all views (a turntable of one frame: BASELINE "
+                                                      "config 5; Renderer.render(feature_volume=...)): the step is the march of the share alone, the "
+                                                      "replicated encoder — the Amdahl term of the figures above — is gone"},
                "strong8_note": "median step of one rank's share (1/8 of the view in whole 8-row tile bands) in the fence / render(ray_range) / "
                                "prefetch loop of --scaling strong, each of the 8 shares in turn on this GPU (all-gather of the RGB tile "
                                "only under torch.distributed.run; DESIGN.md section 6 models it at 0.1-0.15 ms); full_view_ms: the same loop "
