@@ -353,7 +353,10 @@ class Network(nn.Module):
         self.last_ill = None
         self._sat_pending = None  # (fc_0 key, counter tensor) of a later frame's planes, read at the next host synchronisation
         if int(xyz_res) != 10 or int(view_res) != 4:
-            raise NotImplementedError("the HIP decoder is built for xyz_res=10, view_res=4 (view_fc has 346 inputs)")
+            raise NotImplementedError(
+                "xyz_res=10, view_res=4 only: the reference's own Network hard-codes view_fc = Conv1d(346, 128, 1) "
+                "(latent_xyzc.py:27: 256 + 27 + 63 = 346 inputs), so any other embedder resolution (embedder.py:53-54) fails there "
+                "too, at the first view_fc call (:120); the HIP decoder is built for the same 346 inputs")
         self.voxel_size = [float(v) for v in voxel_size]
         self.c = nn.Embedding(N_VERTS, CODE_DIM)
         self.xyzc_net = SparseConvNet()
