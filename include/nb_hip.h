@@ -42,11 +42,12 @@ extern "C" {
                            the sparse trilinear-weight matrix Wt [voxel x sample] on the matrix pipe (three fp16 products per
                            K = 16 voxels, products exact, fp32 accumulate: fp32-level accuracy).  Needs nb_scene.fold.
                            fc_1, fc_2 and the colour head (feature_fc . latent_fc . view_fc folded into one layer): fp16 head x
-                           fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross terms in 6 bits (weights fp6
-                           e2m3 with a pack-time E8M0 scale per row and 32 K, activations bf6 e3m2 with a run-time E8M0 scale
-                           per sample and 32 K) on v_mfma_scale_f32_32x32x64_f8f6f4, fp32 accumulate: ~2^-15 relative per term.
-                           Weight blocks whose elements span more than ~2^5 lose their small elements: see
-                           nb_mlp_six_bit_stats_offset() */
+                           fp16 head on v_mfma_f32_32x32x16_f16 + the two head x remainder cross terms on
+                           v_mfma_scale_f32_32x32x64_f8f6f4 (weights fp4 e2m1 with a pack-time E8M0 scale per row and 32 K — fp6 e2m3
+                           until ABI 19; the build flag NB_FP4_TERMS selects — activations bf6 e3m2 with a run-time E8M0 scale per
+                           sample and 32 K), fp32 accumulate: ~2^-13 relative per cross term, RGB <= 4e-5 on every fixture.
+                           Weight blocks whose elements span more than ~2^3 lose their small elements: see
+                           nb_mlp_six_bit_stats_offset().  Rays whose LAST density it cannot sign: nb_march's ill_scratch. */
 
 /* MLP geometry fixed by lib/networks/latent_xyzc.py:20-28 */
 #define NB_FEAT_DIM 352 /* 32 + 64 + 128 + 128 interpolated channels */
@@ -93,7 +94,7 @@ typedef struct nb_scene {
 /* ---------------------------------------------------------------------------------
  * Packed decoder weights.  nb_mlp_pack_size() floats; produced by nb_mlp_pack() from
  * the reference's parameter tensors (Conv1d(k=1) weights [out,in,1] viewed as [out,in]).
- * The blob holds both formats (fp32 fragments for NB_PREC_F32, the fp16 / fp6 fragment stream of NB_PREC_F16F6).
+ * The blob holds both formats (fp32 fragments for NB_PREC_F32, the fp16 / fp4 fragment stream of NB_PREC_F16F6).
  * The packing re-orders every layer into MFMA A-operand fragment order and merges
  * feature_fc with the first 256 columns of latent_fc (no activation sits between them,
  * latent_xyzc.py:106-111).  nb_mlp_latent_bias() folds the per-frame latent code
@@ -103,8 +104,8 @@ typedef struct nb_scene {
 int64_t nb_mlp_pack_size(void);        /* floats in the packed blob */
 int64_t nb_mlp_latent_bias_size(void); /* floats in the per-frame bias block (384: see nb_mlp_latent_bias) */
 /* Float offset inside the packed blob of 6 int32 counters written with the NB_PACK_F16F6 section: for each of the three
- * layers that kernel runs with six-bit cross terms (fc_1, fc_2, the folded feature_fc / latent_fc / view_fc layer) {small, nonzero}
- * = how many non-zero weights lie below 1/8 of the maximum of their (row, 32 K) block — where fp6 e2m3 keeps fewer than 3
+ * layers that kernel runs with narrow cross terms (fc_1, fc_2, the folded feature_fc / latent_fc / view_fc layer) {small, nonzero}
+ * = how many non-zero weights lie below 1/8 of the maximum of their (row, 32 K) block — where fp6 e2m3 keeps fewer than 3 and fp4 e2m1 no
  * significant bits — and how many are non-zero at all.  small / nonzero is ~0.2 for normally distributed weights; a caller that
  * cannot rule out weight blocks with a wide dynamic range (> ~2^5) uses it to fall back to NB_PREC_F32 (the Python Network does,
  * precision "auto"). */
