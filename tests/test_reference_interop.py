@@ -108,3 +108,34 @@ def test_trainer_plugin_resolves_through_reference_wrapper_factory():
     # the Trainer drives exactly this surface (trainer.py:46-52): parameters() for clip/Adam, forward(batch) -> 4-tuple
     assert len(list(wrapper.parameters())) == 69
     assert set(dict(wrapper.named_parameters())) == {"net." + k for k, _ in net.named_parameters()}
+
+
+def test_the_reference_itself_cannot_run_other_embedder_resolutions():
+    """Why Network(xyz_res != 10 or view_res != 4) is refused: the reference's Network hard-codes view_fc = Conv1d(346, 128, 1)
+    (latent_xyzc.py:27) while its embedders take their width from cfg.xyz_res / cfg.view_res at import (embedder.py:53-54) — with
+    xyz_res = 8 the decoder's concatenation has 334 channels and view_fc raises.  Run in a fresh interpreter: the embedder globals
+    are frozen at the first import of the reference."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from oracle import ref_harness as rh\n"
+        "from tests.golden import scenes\n"
+        "ns = rh.load(opts=('perturb', '0', 'xyz_res', '8'))\n"
+        "assert ns.embedder.xyz_dim == 3 + 6 * 8, ns.embedder.xyz_dim\n"
+        "r, sd, body, batch, cam, _ = scenes.build('small')\n"
+        "net = rh.make_reference_network(sd)\n"
+        "assert tuple(net.view_fc.weight.shape) == (128, 346, 1)\n"
+        "ren = rh.make_reference_renderer(net)\n"
+        "try:\n"
+        "    with torch.no_grad():\n"
+        "        ren.render(rh.torch_batch(batch))\n"
+        "except RuntimeError as e:\n"
+        "    print('REFERENCE RAISED:', str(e)[:120])\n"
+        "else:\n"
+        "    print('REFERENCE RAN')\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "REFERENCE RAISED:" in out.stdout and "REFERENCE RAN" not in out.stdout, out.stdout
