@@ -923,46 +923,51 @@ def main():
         # step with its rays split over the ranks (whole 8-row tile bands) and the RGB tiles all-gathered: north_star's "partition
         # pixel batches across the 8 GPUs".  Its speed-up is quoted against the weak leg's step (one whole view per GPU).
         strong_leg = None
+        strong_error = None
         if dist is not None and args.scaling == "weak" and not args.no_strong_leg:
-            stickets = {}
+            try:  # the headline above must survive whatever this informational leg does
+                stickets = {}
 
-            def strong_step(i):
-                fence = rend.fence() if overlap[0] else None
-                o = render_sharded(rend, poses[i % len(poses)], dist.group.WORLD, prefetched=stickets.pop(i, None))["rgb_map"][0]
-                if overlap[0]:
-                    stickets[i + 1] = rend.prefetch(poses[(i + 1) % len(poses)], after=fence)
-                return o
+                def strong_step(i):
+                    fence = rend.fence() if overlap[0] else None
+                    o = render_sharded(rend, poses[i % len(poses)], dist.group.WORLD, prefetched=stickets.pop(i, None))["rgb_map"][0]
+                    if overlap[0]:
+                        stickets[i + 1] = rend.prefetch(poses[(i + 1) % len(poses)], after=fence)
+                    return o
 
-            for i in range(max(args.warmup, 2)):
-                strong_step(i)
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            ops.MARCH_EVENTS = []
-            s_events = []
-            ts = time.perf_counter()
-            for i in range(args.steps):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                strong_step(max(args.warmup, 2) + i)
-                e1.record()
-                s_events.append((e0, e1))
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
-            s_elapsed = time.perf_counter() - ts
-            s_march, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
-            share = torch.zeros(((n_rays + world - 1) // world, 3), device=dev)
-            all_gather_tiles(share, dist.group.WORLD)
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record()
-            for _ in range(10):
+                for i in range(max(args.warmup, 2)):
+                    strong_step(i)
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                ops.MARCH_EVENTS = []
+                s_events = []
+                ts = time.perf_counter()
+                for i in range(args.steps):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    strong_step(max(args.warmup, 2) + i)
+                    e1.record()
+                    s_events.append((e0, e1))
+                torch.cuda.synchronize()
+                dist.barrier()
+                torch.cuda.synchronize()
+                s_elapsed = time.perf_counter() - ts
+                s_march, ops.MARCH_EVENTS = ops.MARCH_EVENTS, None
+                share = torch.zeros(((n_rays + world - 1) // world, 3), device=dev)
                 all_gather_tiles(share, dist.group.WORLD)
-            g1.record()
-            torch.cuda.synchronize()
-            s_ms = sorted(a.elapsed_time(b) for a, b in s_events)
-            strong_leg = {"elapsed": s_elapsed, "local": [float(np.mean([a.elapsed_time(b) for a, b in s_march])) if s_march else float("nan"),
-                                                          g0.elapsed_time(g1) / 10, s_ms[len(s_ms) // 2]]}
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                for _ in range(10):
+                    all_gather_tiles(share, dist.group.WORLD)
+                g1.record()
+                torch.cuda.synchronize()
+                s_ms = sorted(a.elapsed_time(b) for a, b in s_events)
+                strong_leg = {"elapsed": s_elapsed, "local": [float(np.mean([a.elapsed_time(b) for a, b in s_march])) if s_march else float("nan"),
+                                                              g0.elapsed_time(g1) / 10, s_ms[len(s_ms) // 2]]}
+            except Exception as e:  # noqa: BLE001
+                strong_leg, strong_error = None, repr(e)
+                ops.MARCH_EVENTS = None
         # the same steps strictly serial on one stream (informational: what a single render() call costs)
         serial_ms = None
         if overlap[0] and dist is None:
@@ -993,7 +998,13 @@ def main():
         elapsed, rows = reduce_timings(elapsed, [march_ms, ag_ms, step_ms[len(step_ms) // 2]], _lib.PRECISIONS[net.march_precision()],
                                        dist.group.WORLD, dev)
         per_rank = [{"rank": r, "march_ms": row[0], "allgather_ms": row[1], "median_step_ms": row[2]} for r, row in enumerate(rows)]
-        if strong_leg is not None:
+        # every rank must agree that the leg ran before they meet in its reduction (a rank that raised would leave the others waiting)
+        if not args.no_strong_leg and args.scaling == "weak":
+            okf = torch.tensor([1.0 if strong_leg is not None else 0.0], dtype=torch.float64, device=dev)
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN, group=dist.group.WORLD)
+            if float(okf.item()) < 1.0:
+                strong_leg = {"error": strong_error or "another rank's strong leg failed"}
+        if strong_leg is not None and "error" not in strong_leg:
             s_el, s_rows = reduce_timings(strong_leg["elapsed"], strong_leg["local"], _lib.PRECISIONS[net.march_precision()], dist.group.WORLD, dev)
             strong_leg = {"ms_per_step": s_el / args.steps * 1e3, "steps": args.steps,
                           "value": n_rays * S * args.steps / s_el, "unit": "ray-samples/s (one view per step, rays split over the ranks)",
@@ -1059,7 +1070,7 @@ def main():
         result["serial_ms_per_step"] = serial_ms
     if per_rank is not None:
         result["per_rank"] = per_rank
-    if isinstance(strong_leg, dict) and "ms_per_step" in strong_leg:
+    if isinstance(strong_leg, dict) and ("ms_per_step" in strong_leg or "error" in strong_leg):
         result["strong_leg"] = strong_leg
     if net.precision == "auto":
         result["config"]["auto"] = {"chosen": net.march_precision(), "six_bit_small_fraction_worst_layer": net._auto[2] if net._auto else None}
