@@ -621,10 +621,10 @@ class Network(nn.Module):
         loc = ((z >> 1) << 5) | ((y >> 1) << 4) | ((x >> 1) << 3) | ((z & 1) << 2) | ((y & 1) << 1) | (x & 1)
         return torch.argsort((blk << 6) | loc)
 
-    def _decode(self, wpts, viewdir, feature_volume, sp_input, density_only):
-        prec = self._point_precision()
+    def _decode(self, wpts, viewdir, feature_volume, sp_input, density_only, precision=None):
+        prec = precision or self._point_precision()
         scene = self.make_scene(feature_volume, sp_input, prec)
-        if prec != self._point_precision():  # (see render_rays)
+        if precision is None and prec != self._point_precision():  # (see render_rays)
             prec = self._point_precision()
             scene = self.make_scene(feature_volume, sp_input, prec)
         p = wpts.reshape(-1, 3).float().contiguous()
@@ -640,12 +640,36 @@ class Network(nn.Module):
             return out
         return ops.decode_points(scene, packed, lb, p, v, density_only=density_only, precision=prec)
 
-    def calculate_density(self, wpts, feature_volume, sp_input):
+    def calculate_density(self, wpts, feature_volume, sp_input, precision=None):
+        """latent_xyzc.py:74-89.  precision (an extension): 'f32' / 'f16f6' for this call instead of the Network's arithmetic."""
         B = wpts.shape[0]
         if B != 1:  # frame by frame: every element has its own volumes, pose and bounds
-            return torch.cat([self.calculate_density(wpts[b:b + 1], frame_volumes(feature_volume, b), frame_sp_input(dict(sp_input, batch_size=B), b))
-                              for b in range(B)], 0)
-        return self._decode(wpts, None, feature_volume, sp_input, True).view(1, -1, 1)
+            return torch.cat([self.calculate_density(wpts[b:b + 1], frame_volumes(feature_volume, b), frame_sp_input(dict(sp_input, batch_size=B), b),
+                                                     precision=precision) for b in range(B)], 0)
+        return self._decode(wpts, None, feature_volume, sp_input, True, precision).view(1, -1, 1)
+
+    LAST_DENSITY_FIX_RAYS = 4096  # rays per frame whose last density the unfused path re-decodes at fp32 (the nearest to zero)
+
+    def fix_last_densities(self, raw, wpts, feature_volume, sp_input):
+        """The unfused path's counterpart of nb_march's last-sample fix-up (include/nb_hip.h, `ill_scratch`): raw [B, n, S, 4] as decoded
+        by calculate_density_color with the 'f16f6' arithmetic, wpts [B, n, S, 3].  The reference gives a ray's LAST sample the interval
+        1e10 (nerf_net_utils.py:28), so its alpha is a step function of the sign of its density: the LAST_DENSITY_FIX_RAYS rays of a frame
+        whose last density is nearest to zero are decoded once more with the exact kernel, and those within NB_ILL_SIGMA of zero take the
+        exact value.  No host read-back (a fixed number of rays: top-k on the device).  Identity for the 'f32' arithmetic."""
+        from ._lib import ILL_SIGMA
+
+        if self._point_precision() != "f16f6" or not self.last_sample_fixup or raw.shape[1] == 0:
+            return raw
+        raw = raw.clone()
+        for b in range(raw.shape[0]):
+            sig = raw[b, :, -1, 3]
+            k = min(int(sig.shape[0]), self.LAST_DENSITY_FIX_RAYS)
+            idx = torch.topk(sig.abs(), k, largest=False).indices
+            fv = frame_volumes(feature_volume, b) if raw.shape[0] > 1 else feature_volume
+            sp = frame_sp_input(dict(sp_input, batch_size=raw.shape[0]), b) if raw.shape[0] > 1 else sp_input
+            exact = self.calculate_density(wpts[b, idx, -1][None].contiguous(), fv, sp, precision="f32")[0, :, 0]
+            raw[b, idx, -1, 3] = torch.where(sig[idx].abs() < ILL_SIGMA, exact, sig[idx])
+        return raw
 
     def calculate_density_color(self, wpts, viewdir, feature_volume, sp_input):
         B = wpts.shape[0]

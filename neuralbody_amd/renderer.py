@@ -113,6 +113,10 @@ class Renderer:
             x_point, viewdir_val, feature_volume, sp_input)
         wpts_raw = self.get_density_color(wpts, viewdir, raw_decoder)
         n_batch, n_pixel, n_sample = wpts.shape[:3]
+        fix = getattr(self.net, "fix_last_densities", None)
+        if fix is not None and float(self.cfg.raw_noise_std) == 0.0:
+            # the densities the 1e10 last interval makes sign-critical, re-decoded at fp32 (the fused march does this in nb_march)
+            wpts_raw = fix(wpts_raw.reshape(n_batch, n_pixel, n_sample, 4), wpts, feature_volume, sp_input)
         raw = self._add_raw_noise(wpts_raw.reshape(-1, n_sample, 4), raw_noise).contiguous()
         rgb, disp, acc, weights, depth = ops.composite(raw, z_vals.reshape(-1, n_sample).contiguous(),
                                                        ray_d.reshape(-1, 3).contiguous(), self.cfg.white_bkgd)

@@ -174,3 +174,40 @@ def test_fixup_with_jitter_white_background_and_an_odd_sample_count():
         H.assert_close(fixed[k][decidable].cpu().numpy(), ref[k][decidable].cpu().numpy(), tol, k)
     listed = (plain["raw"][:, -1, 3].abs() < _lib.ILL_SIGMA)
     assert float((fixed["raw"][:, -1, 3][listed & decidable] - sig_ref[listed & decidable]).abs().max()) <= 5e-5
+
+
+def test_unfused_path_fixes_the_last_densities_too():
+    """Renderer.get_pixel_value (points decoded through the Network API, then nb_composite: what a subclass overriding
+    get_density_color runs) with the default arithmetic: Network.fix_last_densities re-decodes at fp32 the last densities nearest to
+    zero.  Same construction as above (alpha_fc's bias moved to the median last density of the picked rays), 4096 rays of the bench view;
+    reference: the same unfused path with precision 'f32'."""
+    dev = torch.device(DEV)
+    sd, body, net, rend, bd, n = bench.build_scene(dev, 512, 512, 64, "f32")
+    net.eval()
+    sel = torch.linspace(0, n - 1, 4096).long().to(dev)
+    rays = {k: bd[k][:, sel].contiguous() for k in ("ray_o", "ray_d", "near", "far")}
+    with torch.no_grad():
+        sp = rend.prepare_sp_input(bd)
+        vols = net.encode_sparse_voxels(sp)
+
+        def pixels(precision, fixup):
+            net.precision, net.last_sample_fixup = precision, fixup
+            return rend.get_pixel_value(rays["ray_o"], rays["ray_d"], rays["near"], rays["far"], vols, sp, bd)
+
+        first = pixels("f32", True)
+        wpts, _ = rend.get_sampling_points(rays["ray_o"], rays["ray_d"], rays["near"], rays["far"])
+        sig_last = net.calculate_density(wpts[:, :, -1].contiguous(), vols, sp)[0, :, 0]
+        net.alpha_fc.bias -= float(sig_last.median())
+        ref = pixels("f32", True)
+        sig_ref = net.calculate_density(wpts[:, :, -1].contiguous(), vols, sp)[0, :, 0]
+        plain = pixels("f16f6", False)
+        fixed = pixels("f16f6", True)
+    torch.cuda.synchronize()
+    decidable = sig_ref.abs() >= bench.FP32_SIGMA
+    e_plain = (plain["rgb_map"][0] - ref["rgb_map"][0]).abs().max(1).values[decidable]
+    e_fixed = (fixed["rgb_map"][0] - ref["rgb_map"][0]).abs().max(1).values[decidable]
+    print("unfused path, 4096 rays, %d within %.0e of the step: un-fixed worst %.3f (%d rays beyond 1e-4), fixed worst %.2e" % (
+        int((sig_ref.abs() < _lib.ILL_SIGMA).sum()), _lib.ILL_SIGMA, float(e_plain.max()), int((e_plain > 1e-4).sum()), float(e_fixed.max())))
+    assert int((sig_ref.abs() < _lib.ILL_SIGMA).sum()) >= 20
+    assert float(e_fixed.max()) <= 6e-5  # (the unfused path's tolerance: points of one depth step share a workgroup, test_render_end_to_end)
+    assert float((first["rgb_map"] - ref["rgb_map"]).abs().max()) > 1e-3  # the bias shift changed the picture
