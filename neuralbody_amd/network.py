@@ -225,8 +225,8 @@ class SparseConvNet(nn.Module):
         dhw = [int(s) for s in out_sh]
         n_max = coord.shape[0]
         layers = [(name, cin, cout, n, stride, j) for name, cin, cout, n, stride in ENCODER_BLOCKS for j in range(n)]
-        # ONE zero fill per element type for everything the pass needs cleared: the index buffers of the levels (rows_vert |
-        # rows_lin | n_rows, then out_lin | n_out per strided layer), and the dense volumes + the layers' fp64 statistics
+        # ONE zero fill for everything the pass needs cleared: the index buffers of the levels (rows_vert | rows_lin | n_rows, then
+        # out_lin | n_out per strided layer), the layers' fp64 statistics and (when made eagerly) the dense volumes
         int_sizes, dense_shapes, cap, d = [1, 2 * max(n_max, 1) + 1], [], n_max, dhw
         for name, cin, cout, n, stride, j in layers:
             if stride == 2:
@@ -234,8 +234,7 @@ class SparseConvNet(nn.Module):
                 cap, d = int_sizes[-1] - 1, ops.down_dhw(d)
             if name in DENSE_AFTER and j == n - 1:
                 dense_shapes.append(d + [cout])
-        int_bufs = list(torch.zeros(sum(int_sizes), dtype=torch.int32, device=dev).split(int_sizes))
-        zeroed_int = int_bufs.pop(0)
+        n_int = (sum(int_sizes) + 63) // 64 * 64  # (the fp32 / fp64 part behind it keeps a fresh allocation's 256-byte alignment)
         # ... and ONE fill with -1 for the index grids of the five levels
         grid_shapes, d = [list(dhw)], dhw
         for name, cin, cout, n, stride, j in layers:
@@ -247,7 +246,12 @@ class SparseConvNet(nn.Module):
                                                                  grid_shapes)]
         n_stats = 2 * len(layers) * 256  # fp64 [layers, 256] in front (8-byte aligned), the volumes behind it (64-float aligned)
         dense_sizes = [0 if lazy else (math.prod(sh) + 63) // 64 * 64 for sh in dense_shapes]
-        f32_buf = torch.zeros(n_stats + sum(dense_sizes), dtype=torch.float32, device=dev)
+        # ONE zero fill: the index buffers (int32), the layers' statistics (fp64) and, when they are made eagerly, the volumes — an
+        # all-zero word is 0 in every one of these types
+        zero_buf = torch.zeros(n_int + n_stats + sum(dense_sizes), dtype=torch.int32, device=dev)
+        int_bufs = list(zero_buf[:sum(int_sizes)].split(int_sizes))
+        zeroed_int = int_bufs.pop(0)
+        f32_buf = zero_buf[n_int:].view(torch.float32)
         stats_all = f32_buf[:n_stats].view(torch.float64).view(len(layers), 256)
         dense_bufs = [None if lazy else b[:math.prod(sh)].view(sh) for b, sh in zip(f32_buf[n_stats:].split(dense_sizes), dense_shapes)]
         level_rows, level_shapes = [], []
@@ -351,6 +355,7 @@ class Network(nn.Module):
         self._sat_checked = None  # fc_0 weight key whose first fold build had its saturation count read (precision 'auto')
         self._planes_overflow = None  # ... and, if that count was not zero, the key again: 'auto' = 'f32' for these weights
         self.last_ill = None
+        self._pose_cache = None  # (R, Th, bounds tensors, versions, the 15-float pose block) of the last make_scene
         self._sat_pending = None  # (fc_0 key, counter tensor) of a later frame's planes, read at the next host synchronisation
         if int(xyz_res) != 10 or int(view_res) != 4:
             raise NotImplementedError(
@@ -379,7 +384,7 @@ class Network(nn.Module):
     def __getstate__(self):
         st = dict(self.__dict__)
         st.update(_packed=None, _packed_key=None, _packed_have=set(), _auto=None, _t_vals={}, _lb_cache=None, _foreign_fold=None,
-                  _sat_checked=None, _planes_overflow=None, _sat_pending=None, last_ill=None)
+                  _sat_checked=None, _planes_overflow=None, _sat_pending=None, last_ill=None, _pose_cache=None)
         return st
 
     def __deepcopy__(self, memo):
@@ -496,7 +501,20 @@ class Network(nn.Module):
         out_sh = [int(s) for s in sp_input["out_sh"]]
         fold = self._fold_planes(feature_volume, vols) if precision == "f16f6" else None
         dev = feature_volume.rows[0].device if lazy else vols[0].device
-        return ops.make_scene(vols, ops.make_pose(R, Th, bounds, device=dev), self.voxel_size, out_sh, fold=fold)
+        return ops.make_scene(vols, self._pose_block(R, Th, bounds, dev), self.voxel_size, out_sh, fold=fold)
+
+    def _pose_block(self, R, Th, bounds, dev):
+        """ops.make_pose, kept per (R, Th, bounds) tensor objects and versions: a loop over the views of one frame (and the two
+        make_scene calls of a prefetched render) builds the 15-float block once instead of one concatenation launch each time.  The
+        entry holds the tensors themselves, so an address cannot be recycled under the key (tests/test_gpu_frames.py)."""
+        c = self._pose_cache
+        if (c is not None and all(isinstance(t, torch.Tensor) for t in (R, Th, bounds)) and c[0] is R and c[1] is Th and c[2] is bounds
+                and c[3] == (R._version, Th._version, bounds._version, str(dev))):
+            return c[4]
+        pose = ops.make_pose(R, Th, bounds, device=dev)
+        if all(isinstance(t, torch.Tensor) for t in (R, Th, bounds)):
+            self._pose_cache = (R, Th, bounds, (R._version, Th._version, bounds._version, str(dev)), pose)
+        return pose
 
     def _fold_planes(self, feature_volume, vols):
         """(NbFold, keepalive) of the volumes: from the encoder's compact rows when the FeatureVolumes object carries them (no
@@ -577,8 +595,9 @@ class Network(nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def encode_sparse_voxels(self, sp_input, save=None):
-        coord = sp_input["coord"]
         B = int(sp_input.get("batch_size", 1))
+        c3 = sp_input.get("_coord_dhw") if B == 1 else None  # Renderer.prepare_sp_input: the [n, 3] tensor the [n, 4] one is built from
+        coord = c3 if c3 is not None else sp_input["coord"]  # (indexing 'coord' is what makes a lazily built sp_input concatenate it)
         if B != 1:
             # B > 1 frames = B independent passes (BatchNorm statistics per frame).  The reference itself cannot run this case:
             # it pairs ONE set of 6890 codes with the B * 6890 coordinates (latent_xyzc.py:35-36), which spconv indexes out of
@@ -588,10 +607,10 @@ class Network(nn.Module):
             if coord.dim() != 2 or coord.shape[0] % B:
                 raise ValueError("encode_sparse_voxels: coord %s does not hold equal row counts for %d frames" % (tuple(coord.shape), B))
             return BatchedFeatureVolumes([self.encode_sparse_voxels(frame_sp_input(sp_input, b)) for b in range(B)])
-        c3 = sp_input.get("_coord_dhw")  # Renderer.prepare_sp_input: the [n, 3] tensor the [n, 4] one was built from
-        if c3 is not None and c3.dim() == 2 and c3.shape == (coord.shape[0], 3) and c3.dtype == torch.int32 and c3.is_contiguous():
+        if c3 is not None and c3.dim() == 2 and c3.shape[1] == 3 and c3.dtype == torch.int32 and c3.is_contiguous():
             coord = c3
         else:
+            coord = sp_input["coord"]
             if coord.dim() == 2 and coord.shape[1] == 4:  # [N,4] = (batch idx, d, h, w), if_clight_renderer.py:33-38
                 coord = coord[:, 1:]
             coord = coord.reshape(-1, 3).to(torch.int32).contiguous()

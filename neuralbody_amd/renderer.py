@@ -28,6 +28,21 @@ class RenderConfig:
         self.mesh_th = float(mesh_th)  # lib/config/config.py:45; the shipped configs override it to 5
 
 
+class SpInput(dict):
+    """The sp_input dict of prepare_sp_input (if_clight_renderer.py:29-52) whose 'coord' entry — [B * n, 4] = (batch index, d, h, w),
+    a concatenation launch per frame — is built when somebody INDEXES it (`sp_input['coord']`, as the reference's
+    encode_sparse_voxels does, latent_xyzc.py:31): this package's encoder takes the [n, 3] coordinates themselves (`_coord_dhw`).
+    `in`, `get`, `keys` see the entry only once it exists, like any dict with a `__missing__`."""
+
+    def __missing__(self, key):
+        if key == "coord" and "_coord_parts" in self:
+            zc, coord = dict.__getitem__(self, "_coord_parts")
+            val = torch.cat([zc, coord], dim=1)
+            self[key] = val
+            return val
+        raise KeyError(key)
+
+
 class Renderer:
     def __init__(self, net, cfg=None):
         self.net = net
@@ -49,7 +64,7 @@ class Renderer:
 
     # -- if_clight_renderer.py:29-52
     def prepare_sp_input(self, batch):
-        sp_input = {}
+        sp_input = SpInput()
         sh = batch["coord"].shape
         # built on the coordinates' device: the reference makes these on the host and copies them over, and a copy from
         # pageable host memory makes the launch thread wait for everything already enqueued (the previous view's march) —
@@ -62,7 +77,7 @@ class Renderer:
             zc = getattr(self, "_zero_col", None)
             if zc is None or zc.shape[0] != sh[1] or zc.dtype != coord.dtype or zc.device != coord.device:
                 zc = self._zero_col = torch.zeros((sh[1], 1), dtype=coord.dtype, device=coord.device)
-            sp_input["coord"] = torch.cat([zc, coord], dim=1)
+            sp_input["_coord_parts"] = (zc, coord)  # 'coord' itself: SpInput.__missing__, on first use
             sp_input["_coord_dhw"] = coord
         else:
             idx = [torch.full([sh[1]], i, dtype=coord.dtype, device=coord.device) for i in range(sh[0])]
@@ -305,7 +320,7 @@ class Renderer:
             return None
         if len(st["slots"]) < self.ENCODER_GRAPH_SLOTS:
             g = torch.cuda.CUDAGraph()
-            sp = dict(sp_input)
+            sp = type(sp_input)(sp_input)
             pend = getattr(self.net, "_sat_pending", None)
             with torch.cuda.graph(g, stream=side):
                 fv = self._encode_for_ticket(sp)
