@@ -223,3 +223,26 @@ def test_bench_names_a_world_size_mismatch():
     out = _bench(["--gpus", "2", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
                                                 "MASTER_PORT": str(_free_port())})
     assert out.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in out.stderr
+
+
+def test_balanced_band_cuts_properties():
+    """For any band histogram and world size: the cuts are monotone band borders from 0 to the last band, and no rank's ray count
+    is further from the ideal n / world than the largest band (the best whole bands allow, up to the nearest-border rule)."""
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.lists(st.integers(min_value=0, max_value=5000), min_size=1, max_size=80), st.integers(min_value=1, max_value=16))
+    def check(per_band, world):
+        cum = [0]
+        for v in per_band:
+            cum.append(cum[-1] + v)
+        cuts = parallel.balanced_band_cuts(cum, world)
+        assert len(cuts) == world + 1 and cuts[0] == 0 and cuts[-1] == len(per_band)
+        assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+        total, biggest = cum[-1], max(per_band)
+        for r in range(1, world):
+            assert abs(cum[cuts[r]] - total * r / world) <= biggest / 2 + 1e-9 or cuts[r] in (cuts[r - 1],)  # nearest border (or pinned by monotonicity)
+        sizes = [cum[cuts[r + 1]] - cum[cuts[r]] for r in range(world)]
+        assert sum(sizes) == total and all(sz <= total / world + biggest + 1e-9 for sz in sizes)
+
+    check()

@@ -248,3 +248,26 @@ def test_zero_arena_hands_out_zeroed_aligned_views():
     assert float(views[1].abs().sum()) == 0.0 and float(views[2].abs().sum()) == 0.0  # the views do not overlap
     with pytest.raises(RuntimeError):
         arena.take((1,))
+
+
+def test_sp_input_builds_the_reference_coord_layout_on_first_use():
+    """prepare_sp_input (if_clight_renderer.py:29-52) for batch size 1: the [n, 4] = (batch index, d, h, w) tensor the reference's
+    encode_sparse_voxels indexes is a concatenation launch per frame that this package's encoder never reads (it takes the [n, 3]
+    coordinates, `_coord_dhw`) — `SpInput` builds it when somebody indexes 'coord', once, and is a dict otherwise."""
+    from neuralbody_amd.renderer import SpInput
+
+    r = _renderer(8, 8)
+    b = _batch()
+    sp = r.prepare_sp_input(b)
+    assert isinstance(sp, SpInput) and isinstance(sp, dict)
+    assert "coord" not in sp and sp.get("coord") is None and "_coord_dhw" in sp
+    assert torch.equal(sp["_coord_dhw"], b["coord"].view(-1, 3))
+    c = sp["coord"]  # the reference's access
+    assert c.shape == (10, 4) and int(c[:, 0].abs().sum()) == 0 and torch.equal(c[:, 1:], b["coord"].view(-1, 3)) and c.dtype == b["coord"].dtype
+    assert "coord" in sp and sp["coord"] is c  # built once
+    cp = type(sp)(sp)  # a copy keeps the behaviour (the graph-captured prefetch copies its sp_input)
+    assert isinstance(cp, SpInput) and cp["coord"] is c
+    with pytest.raises(KeyError):
+        sp["no such key"]
+    for k in ("out_sh", "batch_size", "bounds", "R", "Th", "latent_index"):
+        assert k in sp
