@@ -406,25 +406,43 @@ __global__ void nb_pack_kernel(nb_mlp_params p, float *__restrict__ out) {
 // out[0..255]: bias of the merged feature_fc / latent_fc layer, MFMA fragment order [tile][hi][16];
 // out[256..383]: bias of view_fc with that whole (activation-free) layer pair folded in, i.e. view_b + view_w[:, :256] . (the
 // former), same order — for the kernels that run feature_fc, latent_fc and view_fc as ONE linear layer (nb_march_fold.hip)
-__global__ void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__ latent_row, float *__restrict__ out) {
+// One workgroup for the 256 outputs of the merged layer + one per output of the view layer (round 6: a single workgroup walked both
+// stages in 34 us — the kernel sits between the encoder and the march of every new frame and in every training step; 129 workgroups:
+// 18.6 us, bound by the uncoalesced row reads of the first stage: 9 workgroups or 16-byte loads measured 21-22).  Every workgroup forms
+// the merged layer's bias lbn[m] = latent_b[m] + latent_w[m, :256] . feature_b + latent_w[m, 256:] . latent_row in fp64 (thread m:
+// 384 FMAs in two chains), block 0 writes it out, block 1 + q folds it through row q of view_w[:, :256].
+__global__ __launch_bounds__(256) void nb_latent_bias_kernel(nb_mlp_params p, const float *__restrict__ latent_row, float *__restrict__ out) {
     __shared__ double lbn[256];  // natural order
-    const int rel = threadIdx.x;  // [t][hi][16]
+    __shared__ double part[4];
+    const int rel = threadIdx.x;
     {
         const int row = rel;
-        double s = (double)p.latent_b[row];
-        for (int m = 0; m < 256; ++m) s += (double)p.latent_w[row * 384 + m] * (double)p.feature_b[m];
-        for (int m = 0; m < 128; ++m) s += (double)p.latent_w[row * 384 + 256 + m] * (double)latent_row[m];
-        lbn[row] = s;
+        double s0 = (double)p.latent_b[row], s1 = 0.0;
+        for (int m = 0; m < 256; m += 2) {
+            s0 += (double)p.latent_w[row * 384 + m] * (double)p.feature_b[m];
+            s1 += (double)p.latent_w[row * 384 + m + 1] * (double)p.feature_b[m + 1];
+        }
+        for (int m = 0; m < 128; m += 2) {
+            s0 += (double)p.latent_w[row * 384 + 256 + m] * (double)latent_row[m];
+            s1 += (double)p.latent_w[row * 384 + 256 + m + 1] * (double)latent_row[m + 1];
+        }
+        lbn[row] = s0 + s1;
     }
     __syncthreads();
-    const int r = rel & 15, hi = (rel >> 4) & 1, t = rel >> 5;
-    const int row = 32 * t + tile_row(r, hi);
-    out[rel] = (float)lbn[row];
-    if (rel < 128) {  // t < 4: the 128 outputs of view_fc
-        double s = (double)p.view_b[row];
-        for (int m = 0; m < 256; ++m) s += (double)p.view_w[row * 346 + m] * lbn[m];
-        out[256 + rel] = (float)s;
+    if (blockIdx.x == 0) {  // [t][hi][16] fragment order
+        const int r = rel & 15, hi = (rel >> 4) & 1, t = rel >> 5;
+        out[rel] = (float)lbn[32 * t + tile_row(r, hi)];
+        return;
     }
+    const int q = blockIdx.x - 1;  // position in fragment order of the view layer's 128 outputs
+    const int r = q & 15, hi = (q >> 4) & 1, t = q >> 5;
+    const int row = 32 * t + tile_row(r, hi);
+    double v = (double)p.view_w[row * 346 + rel] * lbn[rel];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if ((rel & 63) == 0) part[rel >> 6] = v;
+    __syncthreads();
+    if (rel == 0) out[256 + q] = (float)((double)p.view_b[row] + ((part[0] + part[1]) + (part[2] + part[3])));
 }
 
 }  // namespace
@@ -463,7 +481,7 @@ int nb_mlp_pack_sections(const nb_mlp_params *p, float *packed, int sections, vo
 int nb_mlp_latent_bias(const nb_mlp_params *p, const float *latent_row, float *out, void *stream) {
     if (int rc = check_params(p)) return rc;
     NB_REQUIRE(latent_row && out, "nb_mlp_latent_bias: NULL pointer");
-    hipLaunchKernelGGL(nb_latent_bias_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *p, latent_row, out);
+    hipLaunchKernelGGL(nb_latent_bias_kernel, dim3(1 + 128), dim3(256), 0, (hipStream_t)stream, *p, latent_row, out);
     NB_CHECK_LAUNCH("nb_latent_bias_kernel");
     return NB_OK;
 }
