@@ -259,6 +259,9 @@ class Renderer:
         dev = batch["coord"].device
         if dev.type != "cuda":
             raise RuntimeError("Renderer.prefetch needs device tensors")
+        if batch["coord"].dim() == 3 and batch["coord"].shape[0] != 1:
+            raise NotImplementedError("Renderer.prefetch takes ONE frame (a batch of B > 1 frames is rendered frame by frame: prefetch "
+                                      "each frame's batch, or call render() without a ticket)")
         side = getattr(self, "_side_stream", None)
         if side is None or side.device != dev:
             side = self._side_stream = torch.cuda.Stream(device=dev)

@@ -260,6 +260,8 @@ def test_a_batch_of_two_frames_matches_the_reference_frame_by_frame(precision):
     H.assert_close(again["rgb_map"].cpu().numpy(), out["rgb_map"].cpu().numpy(), 2e-5, "re-render from the batch's volumes")
     # the reference API on the batch: four [B,C,D,H,W] volumes at the common out_sh, and the point decoder frame by frame
     assert isinstance(vols, BatchedFeatureVolumes) and sp["batch_size"] == 2
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="ONE frame"):
+        rend.prefetch(bd)
     D, Hh, W = sp["out_sh"]
     assert [tuple(v.shape) for v in vols] == [(2, c, D >> (l + 1), Hh >> (l + 1), W >> (l + 1)) for l, c in enumerate((32, 64, 128, 128))]
     wpts, z = rend.get_sampling_points(bd["ray_o"][:, ::16], bd["ray_d"][:, ::16], bd["near"][:, ::16], bd["far"][:, ::16])
