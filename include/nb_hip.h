@@ -225,7 +225,7 @@ typedef struct nb_cull {
  *           the last sample again and rewrites the ray's rgb / disp / acc / depth, weights[n_samples - 1] and raw[n_samples - 1][3].
  *           No host read-back.  Afterwards the scratch starts with int32 {rays listed (may exceed cap: the excess keeps the
  *           march's result), rays whose step changed side}.  The call zeroes that header itself.  NULL: the march's result as is.
- *           The bench view lists ~50 of its 262 144 rays (~10 us); a cap of a few thousand covers any trained scene, whose empty
+ *           The bench view lists ~50 of its 262 144 rays (~20 us); a cap of a few thousand covers any trained scene, whose empty
  *           space has a strongly negative density — only a decoder whose density is ~0 over whole regions lists rays by the
  *           thousand (12 533 listed rays: +0.5 ms), which is what the cap bounds.
  * ------------------------------------------------------------------------------- */
